@@ -1,0 +1,96 @@
+// Shared device/host helpers for the EGM-UNet HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/egm_hip.h"
+
+// ---------------------------------------------------------------- error handling
+void egm_set_error(const char* fmt, ...);
+#define EGM_FAIL(code, ...) do { egm_set_error(__VA_ARGS__); return (code); } while (0)
+#define EGM_REQUIRE(cond, ...) do { if (!(cond)) EGM_FAIL(EGM_ERR_ARG, __VA_ARGS__); } while (0)
+#define EGM_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)
+
+static inline bool egm_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int egm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- bf16 storage type
+struct bf16_t { uint16_t v; };
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest-even, NaN stays NaN
+    __bf16 h = (__bf16)f;
+    return *reinterpret_cast<uint16_t*>(&h);
+}
+
+template <typename T> struct TypeInfo;
+template <> struct TypeInfo<float>  { static constexpr int kDtype = EGM_F32;  static constexpr int kVec = 4; };
+template <> struct TypeInfo<bf16_t> { static constexpr int kDtype = EGM_BF16; static constexpr int kVec = 8; };
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return bf16_to_f32(x.v); }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { bf16_t r; r.v = f32_to_bf16(x); return r; }
+
+// 8 consecutive channels <-> 8 floats (the unit every NHWC elementwise kernel works in; C % 8 == 0 always)
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+    uint4 a = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    uint4 a;
+    a.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    a.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    a.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+    a.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = a;
+}
+__device__ __forceinline__ void zero8(float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+}
+
+// ---------------------------------------------------------------- wave / block reductions (wave = 64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// Sum over a whole block (blockDim.x multiple of 64, <= 1024). `red` = 16 floats of LDS. Result valid in every thread.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// dtype dispatch for host launchers: body sees `T`
+#define EGM_DISPATCH_DTYPE(dtype, ...) \
+    do { if ((dtype) == EGM_F32) { using T = float; __VA_ARGS__; } \
+         else if ((dtype) == EGM_BF16) { using T = bf16_t; __VA_ARGS__; } \
+         else EGM_FAIL(EGM_ERR_ARG, "unknown dtype %d", (int)(dtype)); } while (0)

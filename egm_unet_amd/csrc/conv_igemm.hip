@@ -1,0 +1,313 @@
+// Implicit-GEMM convolution for NHWC activations on CDNA4 matrix cores.
+//
+//   y[n,oy,ox,co] = bias[co] + sum_{r,s,ci} x[n, oy+(r-KH/2)*dil, ox+(s-KW/2)*dil, ci] * wf[r*KW+s][co][ci]
+//
+// replaces nn.Conv2d (stride 1, 'same' zero padding) at src/EGM-UNet.py:49,52,893,899 (3x3 U-Net stacks),
+// :964 (BasicConv 1x1 / dilated 3x3), :1210-1218 (FusionConv 1x1/3x3/5x5/7x7) and, with the flipped/transposed
+// pack `wd`, their data gradients.
+//
+// Work decomposition (wave64, 4 waves per workgroup):
+//   * one workgroup = an 8x32 pixel tile of one image x (NT*32) output channels;
+//     wave w owns tile rows 2w, 2w+1 (two 32-pixel MFMA row blocks) x NT column blocks.
+//   * K loop = input-channel chunks of KC=32; per chunk the (8+KH-1)x(32+KW-1) halo patch is staged ONCE in LDS
+//     and reused by all KH*KW taps (so HBM/L2 traffic is 1x, not 9x); weights of the chunk are staged per
+//     "tap stage" (all taps when they fit, else one kernel row at a time).
+//   * dilated convs (dil>1: 12/24/36 in EdgeEnhancedGRFB) have no halo reuse: they run as KH*KW shifted 1x1
+//     passes over the same accumulators, and passes whose shifted tile lies wholly outside the image are skipped.
+//   * LDS rows are padded (bf16: 64+16 B, f32: 128+4 B) so fragment reads are bank-conflict free.
+//   * blockIdx -> (pixel tile, cout tile) mapping keeps all cout tiles of a pixel tile on one XCD (b % 8),
+//     so the patch re-reads of sibling cout tiles hit that XCD's L2.
+//   * epilogue: +bias, convert, store; optional per-tile per-channel sum / sum-of-squares partials for
+//     train-mode BatchNorm (deterministic: plain stores, reduced by egm_bn_finalize).
+//
+// bf16: v_mfma_f32_32x32x16_bf16 (A = pixels x k, B = k x couts, fp32 accumulate)
+// f32 : v_mfma_f32_32x32x2_f32   (exact fp32 FMA chain; the parity path)
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+namespace {
+
+constexpr int TH = 8, TW = 32, KC = 32;
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static constexpr int kStep = 16;                 // k per MFMA
+    static constexpr int kPixStride = KC * 2 + 16;   // bytes per LDS row (pixel or cout)
+    using Frag = bf16x8_t;
+    static __device__ __forceinline__ Frag load(const unsigned char* row, int ks, int h) {
+        return *reinterpret_cast<const Frag*>(row + ks * 32 + h * 16);
+    }
+    static __device__ __forceinline__ f32x16_t mma(Frag a, Frag b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void stage16(unsigned char* dst, const bf16_t* src, bool ok) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ok) v = *reinterpret_cast<const uint4*>(src);
+        *reinterpret_cast<uint4*>(dst) = v;
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int kStep = 2;
+    static constexpr int kPixStride = KC * 4 + 4;
+    using Frag = float;
+    static __device__ __forceinline__ Frag load(const unsigned char* row, int ks, int h) {
+        return *reinterpret_cast<const float*>(row + (ks * 2 + h) * 4);
+    }
+    static __device__ __forceinline__ f32x16_t mma(Frag a, Frag b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void stage16(unsigned char* dst, const float* src, bool ok) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float4*>(src);
+        float* d = reinterpret_cast<float*>(dst);     // row stride 132 B: only 4-byte aligned
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+};
+
+struct ConvParams {
+    const void* x; const void* w; const float* bias; void* y; float* stats;
+    int ldx, ldy, N, H, W, Cin, Cout, KH, KW, dil, bias_n;
+    int tiles_y, tiles_x, npt, nct;
+    int wrows_per_stage;          // kernel rows whose weights are staged together (halo mode)
+    int patch_bytes;
+};
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using M = Mma<T>;
+    constexpr int VEC = 16 / sizeof(T);               // elements per 16-byte vector
+    constexpr int NVPP = KC / VEC;                    // vectors per LDS row
+    constexpr int PS = M::kPixStride;
+
+    // ---- block -> (pixel tile, cout tile), XCD-aware
+    const int b = blockIdx.x, q = b >> 3;
+    const int ct = q % p.nct;
+    const int pt = (q / p.nct) * 8 + (b & 7);
+    if (pt >= p.npt) return;
+    const int tpi = p.tiles_y * p.tiles_x;
+    const int n = pt / tpi, trem = pt - n * tpi;
+    const int oy0 = (trem / p.tiles_x) * TH, ox0 = (trem % p.tiles_x) * TW;
+    const int co0 = ct * NT * 32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r31 = lane & 31, h = lane >> 5;
+    const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ wg = reinterpret_cast<const T*>(p.w);
+
+    const bool halo = (p.dil == 1);
+    const int ngroups = halo ? 1 : p.KH * p.KW;
+    const int wh = halo ? p.KH : 1, ww = halo ? p.KW : 1;
+    const int PH = TH + wh - 1, PW = TW + ww - 1;
+    unsigned char* patch = smem;
+    unsigned char* wts = smem + p.patch_bytes;
+    const int rows_per_stage = halo ? p.wrows_per_stage : 1;
+
+    f32x16_t acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.f;
+
+    for (int g = 0; g < ngroups; ++g) {
+        int offy, offx, tapbase;
+        if (halo) { offy = -(p.KH / 2); offx = -(p.KW / 2); tapbase = 0; }
+        else {
+            offy = (g / p.KW - p.KH / 2) * p.dil; offx = (g % p.KW - p.KW / 2) * p.dil; tapbase = g;
+            // shifted tile entirely outside the image -> contributes only zeros (block-uniform test)
+            if (oy0 + offy >= p.H || oy0 + offy + TH <= 0 || ox0 + offx >= p.W || ox0 + offx + TW <= 0) continue;
+        }
+        for (int c0 = 0; c0 < p.Cin; c0 += KC) {
+            const int kc = min(KC, p.Cin - c0);
+            const int nks = (kc + M::kStep - 1) / M::kStep;
+            __syncthreads();                                   // everyone done reading the previous patch/weights
+            // ---- stage the input patch (zero-filled outside the image / beyond Cin)
+            for (int i = tid; i < PH * PW * NVPP; i += 256) {
+                const int pix = i / NVPP, v = i - pix * NVPP;
+                const int py = pix / PW, px = pix - py * PW;
+                const int iy = oy0 + offy + py, ix = ox0 + offx + px, c = c0 + v * VEC;
+                const bool ok = (iy >= 0) && (iy < p.H) && (ix >= 0) && (ix < p.W) && (c < p.Cin);
+                const T* src = xg + ((long long)(n * p.H + iy) * p.W + ix) * p.ldx + c;
+                M::stage16(patch + pix * PS + v * 16, src, ok);
+            }
+            for (int wr0 = 0; wr0 < wh; wr0 += rows_per_stage) {
+                const int nrows = min(rows_per_stage, wh - wr0);
+                const int ntaps = nrows * ww;
+                if (wr0 > 0) __syncthreads();                  // previous weight stage consumed
+                // ---- stage weights of taps [wr0*ww, wr0*ww+ntaps) x NT*32 couts x KC
+                for (int i = tid; i < ntaps * NT * 32 * NVPP; i += 256) {
+                    const int row = i / NVPP, v = i - row * NVPP;
+                    const int t = row / (NT * 32), j = row - t * (NT * 32);
+                    const int co = co0 + j, c = c0 + v * VEC;
+                    const int tap = tapbase + wr0 * ww + t;
+                    const bool ok = (co < p.Cout) && (c < p.Cin);
+                    const T* src = wg + ((long long)tap * p.Cout + co) * p.Cin + c;
+                    M::stage16(wts + row * PS + v * 16, src, ok);
+                }
+                __syncthreads();
+                // ---- MFMA over the staged taps
+                for (int t = 0; t < ntaps; ++t) {
+                    const int wr = wr0 + t / ww, ws = t - (t / ww) * ww;
+                    const unsigned char* a0 = patch + ((2 * wv + 0 + wr) * PW + r31 + ws) * PS;
+                    const unsigned char* a1 = patch + ((2 * wv + 1 + wr) * PW + r31 + ws) * PS;
+                    const unsigned char* b0 = wts + (t * NT * 32 + r31) * PS;
+                    for (int ks = 0; ks < nks; ++ks) {
+                        const typename M::Frag fa0 = M::load(a0, ks, h), fa1 = M::load(a1, ks, h);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const typename M::Frag fb = M::load(b0 + nt * 32 * PS, ks, h);
+                            acc[0][nt] = M::mma(fa0, fb, acc[0][nt]);
+                            acc[1][nt] = M::mma(fa1, fb, acc[1][nt]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col (cout) = lane&31, row (pixel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    T* __restrict__ yg = reinterpret_cast<T*>(p.y);
+    float ssum[NT], ssq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { ssum[nt] = 0.f; ssq[nt] = 0.f; }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = co0 + nt * 32 + r31;
+        const bool cok = co < p.Cout;
+        const float bv = (p.bias != nullptr && co < p.bias_n) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int oy = oy0 + 2 * wv + m;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ox = ox0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (cok && oy < p.H && ox < p.W) {
+                    const T o = from_f32<T>(acc[m][nt][i] + bv);
+                    yg[((long long)(n * p.H + oy) * p.W + ox) * p.ldy + co] = o;
+                    const float f = to_f32(o);
+                    ssum[nt] += f; ssq[nt] += f * f;
+                }
+            }
+        }
+    }
+    if (p.stats != nullptr) {
+        __syncthreads();                                       // LDS is free again
+        float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][NT*32]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float s = ssum[nt] + __shfl_xor(ssum[nt], 32, 64);
+            const float qq = ssq[nt] + __shfl_xor(ssq[nt], 32, 64);
+            if (h == 0) {
+                red[(wv * 2 + 0) * NT * 32 + nt * 32 + r31] = s;
+                red[(wv * 2 + 1) * NT * 32 + nt * 32 + r31] = qq;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * NT * 32) {
+            const int which = tid / (NT * 32), j = tid - which * NT * 32;
+            const int co = co0 + j;
+            if (co < p.Cout) {
+                float v = 0.f;
+                for (int w4 = 0; w4 < 4; ++w4) v += red[(w4 * 2 + which) * NT * 32 + j];
+                p.stats[((long long)pt * 2 + which) * p.Cout + co] = v;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// weight packing: fp32 OIHW (grouped) -> dense T [taps][CoutP][CinP] (fwd) and [taps flipped][CinP][CoutP] (dgrad)
+template <typename T>
+__global__ void conv_pack_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Cout, int Cin,
+                                 int CoutP, int CinP, int KH, int KW, int groups) {
+    const long long total = (long long)KH * KW * CoutP * CinP;
+    const int cin_g = Cin / groups, cout_g = Cout / groups;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % CinP);
+        const int co = (int)((i / CinP) % CoutP);
+        const int tap = (int)(i / ((long long)CinP * CoutP));
+        float v = 0.f;
+        if (co < Cout && ci < Cin && (co / cout_g) == (ci / cin_g)) {
+            const int r = tap / KW, s = tap % KW;
+            v = w[(((long long)co * cin_g + (ci % cin_g)) * KH + r) * KW + s];
+        }
+        if (wf != nullptr) wf[i] = from_f32<T>(v);
+        if (wd != nullptr) {
+            const int ftap = KH * KW - 1 - tap;
+            wd[((long long)ftap * CinP + ci) * CoutP + co] = from_f32<T>(v);
+        }
+    }
+}
+
+template <typename T, int NT>
+int launch_conv(const ConvParams& p, size_t smem, hipStream_t st) {
+    static bool attr_done = false;      // >64 KiB dynamic LDS needs an opt-in; done once per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<T, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_igemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    const int grid = ((p.npt + 7) / 8) * 8 * p.nct;
+    hipLaunchKernelGGL((conv_igemm_kernel<T, NT>), dim3(grid), dim3(256), smem, st, p);
+    EGM_CHECK_LAUNCH("conv_igemm");
+    return EGM_OK;
+}
+
+}  // namespace
+
+extern "C" int egm_conv_stats_tiles(int N, int H, int W) { return N * egm_cdiv(H, TH) * egm_cdiv(W, TW); }
+
+extern "C" int egm_conv_pack(int dtype, const void* w, void* wf, void* wd, int Cout, int Cin, int KH, int KW, int groups,
+                             egm_stream_t s) {
+    EGM_REQUIRE(w != nullptr && (wf != nullptr || wd != nullptr), "conv_pack: null pointer");
+    EGM_REQUIRE(Cout > 0 && Cin > 0 && groups > 0 && Cout % groups == 0 && Cin % groups == 0, "conv_pack: bad channels/groups");
+    EGM_REQUIRE(KH > 0 && KW > 0 && (KH & 1) && (KW & 1), "conv_pack: kernel must be odd");
+    const int CoutP = (Cout + 7) / 8 * 8, CinP = (Cin + 7) / 8 * 8;
+    const long long total = (long long)KH * KW * CoutP * CinP;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)s,
+                                                 (const float*)w, (T*)wf, (T*)wd, Cout, Cin, CoutP, CinP, KH, KW, groups));
+    EGM_CHECK_LAUNCH("conv_pack");
+    return EGM_OK;
+}
+
+extern "C" int egm_conv_fwd(int dtype, const void* x, int ldx, const void* wf, const void* bias, int bias_n, void* y, int ldy,
+                            float* stats, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, egm_stream_t s) {
+    EGM_REQUIRE(x && wf && y, "conv_fwd: null pointer");
+    EGM_REQUIRE(!bias || (bias_n > 0 && bias_n <= Cout), "conv_fwd: bad bias_n %d", bias_n);
+    EGM_REQUIRE(N > 0 && H > 0 && W > 0, "conv_fwd: bad shape N=%d H=%d W=%d", N, H, W);
+    EGM_REQUIRE(Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, "conv_fwd: Cin=%d/Cout=%d must be multiples of 8", Cin, Cout);
+    EGM_REQUIRE(ldx >= Cin && ldy >= Cout && ldx % 8 == 0 && ldy % 8 == 0, "conv_fwd: bad ld (ldx=%d ldy=%d)", ldx, ldy);
+    EGM_REQUIRE((KH & 1) && (KW & 1) && KH <= 7 && KW <= 7 && dil >= 1, "conv_fwd: unsupported kernel %dx%d dil %d", KH, KW, dil);
+    EGM_REQUIRE(egm_aligned16(x) && egm_aligned16(wf) && egm_aligned16(y), "conv_fwd: pointers must be 16-byte aligned");
+    EGM_REQUIRE((long long)N * H * W * (long long)(ldx > ldy ? ldx : ldy) < (1LL << 40), "conv_fwd: tensor too large");
+    if (KH == 1 && KW == 1) dil = 1;
+
+    ConvParams p;
+    p.x = x; p.w = wf; p.bias = (const float*)bias; p.y = y; p.stats = stats;
+    p.ldx = ldx; p.ldy = ldy; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.dil = dil; p.bias_n = bias ? bias_n : 0;
+    p.tiles_y = egm_cdiv(H, TH); p.tiles_x = egm_cdiv(W, TW); p.npt = N * p.tiles_y * p.tiles_x;
+    const int NT = (Cout > 32) ? 2 : 1;
+    p.nct = egm_cdiv(Cout, NT * 32);
+    const int ps = (dtype == EGM_BF16) ? Mma<bf16_t>::kPixStride : Mma<float>::kPixStride;
+    const bool halo = (dil == 1);
+    const int wh = halo ? KH : 1, ww = halo ? KW : 1;
+    int patch = (TH + wh - 1) * (TW + ww - 1) * ps;
+    patch = (patch + 15) / 16 * 16;
+    p.patch_bytes = patch;
+    // stage all taps if the weight slab stays <= 48 KiB, else one kernel row at a time
+    const int row_bytes = ww * NT * 32 * ps;
+    p.wrows_per_stage = (wh * row_bytes <= 48 * 1024) ? wh : 1;
+    size_t smem = (size_t)patch + (size_t)p.wrows_per_stage * row_bytes;
+    const size_t red_bytes = 4 * 2 * NT * 32 * sizeof(float);
+    if (smem < red_bytes) smem = red_bytes;
+    EGM_REQUIRE(smem <= 160 * 1024, "conv_fwd: LDS budget exceeded (%zu)", smem);
+    hipStream_t st = (hipStream_t)s;
+    if (dtype == EGM_BF16) return NT == 2 ? launch_conv<bf16_t, 2>(p, smem, st) : launch_conv<bf16_t, 1>(p, smem, st);
+    if (dtype == EGM_F32) return NT == 2 ? launch_conv<float, 2>(p, smem, st) : launch_conv<float, 1>(p, smem, st);
+    EGM_FAIL(EGM_ERR_ARG, "conv_fwd: unknown dtype %d", dtype);
+}

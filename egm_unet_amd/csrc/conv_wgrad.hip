@@ -1,0 +1,294 @@
+// Weight-gradient convolution for NHWC activations on CDNA4 matrix cores.
+//
+//   dW[co][ci][r][s] = sum_{n,oy,ox} dy[n,oy,ox,co] * x[n, oy+(r-KH/2)*dil, ox+(s-KW/2)*dil, ci]
+//
+// (the weight half of autograd's convolution_backward for every nn.Conv2d of src/EGM-UNet.py; see conv_igemm.hip).
+//
+// GEMM view per tap: M = cout, N = cin, K = pixels.  Both operands are channel-contiguous in memory (NHWC) while
+// the MFMA wants K(pixel)-contiguous fragments, so the bf16 path reads its fragments with the gfx950 transposing
+// LDS read ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group); the f32 path uses v_mfma_f32_32x32x2_f32
+// whose fragments are single elements and need no transpose.
+//
+// Decomposition:
+//   * a workgroup (4 waves) owns a (32*A couts) x (32*B cins) block of dW for one tap group and a strided subset
+//     ("split") of the 8x32 pixel tiles; inside the workgroup the 4 waves are split A x B x C with C waves sharing
+//     a dW block and taking alternate tile rows (A*B*C = 4).
+//   * tap group = NTAPS taps that share one staged halo patch: 3x3 (dil 1) -> all 9; 1xKW rows for 5x5/7x7;
+//     single taps for 1x1 and for dilated convs.  Each wave keeps NTAPS 32x32 fp32 accumulators in registers for
+//     the whole pixel loop, so dy fragments are read once per k-step and reused by every tap.
+//   * LDS images are [32-channel block][pixel][32 channels] (64-byte bf16 rows) -> every tr-read/row read touches
+//     4 consecutive rows = all 64 banks once: conflict-free, no padding.
+//   * partial blocks go to a slab [split*C][tap][CoutP][CinP] with plain stores; a second kernel sums the slabs in
+//     fixed order (bitwise reproducible) and scatters into the fp32 OIHW gradient.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+namespace {
+
+constexpr int TH = 8, TW = 32;
+
+template <typename T> struct WMma;
+template <> struct WMma<bf16_t> {
+    static constexpr int kStep = 16;          // pixels per MFMA
+    static constexpr int kRowBytes = 64;      // 32 channels
+    using Frag = bf16x8_t;
+    // blk: LDS [pixel][32 ch] block; returns rows(channel) l&31, k = pixels pix0 + 8*(l>>5) + 0..7
+    static __device__ __forceinline__ Frag load(const unsigned char* blk, int pix0, int lane) {
+        const int gq = lane >> 4, t = lane & 15;
+        const unsigned char* a = blk + (pix0 + 8 * (gq >> 1) + (t >> 2)) * 64 + ((gq & 1) * 16 + 4 * (t & 3)) * 2;
+        typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(a));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(a + 4 * 64));
+        s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(Frag, v);
+    }
+    static __device__ __forceinline__ f32x16_t mma(Frag a, Frag b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct WMma<float> {
+    static constexpr int kStep = 2;
+    static constexpr int kRowBytes = 128;
+    using Frag = float;
+    static __device__ __forceinline__ Frag load(const unsigned char* blk, int pix0, int lane) {
+        return *reinterpret_cast<const float*>(blk + (pix0 + (lane >> 5)) * 128 + (lane & 31) * 4);
+    }
+    static __device__ __forceinline__ f32x16_t mma(Frag a, Frag b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+};
+
+struct WgradParams {
+    const void* x; const void* dy; float* slab;
+    int ldx, lddy, N, H, W, Cin, Cout, KH, KW, dil;
+    int tiles_y, tiles_x, npt, nsplit;
+    int A, B, C;                 // wave split: couts x cins x pixel rows
+    int nci_tiles;               // ceil(Cin / (32*B))
+    int ngroups;                 // tap groups
+};
+
+template <int NTAPS> struct Window;   // staged window of a tap group
+template <> struct Window<9> { static constexpr int WH = 3, WW = 3; };
+template <> struct Window<7> { static constexpr int WH = 1, WW = 7; };
+template <> struct Window<5> { static constexpr int WH = 1, WW = 5; };
+template <> struct Window<1> { static constexpr int WH = 1, WW = 1; };
+
+template <typename T, int NTAPS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using M = WMma<T>;
+    constexpr int WH = Window<NTAPS>::WH, WW = Window<NTAPS>::WW;
+    constexpr int PH = TH + WH - 1, PW = TW + WW - 1;
+    constexpr int RB = M::kRowBytes;
+    constexpr int VEC = 16 / sizeof(T);           // elements per 16-byte vector
+    constexpr int VPR = 32 / VEC;                 // vectors per 32-channel row
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wa = wv % p.A, wb = (wv / p.A) % p.B, wc = wv / (p.A * p.B);
+    const int split = blockIdx.x;
+    const int cot = blockIdx.y / p.nci_tiles, cit = blockIdx.y % p.nci_tiles;
+    const int grp = blockIdx.z;
+    const int co_base = cot * 32 * p.A, ci_base = cit * 32 * p.B;
+
+    // tap group geometry: offset of the staged window relative to the output pixel, first tap index
+    int offy, offx, tap0;
+    if (p.dil == 1) {
+        if (NTAPS == 9 || NTAPS == 1) { offy = -(p.KH / 2); offx = -(p.KW / 2); tap0 = 0; }
+        else { offy = grp - p.KH / 2; offx = -(p.KW / 2); tap0 = grp * p.KW; }        // one kernel row
+    } else {
+        offy = (grp / p.KW - p.KH / 2) * p.dil; offx = (grp % p.KW - p.KW / 2) * p.dil; tap0 = grp;
+    }
+
+    unsigned char* dyl = smem;                                   // [A][256 px][32 ch]
+    unsigned char* xl = smem + p.A * (TH * TW) * RB;             // [B][PH*PW px][32 ch]
+    const T* __restrict__ xg = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ dyg = reinterpret_cast<const T*>(p.dy);
+
+    f32x16_t acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    const int tpi = p.tiles_y * p.tiles_x;
+    for (int pt = split; pt < p.npt; pt += p.nsplit) {
+        const int n = pt / tpi, trem = pt - n * tpi;
+        const int oy0 = (trem / p.tiles_x) * TH, ox0 = (trem % p.tiles_x) * TW;
+        if (p.dil > 1 &&   // shifted tile wholly outside the image: zero contribution (block-uniform)
+            (oy0 + offy >= p.H || oy0 + offy + TH <= 0 || ox0 + offx >= p.W || ox0 + offx + TW <= 0)) continue;
+        __syncthreads();
+        // ---- stage dy tile: [A blocks][256 px][32 ch]
+        for (int i = tid; i < p.A * TH * TW * VPR; i += 256) {
+            const int v = i % VPR, pix = (i / VPR) % (TH * TW), blk = i / (VPR * TH * TW);
+            const int oy = oy0 + pix / TW, ox = ox0 + pix % TW, c = co_base + blk * 32 + v * VEC;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (oy < p.H && ox < p.W && c < p.Cout)
+                val = *reinterpret_cast<const uint4*>(dyg + ((long long)(n * p.H + oy) * p.W + ox) * p.lddy + c);
+            *reinterpret_cast<uint4*>(dyl + (blk * TH * TW + pix) * RB + v * 16) = val;
+        }
+        // ---- stage x patch: [B blocks][PH*PW px][32 ch]
+        for (int i = tid; i < p.B * PH * PW * VPR; i += 256) {
+            const int v = i % VPR, pix = (i / VPR) % (PH * PW), blk = i / (VPR * PH * PW);
+            const int iy = oy0 + offy + pix / PW, ix = ox0 + offx + pix % PW, c = ci_base + blk * 32 + v * VEC;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.Cin)
+                val = *reinterpret_cast<const uint4*>(xg + ((long long)(n * p.H + iy) * p.W + ix) * p.ldx + c);
+            *reinterpret_cast<uint4*>(xl + (blk * PH * PW + pix) * RB + v * 16) = val;
+        }
+        __syncthreads();
+        // ---- MFMA: rows wc, wc+C, ... of the tile; k runs along the row
+        const unsigned char* ablk = dyl + wa * (TH * TW) * RB;
+        const unsigned char* bblk = xl + wb * (PH * PW) * RB;
+        for (int ry = wc; ry < TH; ry += p.C) {
+#pragma unroll 2
+            for (int k0 = 0; k0 < TW; k0 += M::kStep) {
+                const typename M::Frag fa = M::load(ablk, ry * TW + k0, lane);
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t) {
+                    const int wr = t / WW, ws = t % WW;
+                    const typename M::Frag fb = M::load(bblk, (ry + wr) * PW + k0 + ws, lane);
+                    acc[t] = M::mma(fa, fb, acc[t]);
+                }
+            }
+        }
+    }
+
+    // ---- write the partial block: slab[(split*C + wc)][tap][co][ci]; D layout: col(ci) = lane&31, row(co) = f(reg, lane>>5)
+    const int h = lane >> 5, r31 = lane & 31;
+    const int ci = ci_base + wb * 32 + r31;
+    const long long taps = (long long)p.KH * p.KW;
+    float* slab = p.slab + ((long long)(split * p.C + wc) * taps) * p.Cout * p.Cin;
+    if (ci < p.Cin) {
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = co_base + wa * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (co < p.Cout) slab[((long long)(tap0 + t) * p.Cout + co) * p.Cin + ci] = acc[t][i];
+            }
+        }
+    }
+}
+
+// sum slabs in fixed order and scatter to fp32 OIHW (real, possibly grouped, shape)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslab, int taps, int CoutP,
+                                    int CinP, int CoutR, int CinR, int groups, int accumulate) {
+    const long long total = (long long)taps * CoutP * CinP;
+    const int cin_g = CinR / groups, cout_g = CoutR / groups;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % CinP), co = (int)((i / CinP) % CoutP), tap = (int)(i / ((long long)CinP * CoutP));
+        if (co >= CoutR || ci >= CinR || (co / cout_g) != (ci / cin_g)) continue;
+        float s = 0.f;
+        for (int k = 0; k < nslab; ++k) s += slab[(long long)k * total + i];
+        const long long o = ((long long)co * cin_g + (ci % cin_g)) * taps + tap;
+        dw[o] = accumulate ? dw[o] + s : s;
+    }
+}
+
+struct WgradPlan { int A, B, C, ntaps, ngroups, nsplit, nco_tiles, nci_tiles, npt, tiles_y, tiles_x; size_t smem; long long slab_bytes; };
+
+int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, WgradPlan* pl) {
+    if (KH == 1 && KW == 1) dil = 1;
+    if (dil == 1) {
+        if (KH == 3 && KW == 3) { pl->ntaps = 9; pl->ngroups = 1; }
+        else if (KH == 1 && KW == 1) { pl->ntaps = 1; pl->ngroups = 1; }
+        else if (KW == 5) { pl->ntaps = 5; pl->ngroups = KH; }
+        else if (KW == 7) { pl->ntaps = 7; pl->ngroups = KH; }
+        else return EGM_ERR_UNSUPPORTED;
+    } else { pl->ntaps = 1; pl->ngroups = KH * KW; }
+    int A = Cout > 32 ? 2 : 1, B = Cin > 32 ? 2 : 1;
+    if (dtype == EGM_F32 && A * B == 4) A = 1;          // keep the fp32 LDS image under 160 KiB
+    pl->A = A; pl->B = B; pl->C = 4 / (A * B);
+    pl->nco_tiles = egm_cdiv(Cout, 32 * A); pl->nci_tiles = egm_cdiv(Cin, 32 * B);
+    pl->tiles_y = egm_cdiv(H, TH); pl->tiles_x = egm_cdiv(W, TW); pl->npt = N * pl->tiles_y * pl->tiles_x;
+    const int blocks_per_split = pl->nco_tiles * pl->nci_tiles * pl->ngroups;
+    int nsplit = 512 / blocks_per_split;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > pl->npt) nsplit = pl->npt;
+    pl->nsplit = nsplit;
+    const int rb = dtype == EGM_BF16 ? 64 : 128;
+    const int wh = pl->ntaps == 9 ? 3 : 1, ww = pl->ntaps == 9 ? 3 : pl->ntaps;
+    pl->smem = (size_t)A * TH * TW * rb + (size_t)B * (TH + wh - 1) * (TW + ww - 1) * rb;
+    pl->slab_bytes = (long long)nsplit * pl->C * KH * KW * Cout * Cin * (long long)sizeof(float);
+    return EGM_OK;
+}
+
+template <typename T, int NTAPS>
+int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<T, NTAPS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    dim3 grid(pl.nsplit, pl.nco_tiles * pl.nci_tiles, pl.ngroups);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, NTAPS>), grid, dim3(256), pl.smem, st, p);
+    EGM_CHECK_LAUNCH("conv_wgrad");
+    return EGM_OK;
+}
+
+template <typename T>
+int dispatch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
+    switch (pl.ntaps) {
+        case 9: return launch_wgrad<T, 9>(p, pl, st);
+        case 7: return launch_wgrad<T, 7>(p, pl, st);
+        case 5: return launch_wgrad<T, 5>(p, pl, st);
+        case 1: return launch_wgrad<T, 1>(p, pl, st);
+    }
+    EGM_FAIL(EGM_ERR_UNSUPPORTED, "conv_wgrad: unsupported tap group %d", pl.ntaps);
+}
+
+}  // namespace
+
+extern "C" long long egm_conv_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int KH, int KW) {
+    WgradPlan pl;
+    // the slab size does not depend on dtype or dilation beyond the split count; take the larger (dil>1 -> more groups, fewer splits)
+    if (wgrad_plan(EGM_F32, N, H, W, Cin, Cout, KH, KW, 1, &pl) != EGM_OK) return -1;
+    long long a = pl.slab_bytes;
+    if (wgrad_plan(EGM_BF16, N, H, W, Cin, Cout, KH, KW, 1, &pl) != EGM_OK) return -1;
+    if (pl.slab_bytes > a) a = pl.slab_bytes;
+    if (wgrad_plan(EGM_BF16, N, H, W, Cin, Cout, KH, KW, 2, &pl) != EGM_OK) return -1;
+    if (pl.slab_bytes > a) a = pl.slab_bytes;
+    if (wgrad_plan(EGM_F32, N, H, W, Cin, Cout, KH, KW, 2, &pl) != EGM_OK) return -1;
+    if (pl.slab_bytes > a) a = pl.slab_bytes;
+    return a;
+}
+
+extern "C" int egm_conv_wgrad(int dtype, const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace, int N,
+                              int H, int W, int Cin, int Cout, int CinR, int CoutR, int KH, int KW, int dil, int groups,
+                              int accumulate, egm_stream_t s) {
+    EGM_REQUIRE(x && dy && dw && workspace, "conv_wgrad: null pointer");
+    EGM_REQUIRE(N > 0 && H > 0 && W > 0, "conv_wgrad: bad shape");
+    EGM_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && Cin > 0 && Cout > 0, "conv_wgrad: padded channels must be multiples of 8");
+    EGM_REQUIRE(CinR <= Cin && CoutR <= Cout && CinR > 0 && CoutR > 0 && groups > 0 && CinR % groups == 0 && CoutR % groups == 0,
+                "conv_wgrad: bad real channel counts");
+    EGM_REQUIRE(ldx >= Cin && lddy >= Cout && ldx % 8 == 0 && lddy % 8 == 0, "conv_wgrad: bad ld");
+    EGM_REQUIRE(egm_aligned16(x) && egm_aligned16(dy) && egm_aligned16(workspace), "conv_wgrad: pointers must be 16-byte aligned");
+    EGM_REQUIRE(dil >= 1 && (KH & 1) && (KW & 1), "conv_wgrad: bad kernel");
+    if (KH == 1 && KW == 1) dil = 1;
+    WgradPlan pl;
+    if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl) != EGM_OK)
+        EGM_FAIL(EGM_ERR_UNSUPPORTED, "conv_wgrad: unsupported kernel %dx%d dil %d", KH, KW, dil);
+    EGM_REQUIRE(pl.smem <= 160 * 1024, "conv_wgrad: LDS budget exceeded");
+    WgradParams p;
+    p.x = x; p.dy = dy; p.slab = (float*)workspace; p.ldx = ldx; p.lddy = lddy; p.N = N; p.H = H; p.W = W;
+    p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.dil = dil; p.tiles_y = pl.tiles_y; p.tiles_x = pl.tiles_x;
+    p.npt = pl.npt; p.nsplit = pl.nsplit; p.A = pl.A; p.B = pl.B; p.C = pl.C; p.nci_tiles = pl.nci_tiles; p.ngroups = pl.ngroups;
+    hipStream_t st = (hipStream_t)s;
+    int rc;
+    if (dtype == EGM_BF16) rc = dispatch_wgrad<bf16_t>(p, pl, st);
+    else if (dtype == EGM_F32) rc = dispatch_wgrad<float>(p, pl, st);
+    else EGM_FAIL(EGM_ERR_ARG, "conv_wgrad: unknown dtype %d", dtype);
+    if (rc != EGM_OK) return rc;
+    const long long total = (long long)KH * KW * Cout * Cin;
+    const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)workspace, dw, pl.nsplit * pl.C,
+                       KH * KW, Cout, Cin, CoutR, CinR, groups, accumulate);
+    EGM_CHECK_LAUNCH("wgrad_reduce");
+    return EGM_OK;
+}

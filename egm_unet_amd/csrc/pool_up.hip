@@ -1,0 +1,486 @@
+// Layout conversion, 2x2 max-pool, fused bilinear-upsample + pad + concat, depthwise 3x3, and small streaming helpers
+// for NHWC activations.  All HBM-bound: one lane = 8 channels (16 B bf16 / 32 B fp32) of one pixel.
+//   nn.MaxPool2d(2,2)                       src/EGM-UNet.py:908
+//   Up.forward (upsample, pad, cat)         src/EGM-UNet.py:937-947, src/unet.py:39-49
+//   RecursiveGatedAttention.dwconv * scale  src/EGM-UNet.py:507-509,527
+#include "common.h"
+
+namespace {
+
+inline int stream_grid(long long total_threads) {
+    long long b = (total_threads + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---- NCHW fp32 <-> NHWC T (module boundary: few channels) -----------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int ld, int N, int C, long long HW) {
+    const long long total = (long long)N * HW;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long n = i / HW, p = i - n * HW;
+        for (int c0 = 0; c0 < ld; c0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (c0 + j < C) ? src[(n * C + c0 + j) * HW + p] : 0.f;
+            store8(dst + i * ld + c0, v);
+        }
+    }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int ld, float* __restrict__ dst, int N, int C, long long HW) {
+    const long long total = (long long)N * HW;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long n = i / HW, p = i - n * HW;
+        for (int c0 = 0; c0 < C; c0 += 8) {
+            float v[8];
+            load8(src + i * ld + c0, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (c0 + j < C) dst[(n * C + c0 + j) * HW + p] = v[j];
+        }
+    }
+}
+
+// ---- 2x2 max pool --------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int N, int H, int W, int C) {
+    const int ncv = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const long long total = (long long)N * Ho * Wo * ncv;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % ncv); long long p = i / ncv;
+        const int ox = (int)(p % Wo); p /= Wo; const int oy = (int)(p % Ho); const int n = (int)(p / Ho);
+        const T* b = x + (((long long)n * H + 2 * oy) * W + 2 * ox) * ldx + cv * 8;
+        float a[8], v[8];
+        load8(b, a);
+        load8(b + ldx, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = fmaxf(a[j], v[j]);
+        load8(b + (long long)W * ldx, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = fmaxf(a[j], v[j]);
+        load8(b + (long long)W * ldx + ldx, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = fmaxf(a[j], v[j]);
+        store8(y + (((long long)n * Ho + oy) * Wo + ox) * ldy + cv * 8, a);
+    }
+}
+// gradient goes to the FIRST maximum in window scan order (torch max_pool2d semantics)
+template <typename T>
+__global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy, T* __restrict__ dx,
+                                    int lddx, int N, int H, int W, int C) {
+    const int ncv = C >> 3, Ho = H >> 1, Wo = W >> 1;
+    const long long total = (long long)N * Ho * Wo * ncv;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % ncv); long long p = i / ncv;
+        const int ox = (int)(p % Wo); p /= Wo; const int oy = (int)(p % Ho); const int n = (int)(p / Ho);
+        const long long base = (((long long)n * H + 2 * oy) * W + 2 * ox);
+        float v[4][8], g[8], o[4][8];
+        load8(x + base * ldx + cv * 8, v[0]);
+        load8(x + (base + 1) * ldx + cv * 8, v[1]);
+        load8(x + (base + W) * ldx + cv * 8, v[2]);
+        load8(x + (base + W + 1) * ldx + cv * 8, v[3]);
+        load8(dy + (((long long)n * Ho + oy) * Wo + ox) * lddy + cv * 8, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int best = 0; float m = v[0][j];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (v[k][j] > m) { m = v[k][j]; best = k; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k][j] = (k == best) ? g[j] : 0.f;
+        }
+        store8(dx + base * lddx + cv * 8, o[0]);
+        store8(dx + (base + 1) * lddx + cv * 8, o[1]);
+        store8(dx + (base + W) * lddx + cv * 8, o[2]);
+        store8(dx + (base + W + 1) * lddx + cv * 8, o[3]);
+    }
+}
+// odd trailing row/column of dx (never pooled) gets zero gradient
+template <typename T>
+__global__ void zero_tail_kernel(T* __restrict__ dx, int lddx, int N, int H, int W, int C) {
+    const int ncv = C >> 3;
+    const long long total = (long long)N * H * W * ncv;
+    float z[8]; zero8(z);
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % ncv); long long p = i / ncv;
+        const int xx = (int)(p % W); const int yy = (int)((p / W) % H);
+        if (yy >= (H & ~1) || xx >= (W & ~1)) store8(dx + p * lddx + cv * 8, z);
+    }
+}
+
+// ---- bilinear x2 (align_corners=True) + zero pad + concat after the skip tensor ---------------------
+struct Lerp { int i0, i1; float w0, w1; };
+__device__ __forceinline__ Lerp lerp_coord(int dst, int in_size, int out_size) {
+    // torch upsample_bilinear2d, align_corners=True: scale = (in-1)/(out-1) (0 when out == 1), all in fp32
+    const float scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+    const float src = scale * (float)dst;
+    Lerp l;
+    l.i0 = (int)src;
+    l.i1 = l.i0 + (l.i0 < in_size - 1 ? 1 : 0);
+    l.w1 = src - (float)l.i0;
+    l.w0 = 1.f - l.w1;
+    return l;
+}
+
+template <typename T>
+__global__ void upcat_fwd_kernel(const T* __restrict__ skip, int lds, const T* __restrict__ low, int ldl, T* __restrict__ out,
+                                 int ldo, int N, int Hs, int Ws, int Cs, int Hl, int Wl, int Cl) {
+    const int ncs = Cs >> 3, ncv = (Cs + Cl) >> 3;
+    const int Hu = 2 * Hl, Wu = 2 * Wl, py = (Hs - Hu) / 2, px = (Ws - Wu) / 2;
+    const long long total = (long long)N * Hs * Ws * ncv;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % ncv); const long long p = i / ncv;
+        float v[8];
+        if (cv < ncs) {
+            load8(skip + p * lds + cv * 8, v);
+        } else {
+            const int x = (int)(p % Ws), y = (int)((p / Ws) % Hs), n = (int)(p / ((long long)Ws * Hs));
+            const int uy = y - py, ux = x - px, c = (cv - ncs) * 8;
+            zero8(v);
+            if (uy >= 0 && uy < Hu && ux >= 0 && ux < Wu) {
+                const Lerp ly = lerp_coord(uy, Hl, Hu), lx = lerp_coord(ux, Wl, Wu);
+                const T* b = low + (long long)n * Hl * Wl * ldl + c;
+                float a[8];
+                load8(b + ((long long)ly.i0 * Wl + lx.i0) * ldl, a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += ly.w0 * lx.w0 * a[j];
+                load8(b + ((long long)ly.i0 * Wl + lx.i1) * ldl, a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += ly.w0 * lx.w1 * a[j];
+                load8(b + ((long long)ly.i1 * Wl + lx.i0) * ldl, a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += ly.w1 * lx.w0 * a[j];
+                load8(b + ((long long)ly.i1 * Wl + lx.i1) * ldl, a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += ly.w1 * lx.w1 * a[j];
+            }
+        }
+        store8(out + p * ldo + cv * 8, v);
+    }
+}
+
+// transposed interpolation as a gather: every low-res pixel collects from the <=6x6 up-res pixels that can touch it
+template <typename T>
+__global__ void upcat_bwd_low_kernel(const T* __restrict__ dout, int ldo, T* __restrict__ dlow, int ldl, int N, int Hs, int Ws,
+                                     int Cs, int Hl, int Wl, int Cl) {
+    const int ncl = Cl >> 3;
+    const int Hu = 2 * Hl, Wu = 2 * Wl, py = (Hs - Hu) / 2, px = (Ws - Wu) / 2;
+    const long long total = (long long)N * Hl * Wl * ncl;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % ncl); long long p = i / ncl;
+        const int xl = (int)(p % Wl), yl = (int)((p / Wl) % Hl), n = (int)(p / ((long long)Wl * Hl));
+        float acc[8]; zero8(acc);
+        for (int uy = max(0, 2 * yl - 2); uy <= min(Hu - 1, 2 * yl + 3); ++uy) {
+            const Lerp ly = lerp_coord(uy, Hl, Hu);
+            const float wy = (ly.i0 == yl ? ly.w0 : 0.f) + (ly.i1 == yl ? ly.w1 : 0.f);
+            if (wy == 0.f) continue;
+            const int y = uy + py;
+            if (y < 0 || y >= Hs) continue;
+            for (int ux = max(0, 2 * xl - 2); ux <= min(Wu - 1, 2 * xl + 3); ++ux) {
+                const Lerp lx = lerp_coord(ux, Wl, Wu);
+                const float wx = (lx.i0 == xl ? lx.w0 : 0.f) + (lx.i1 == xl ? lx.w1 : 0.f);
+                if (wx == 0.f) continue;
+                const int x = ux + px;
+                if (x < 0 || x >= Ws) continue;
+                float g[8];
+                load8(dout + (((long long)n * Hs + y) * Ws + x) * ldo + Cs + cv * 8, g);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += wy * wx * g[j];
+            }
+        }
+        store8(dlow + p * ldl + cv * 8, acc);
+    }
+}
+
+// ---- depthwise 3x3 (+bias) * scale ------------------------------------------------------------------
+template <typename T>
+__global__ void dwconv3_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ b,
+                                   const float* __restrict__ scale, T* __restrict__ y, int ldy, int N, int H, int W, int C) {
+    const int ncv = C >> 3;
+    const long long total = (long long)N * H * W * ncv;
+    const float sc = scale ? scale[0] : 1.f;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % ncv); const long long p = i / ncv;
+        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = b ? b[cv * 8 + j] : 0.f;
+        for (int r = -1; r <= 1; ++r) {
+            if (yy + r < 0 || yy + r >= H) continue;
+            for (int s = -1; s <= 1; ++s) {
+                if (xx + s < 0 || xx + s >= W) continue;
+                float v[8];
+                load8(x + (p + (long long)r * W + s) * ldx + cv * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j] * w[(cv * 8 + j) * 9 + (r + 1) * 3 + (s + 1)];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] *= sc;
+        store8(y + p * ldy + cv * 8, acc);
+    }
+}
+// dx[p] = scale * sum_taps dy[p - tap] * w[tap]
+template <typename T>
+__global__ void dwconv3_bwd_data_kernel(const T* __restrict__ dy, int lddy, const float* __restrict__ w, const float* __restrict__ scale,
+                                        T* __restrict__ dx, int lddx, int N, int H, int W, int C) {
+    const int ncv = C >> 3;
+    const long long total = (long long)N * H * W * ncv;
+    const float sc = scale ? scale[0] : 1.f;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % ncv); const long long p = i / ncv;
+        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        float acc[8]; zero8(acc);
+        for (int r = -1; r <= 1; ++r) {
+            if (yy - r < 0 || yy - r >= H) continue;
+            for (int s = -1; s <= 1; ++s) {
+                if (xx - s < 0 || xx - s >= W) continue;
+                float g[8];
+                load8(dy + (p - (long long)r * W - s) * lddy + cv * 8, g);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += g[j] * w[(cv * 8 + j) * 9 + (r + 1) * 3 + (s + 1)];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] *= sc;
+        store8(dx + p * lddx + cv * 8, acc);
+    }
+}
+// per-block partials of: dw[c][tap] (9), db[c] (1), dscale contribution (1)  -> out[blk][11][C]
+//   y = (conv + b) * s  =>  dconv = dy*s ; dw = sum dconv * x_shift ; db = sum dconv ; ds = sum dy * (conv + b)
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3_bwd_param_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                                                const float* __restrict__ w, const float* __restrict__ b,
+                                                                const float* __restrict__ scale, float* __restrict__ out, int N, int H,
+                                                                int W, int C) {
+    extern __shared__ float red[];                       // [rows][11][8*ncv] -> we reduce one quantity at a time
+    const int ncv = C >> 3, rows = 256 / ncv;
+    const int tid = threadIdx.x, cv = tid % ncv, row = tid / ncv;
+    const float sc = scale ? scale[0] : 1.f;
+    float a[11][8];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) zero8(a[k]);
+    const long long npix = (long long)N * H * W;
+    if (row < rows) {
+        for (long long p = (long long)blockIdx.x * rows + row; p < npix; p += (long long)gridDim.x * rows) {
+            const int xx = (int)(p % W), yy = (int)((p / W) % H);
+            float g[8], conv[8];
+            load8(dy + p * lddy + cv * 8, g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) conv[j] = b ? b[cv * 8 + j] : 0.f;
+#pragma unroll
+            for (int r = -1; r <= 1; ++r) {
+#pragma unroll
+                for (int s = -1; s <= 1; ++s) {
+                    if (yy + r < 0 || yy + r >= H || xx + s < 0 || xx + s >= W) continue;
+                    float v[8];
+                    load8(x + (p + (long long)r * W + s) * ldx + cv * 8, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        a[(r + 1) * 3 + (s + 1)][j] += g[j] * sc * v[j];
+                        conv[j] += v[j] * w[(cv * 8 + j) * 9 + (r + 1) * 3 + (s + 1)];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a[9][j] += g[j] * sc; a[10][j] += g[j] * conv[j]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid * 8 + j] = a[k][j];
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            float v = 0.f;
+            for (int r = 0; r < rows; ++r) v += red[(r * ncv + (c >> 3)) * 8 + (c & 7)];
+            out[((long long)blockIdx.x * 11 + k) * C + c] = v;
+        }
+    }
+}
+// out[blk][11][C] -> dw[C][9], db[C], dscale (sum over channels of k=10)
+__global__ void dwconv3_bwd_finish_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ dw, float* __restrict__ db,
+                                          float* __restrict__ dscale) {
+    __shared__ float red[16];
+    float ds = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        for (int k = 0; k < 11; ++k) {
+            double v = 0.0;
+            for (int bk = 0; bk < nblk; ++bk) v += (double)part[((long long)bk * 11 + k) * C + c];
+            if (k < 9) dw[c * 9 + k] = (float)v;
+            else if (k == 9) { if (db) db[c] = (float)v; }
+            else ds += (float)v;
+        }
+    }
+    ds = block_sum(ds, red);
+    if (threadIdx.x == 0 && dscale) dscale[0] = ds;
+}
+
+// ---- streaming helpers -------------------------------------------------------------------------------
+template <typename T>
+__global__ void axpby_kernel(const T* __restrict__ a, int lda, float alpha, const T* __restrict__ b, int ldb, float beta,
+                             T* __restrict__ out, int ldo, long long npix, int C) {
+    const int ncv = C >> 3;
+    const long long total = npix * ncv;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        float v[8], u[8];
+        load8(a + p * lda + cv * 8, v);
+        if (b != nullptr) {
+            load8(b + p * ldb + cv * 8, u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = alpha * v[j] + beta * u[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = alpha * v[j];
+        }
+        store8(out + p * ldo + cv * 8, v);
+    }
+}
+__global__ void vec_add_f32_kernel(float* __restrict__ y, const float* __restrict__ x, long long n) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] += x[i];
+}
+__global__ void fill_f32_kernel(float* __restrict__ y, float v, long long n) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = v;
+}
+
+}  // namespace
+
+#define EGM_REQ_VEC(name, ptr, ld, C)                                                                      \
+    EGM_REQUIRE((ptr) != nullptr && egm_aligned16(ptr) && (C) > 0 && (C) % 8 == 0 && (ld) >= (C) && (ld) % 8 == 0, \
+                name ": bad tensor (ptr/alignment/C=%d/ld=%d)", (int)(C), (int)(ld))
+
+extern "C" int egm_nchw_to_nhwc(int dtype, const void* src, void* dst, int ld, int N, int C, int H, int W, egm_stream_t s) {
+    EGM_REQUIRE(src && dst && egm_aligned16(dst) && N > 0 && C > 0 && H > 0 && W > 0 && ld >= C && ld % 8 == 0, "nchw_to_nhwc: bad args");
+    const long long HW = (long long)H * W;
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(stream_grid(N * HW)), dim3(256), 0, (hipStream_t)s,
+                                                 (const float*)src, (T*)dst, ld, N, C, HW));
+    EGM_CHECK_LAUNCH("nchw_to_nhwc");
+    return EGM_OK;
+}
+extern "C" int egm_nhwc_to_nchw(int dtype, const void* src, int ld, void* dst, int N, int C, int H, int W, egm_stream_t s) {
+    EGM_REQUIRE(src && dst && egm_aligned16(src) && N > 0 && C > 0 && H > 0 && W > 0 && ld >= C && ld % 8 == 0, "nhwc_to_nchw: bad args");
+    const long long HW = (long long)H * W;
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(stream_grid(N * HW)), dim3(256), 0, (hipStream_t)s,
+                                                 (const T*)src, ld, (float*)dst, N, C, HW));
+    EGM_CHECK_LAUNCH("nhwc_to_nchw");
+    return EGM_OK;
+}
+
+extern "C" int egm_maxpool2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, egm_stream_t s) {
+    EGM_REQ_VEC("maxpool2_fwd", x, ldx, C);
+    EGM_REQ_VEC("maxpool2_fwd", y, ldy, C);
+    EGM_REQUIRE(N > 0 && H >= 2 && W >= 2, "maxpool2_fwd: bad shape");
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 8);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool2_fwd_kernel<T>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)s,
+                                                 (const T*)x, ldx, (T*)y, ldy, N, H, W, C));
+    EGM_CHECK_LAUNCH("maxpool2_fwd");
+    return EGM_OK;
+}
+extern "C" int egm_maxpool2_bwd(int dtype, const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int N, int H, int W,
+                                int C, egm_stream_t s) {
+    EGM_REQ_VEC("maxpool2_bwd", x, ldx, C);
+    EGM_REQ_VEC("maxpool2_bwd", dy, lddy, C);
+    EGM_REQ_VEC("maxpool2_bwd", dx, lddx, C);
+    EGM_REQUIRE(N > 0 && H >= 2 && W >= 2, "maxpool2_bwd: bad shape");
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 8);
+    EGM_DISPATCH_DTYPE(dtype, {
+        hipLaunchKernelGGL((maxpool2_bwd_kernel<T>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx,
+                           (const T*)dy, lddy, (T*)dx, lddx, N, H, W, C);
+        if ((H & 1) || (W & 1))
+            hipLaunchKernelGGL((zero_tail_kernel<T>), dim3(stream_grid((long long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)s,
+                               (T*)dx, lddx, N, H, W, C);
+    });
+    EGM_CHECK_LAUNCH("maxpool2_bwd");
+    return EGM_OK;
+}
+
+extern "C" int egm_upcat_fwd(int dtype, const void* skip, int lds, const void* low, int ldl, void* out, int ldo, int N, int Hs, int Ws,
+                             int Cs, int Hl, int Wl, int Cl, egm_stream_t s) {
+    EGM_REQ_VEC("upcat_fwd", skip, lds, Cs);
+    EGM_REQ_VEC("upcat_fwd", low, ldl, Cl);
+    EGM_REQ_VEC("upcat_fwd", out, ldo, Cs + Cl);
+    EGM_REQUIRE(N > 0 && Hl > 0 && Wl > 0 && Hs >= 2 * Hl && Ws >= 2 * Wl, "upcat_fwd: skip must be at least 2x the low-res size");
+    const long long total = (long long)N * Hs * Ws * ((Cs + Cl) / 8);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((upcat_fwd_kernel<T>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)s,
+                                                 (const T*)skip, lds, (const T*)low, ldl, (T*)out, ldo, N, Hs, Ws, Cs, Hl, Wl, Cl));
+    EGM_CHECK_LAUNCH("upcat_fwd");
+    return EGM_OK;
+}
+extern "C" int egm_upcat_bwd_low(int dtype, const void* dout, int ldo, void* dlow, int ldl, int N, int Hs, int Ws, int Cs, int Hl,
+                                 int Wl, int Cl, egm_stream_t s) {
+    EGM_REQ_VEC("upcat_bwd_low", dout, ldo, Cs + Cl);
+    EGM_REQ_VEC("upcat_bwd_low", dlow, ldl, Cl);
+    EGM_REQUIRE(N > 0 && Hl > 0 && Wl > 0 && Hs >= 2 * Hl && Ws >= 2 * Wl && Cs % 8 == 0, "upcat_bwd_low: bad shape");
+    const long long total = (long long)N * Hl * Wl * (Cl / 8);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((upcat_bwd_low_kernel<T>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)s,
+                                                 (const T*)dout, ldo, (T*)dlow, ldl, N, Hs, Ws, Cs, Hl, Wl, Cl));
+    EGM_CHECK_LAUNCH("upcat_bwd_low");
+    return EGM_OK;
+}
+
+extern "C" int egm_dwconv3_fwd(int dtype, const void* x, int ldx, const float* w, const float* b, const float* scale, void* y, int ldy,
+                               int N, int H, int W, int C, egm_stream_t s) {
+    EGM_REQ_VEC("dwconv3_fwd", x, ldx, C);
+    EGM_REQ_VEC("dwconv3_fwd", y, ldy, C);
+    EGM_REQUIRE(w && N > 0 && H > 0 && W > 0, "dwconv3_fwd: bad args");
+    const long long total = (long long)N * H * W * (C / 8);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3_fwd_kernel<T>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)s,
+                                                 (const T*)x, ldx, w, b, scale, (T*)y, ldy, N, H, W, C));
+    EGM_CHECK_LAUNCH("dwconv3_fwd");
+    return EGM_OK;
+}
+static int dw_blocks(long long npix, int C) {
+    const int rows = 256 / (C >> 3);
+    long long b = (npix + rows - 1) / rows;
+    if (b > 256) b = 256;
+    return (int)(b < 1 ? 1 : b);
+}
+extern "C" long long egm_dwconv3_bwd_workspace(int N, int H, int W, int C) {
+    if (C <= 0 || C % 8 || C > 2048) return -1;
+    return (long long)dw_blocks((long long)N * H * W, C) * 11 * C * (long long)sizeof(float);
+}
+extern "C" int egm_dwconv3_bwd(int dtype, const void* x, int ldx, const void* dy, int lddy, const float* w, const float* b,
+                               const float* scale, void* dx, int lddx, float* dw, float* db, float* dscale, void* workspace, int N,
+                               int H, int W, int C, egm_stream_t s) {
+    EGM_REQ_VEC("dwconv3_bwd", x, ldx, C);
+    EGM_REQ_VEC("dwconv3_bwd", dy, lddy, C);
+    EGM_REQ_VEC("dwconv3_bwd", dx, lddx, C);
+    EGM_REQUIRE(w && dw && workspace && N > 0 && H > 0 && W > 0 && C <= 2048, "dwconv3_bwd: bad args");
+    const long long npix = (long long)N * H * W;
+    const int nb = dw_blocks(npix, C);
+    EGM_DISPATCH_DTYPE(dtype, {
+        hipLaunchKernelGGL((dwconv3_bwd_data_kernel<T>), dim3(stream_grid(npix * (C / 8))), dim3(256), 0, (hipStream_t)s, (const T*)dy,
+                           lddy, w, scale, (T*)dx, lddx, N, H, W, C);
+        hipLaunchKernelGGL((dwconv3_bwd_param_kernel<T>), dim3(nb), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)s, (const T*)x, ldx,
+                           (const T*)dy, lddy, w, b, scale, (float*)workspace, N, H, W, C);
+    });
+    hipLaunchKernelGGL(dwconv3_bwd_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, (const float*)workspace, nb, C, dw, db, dscale);
+    EGM_CHECK_LAUNCH("dwconv3_bwd");
+    return EGM_OK;
+}
+
+extern "C" int egm_axpby(int dtype, const void* a, int lda, float alpha, const void* b, int ldb, float beta, void* out, int ldo,
+                         long long npix, int C, egm_stream_t s) {
+    EGM_REQ_VEC("axpby", a, lda, C);
+    EGM_REQ_VEC("axpby", out, ldo, C);
+    if (b) EGM_REQ_VEC("axpby", b, ldb, C);
+    EGM_REQUIRE(npix > 0, "axpby: bad npix");
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((axpby_kernel<T>), dim3(stream_grid(npix * (C / 8))), dim3(256), 0, (hipStream_t)s,
+                                                 (const T*)a, lda, alpha, (const T*)b, ldb, beta, (T*)out, ldo, npix, C));
+    EGM_CHECK_LAUNCH("axpby");
+    return EGM_OK;
+}
+extern "C" int egm_vec_add_f32(float* y, const float* x, long long n, egm_stream_t s) {
+    EGM_REQUIRE(y && x && n > 0, "vec_add_f32: bad args");
+    hipLaunchKernelGGL(vec_add_f32_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)s, y, x, n);
+    EGM_CHECK_LAUNCH("vec_add_f32");
+    return EGM_OK;
+}
+extern "C" int egm_fill_f32(float* y, float v, long long n, egm_stream_t s) {
+    EGM_REQUIRE(y && n > 0, "fill_f32: bad args");
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)s, y, v, n);
+    EGM_CHECK_LAUNCH("fill_f32");
+    return EGM_OK;
+}

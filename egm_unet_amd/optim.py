@@ -1,0 +1,49 @@
+"""Fused multi-tensor SGD on the HIP library: the drop-in for torch.optim.SGD(lr, momentum, weight_decay) as
+constructed at train.py:115-118 of the reference (same param_groups / state_dict layout, so LambdaLR schedulers and
+checkpoints work unchanged).  One kernel launch updates every parameter."""
+import torch
+
+from . import ops
+from ._lib import lib, ptr, stream
+
+
+class SGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0, weight_decay=0.0, nesterov=False):
+        if dampening != 0 or nesterov:
+            raise NotImplementedError("egm_unet_amd.optim.SGD: dampening/nesterov are not used by the reference")
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self.grad_scale = 1.0          # e.g. 1/world_size when gradients arrive as an all-reduced SUM
+        self.grad_source = None        # optional {param: fp32 tensor view} overriding p.grad (DDP buckets)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            for first in (True, False):           # parameters on their first step take v = g (no stale buffer read)
+                rows, keep = [], []
+                for p in group["params"]:
+                    g = self.grad_source.get(p) if self.grad_source is not None else p.grad
+                    if g is None:
+                        continue
+                    if p.dtype != torch.float32 or not p.is_contiguous():
+                        raise RuntimeError("egm_unet_amd.optim.SGD needs contiguous fp32 parameters")
+                    st = self.state[p]
+                    is_first = "momentum_buffer" not in st or st["momentum_buffer"] is None
+                    if is_first != first:
+                        continue
+                    g = g if (g.is_contiguous() and g.dtype == torch.float32) else g.contiguous().float()
+                    keep.append(g)
+                    buf = None
+                    if group["momentum"] != 0:
+                        if is_first:
+                            st["momentum_buffer"] = torch.empty_like(p)
+                        buf = st["momentum_buffer"]
+                    rows.append((p.data_ptr(), g.data_ptr(), buf.data_ptr() if buf is not None else 0, p.numel()))
+                if not rows:
+                    continue
+                dev = group["params"][0].device
+                table = torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=False)
+                lib().call("egm_sgd_multi", ptr(table), len(rows), None, float(group["lr"]), float(group["momentum"]),
+                           float(group["weight_decay"]), float(self.grad_scale), 1 if first else 0, stream())
+        ops.bump_weight_generation()
+        return loss

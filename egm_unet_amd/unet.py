@@ -1,0 +1,121 @@
+"""Vanilla U-Net with the reference's constructor, forward() and state_dict() surface (src/unet.py:7-96),
+computed by the HIP library.  The nn.Conv2d / nn.BatchNorm2d children are PARAMETER HOLDERS only (identical names,
+shapes and default initialisation order as the reference, so seeds and checkpoints carry over); their own forward
+is never called."""
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import ACT_RELU, require_gpu
+
+
+class DoubleConv(nn.Sequential):
+    """(conv3x3 -> BN -> ReLU) x 2   (src/unet.py:7-18, src/EGM-UNet.py:44-55)"""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None, use_attention=False):
+        if mid_channels is None:
+            mid_channels = out_channels
+        super().__init__(
+            nn.Conv2d(in_channels, mid_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(mid_channels),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True),
+        )
+
+    def forward(self, x):            # x: NHWC
+        x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU)
+        return ops.conv_bn_act(x, self[3], self[4], ACT_RELU)
+
+
+class Down(nn.Sequential):
+    """MaxPool2d(2) -> DoubleConv   (src/unet.py:21-26)"""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__(nn.MaxPool2d(2, stride=2), DoubleConv(in_channels, out_channels))
+
+    def forward(self, x):
+        return self[1](ops.maxpool2(x))
+
+
+class Up(nn.Module):
+    """bilinear x2 (align_corners=True) -> pad -> cat([skip, up]) -> DoubleConv   (src/unet.py:29-51)"""
+
+    def __init__(self, in_channels, out_channels, bilinear=True, use_attention=False):
+        super().__init__()
+        if not bilinear:
+            raise NotImplementedError("egm_unet_amd: only the bilinear Up path of the reference is implemented")
+        self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+        self.conv = DoubleConv(in_channels, out_channels, in_channels // 2)
+
+    def forward(self, x1, x2):       # x1: low-res, x2: skip (both NHWC)
+        return self.conv(ops.upcat(x2, x1))
+
+
+class OutConv(nn.Sequential):
+    """1x1 conv to class logits   (src/unet.py:54-58)"""
+
+    def __init__(self, in_channels, num_classes):
+        super().__init__(nn.Conv2d(in_channels, num_classes, kernel_size=1))
+
+    def forward(self, x):
+        return ops.conv2d(x, self[0].weight, self[0].bias)
+
+
+class _SegNetBase(nn.Module):
+    """Module-boundary plumbing shared by UNet and GRFBUNet: NCHW fp32 in, {"out": NCHW fp32 logits} out."""
+
+    compute_dtype = torch.float32
+
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (parity path) or torch.bfloat16 (throughput path) activation storage."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = dtype
+        return self
+
+    def _enter(self, x):
+        require_gpu()
+        if not x.is_cuda:
+            raise RuntimeError("egm_unet_amd models run on the GPU only: move the input (and the model) to cuda")
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise RuntimeError(f"expected input [N,{self.in_channels},H,W], got {tuple(x.shape)}")
+        return ops.to_nhwc(x, self.compute_dtype)
+
+    def _exit(self, y) -> Dict[str, torch.Tensor]:
+        return {"out": ops.to_nchw(y, self.num_classes)}
+
+
+class UNet(_SegNetBase):
+    def __init__(self, in_channels: int = 1, num_classes: int = 2, bilinear: bool = True, base_c: int = 64):
+        super().__init__()
+        self.in_channels = in_channels
+        self.num_classes = num_classes
+        self.bilinear = bilinear
+        self.in_conv = DoubleConv(in_channels, base_c)
+        self.down1 = Down(base_c, base_c * 2)
+        self.down2 = Down(base_c * 2, base_c * 4)
+        self.down3 = Down(base_c * 4, base_c * 8)
+        factor = 2 if bilinear else 1
+        self.down4 = Down(base_c * 8, base_c * 16 // factor)
+        self.up1 = Up(base_c * 16, base_c * 8 // factor, bilinear)
+        self.up2 = Up(base_c * 8, base_c * 4 // factor, bilinear)
+        self.up3 = Up(base_c * 4, base_c * 2 // factor, bilinear)
+        self.up4 = Up(base_c * 2, base_c, bilinear)
+        self.out_conv = OutConv(base_c, num_classes)
+
+    def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        x = self._enter(x)
+        x1, x1s = ops.fork2(self.in_conv(x))
+        x2, x2s = ops.fork2(self.down1(x1))
+        x3, x3s = ops.fork2(self.down2(x2))
+        x4, x4s = ops.fork2(self.down3(x3))
+        x5 = self.down4(x4)
+        y = self.up1(x5, x4s)
+        y = self.up2(y, x3s)
+        y = self.up3(y, x2s)
+        y = self.up4(y, x1s)
+        return self._exit(self.out_conv(y))

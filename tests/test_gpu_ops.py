@@ -1,0 +1,207 @@
+"""GPU parity tests of the primitive operators (through the C ABI) against plain PyTorch fp32 CPU references of the
+same op.  fp32 path: tight tolerances; bf16 path: tolerances scaled to bf16 storage (8 significant bits)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from egm_unet_amd import ops
+    return ops
+
+
+def nhwc(x_nchw, dtype):
+    """CPU NCHW fp32 -> GPU NHWC (padded to 8 channels) via torch only (independent of the kernel under test)."""
+    N, C, H, W = x_nchw.shape
+    CP = (C + 7) // 8 * 8
+    out = torch.zeros(N, H, W, CP, dtype=dtype, device=DEV)
+    out[..., :C] = x_nchw.permute(0, 2, 3, 1).to(DEV).to(dtype)
+    return out
+
+
+def nchw(y_nhwc, C):
+    return y_nhwc[..., :C].float().permute(0, 3, 1, 2).cpu()
+
+
+def tol(dtype, scale=1.0):
+    return (dict(rtol=2e-4, atol=2e-4 * scale) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2 * scale))
+
+
+def check(a, b, what, rtol, atol):
+    a, b = a.double(), b.double()
+    err = (a - b).abs()
+    lim = atol + rtol * b.abs()
+    assert (err <= lim).all(), f"{what}: max err {err.max():.3e} (allowed {lim[err.argmax()] if err.numel() else 0:.3e}), rel-L2 {((a-b).norm()/(b.norm()+1e-30)):.3e}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layout_roundtrip(dtype):
+    ops = _ops()
+    x = torch.randn(2, 3, 9, 13)
+    y = ops.to_nhwc(x.to(DEV), dtype)
+    assert y.shape == (2, 9, 13, 8)
+    ref = nhwc(x, dtype)
+    assert torch.equal(y.float().cpu(), ref.float().cpu())
+    z = ops.to_nchw(y, 3)
+    assert torch.equal(z.cpu(), ref[..., :3].float().permute(0, 3, 1, 2).cpu())
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, dil, groups, bias
+    (2, 20, 24, 8, 16, 3, 1, 1, False),
+    (2, 40, 44, 64, 64, 3, 1, 1, False),
+    (1, 33, 70, 32, 40, 3, 1, 1, True),      # ragged tiles, Cout not a multiple of 32
+    (2, 16, 16, 72, 24, 1, 1, 1, True),      # 1x1, Cin spans 3 chunks
+    (2, 12, 14, 16, 16, 5, 1, 1, True),
+    (2, 12, 14, 16, 16, 7, 1, 1, True),
+    (2, 40, 44, 16, 16, 3, 12, 1, False),    # dilated (GRFB branch_dir)
+    (1, 40, 44, 16, 16, 3, 36, 1, False),    # dilation ~ image size: most taps skipped
+    (2, 16, 20, 8, 16, 3, 1, 8, False),      # grouped 1->2 per group (branch_edge.2)
+    (2, 16, 20, 8, 16, 3, 1, 2, False),      # groups=2 (branch_ctx.1)
+    (2, 18, 18, 3, 32, 3, 1, 1, False),      # Cin=3 (in_conv.0)
+    (2, 18, 18, 32, 2, 1, 1, 1, True),       # OutConv
+    (2, 18, 18, 64, 3, 3, 1, 1, True),       # target_enhancer
+    (2, 10, 10, 2, 1, 7, 1, 1, False),       # spatial attention
+    (1, 64, 64, 128, 256, 3, 1, 1, False),   # wide
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv_fwd_bwd(case, dtype):
+    ops = _ops()
+    N, H, W, Cin, Cout, k, dil, groups, bias = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin // groups, k, k, generator=g) / (Cin // groups * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) if bias else None
+    gy = torch.randn(N, Cout, H, W, generator=g)
+    if dtype == torch.bfloat16:       # compare on bf16-representable operands so only accumulation order differs
+        x, w, gy = x.bfloat16().float(), w.bfloat16().float(), gy.bfloat16().float()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, padding=dil * (k - 1) // 2, dilation=dil, groups=groups)
+    yr.backward(gy)
+
+    xg = nhwc(x, dtype).requires_grad_(True)
+    wg = w.to(DEV).requires_grad_(True)
+    bg = b.to(DEV).requires_grad_(True) if bias else None
+    y = ops.conv2d(xg, wg, bg, dil=dil, groups=groups)
+    t = tol(dtype)
+    check(nchw(y, Cout), yr.detach(), "y", **t)
+    CP = y.shape[3]
+    if CP > Cout:
+        assert float(y[..., Cout:].float().abs().max()) == 0.0, "padded output channels must stay zero"
+    y.backward(nhwc(gy, dtype))
+    check(nchw(xg.grad, Cin), xr.grad, "dx", **t)
+    check(wg.grad.cpu(), wr.grad, "dw", rtol=t["rtol"], atol=t["atol"] * (N * H * W) ** 0.5)
+    if bias:
+        check(bg.grad.cpu(), br.grad, "db", rtol=t["rtol"], atol=t["atol"] * (N * H * W) ** 0.5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["relu", "sigmoid", "none"])
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("C", [16, 4])
+def test_bn_act(dtype, act, train, C):
+    ops = _ops()
+    from egm_unet_amd._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID
+    code = {"relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "none": ACT_NONE}[act]
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(3, C, 10, 12, generator=g) * 2 + 0.5)
+    gz = torch.randn(3, C, 10, 12, generator=g)
+    if dtype == torch.bfloat16:
+        x, gz = x.bfloat16().float(), gz.bfloat16().float()
+    bn_ref = torch.nn.BatchNorm2d(C, momentum=0.01)
+    with torch.no_grad():
+        bn_ref.weight.copy_(1 + 0.2 * torch.randn(C, generator=g)); bn_ref.bias.copy_(0.2 * torch.randn(C, generator=g))
+        bn_ref.running_mean.copy_(0.3 * torch.randn(C, generator=g)); bn_ref.running_var.copy_(1 + 0.3 * torch.rand(C, generator=g))
+    bn_gpu = torch.nn.BatchNorm2d(C, momentum=0.01)
+    bn_gpu.load_state_dict(bn_ref.state_dict())
+    bn_gpu.to(DEV)
+    bn_ref.train(train); bn_gpu.train(train)
+    fact = {"relu": torch.relu, "sigmoid": torch.sigmoid, "none": lambda v: v}[act]
+    xr = x.clone().requires_grad_(True)
+    zr = fact(bn_ref(xr)); zr.backward(gz)
+    xg = nhwc(x, dtype).requires_grad_(True)
+    z = ops.bn_act(xg, bn_gpu, code)
+    z.backward(nhwc(gz, dtype))
+    t = tol(dtype, 2.0)
+    check(nchw(z, C), zr.detach(), "z", **t)
+    check(nchw(xg.grad, C), xr.grad, "dx", **t)
+    check(bn_gpu.weight.grad.cpu(), bn_ref.weight.grad, "dgamma", rtol=t["rtol"], atol=t["atol"] * 20)
+    check(bn_gpu.bias.grad.cpu(), bn_ref.bias.grad, "dbeta", rtol=t["rtol"], atol=t["atol"] * 20)
+    check(bn_gpu.running_mean.cpu(), bn_ref.running_mean, "running_mean", rtol=1e-4, atol=1e-4)
+    check(bn_gpu.running_var.cpu(), bn_ref.running_var, "running_var", rtol=1e-4, atol=1e-4)
+    assert int(bn_gpu.num_batches_tracked) == int(bn_ref.num_batches_tracked)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_bn_stats_fused(dtype):
+    """BN statistics from the conv epilogue == statistics of the stored conv output."""
+    ops = _ops()
+    from egm_unet_amd._lib import ACT_RELU
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 16, 19, 37, generator=g)
+    conv = torch.nn.Conv2d(16, 24, 3, padding=1, bias=False)
+    bn = torch.nn.BatchNorm2d(24)
+    xr = x.clone().requires_grad_(True)
+    zr = torch.relu(bn(conv(xr))); zr.sum().backward()
+    import copy
+    conv_g, bn_g = copy.deepcopy(conv).to(DEV), torch.nn.BatchNorm2d(24).to(DEV)
+    conv_g.weight.grad = None
+    xg = nhwc(x, dtype).requires_grad_(True)
+    z = ops.conv_bn_act(xg, conv_g, bn_g, ACT_RELU)
+    z.float().sum().backward()
+    t = tol(dtype, 3.0)
+    check(nchw(z, 24), zr.detach(), "z", **t)
+    check(bn_g.running_var.cpu(), bn.running_var, "running_var", rtol=2e-2 if dtype == torch.bfloat16 else 1e-4, atol=1e-4)
+    check(nchw(xg.grad, 16), xr.grad, "dx", rtol=t["rtol"], atol=t["atol"] * 3)
+    check(conv_g.weight.grad.cpu(), conv.weight.grad, "dw", rtol=t["rtol"], atol=t["atol"] * 40)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 16, 12, 20), (1, 8, 7, 9)])
+def test_maxpool2(dtype, shape):
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(*shape, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2, 2)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xg = nhwc(x, dtype).requires_grad_(True)
+    y = ops.maxpool2(xg)
+    y.backward(nhwc(gy, dtype))
+    check(nchw(y, shape[1]), yr.detach(), "y", rtol=0, atol=0)
+    check(nchw(xg.grad, shape[1]), xr.grad.bfloat16().float() if dtype == torch.bfloat16 else xr.grad, "dx", rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shapes", [((2, 16, 10, 12), (2, 16, 20, 24)), ((1, 8, 7, 9), (1, 16, 15, 19))])
+def test_upcat(dtype, shapes):
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    low, skip = torch.randn(*shapes[0], generator=g), torch.randn(*shapes[1], generator=g)
+    if dtype == torch.bfloat16:
+        low, skip = low.bfloat16().float(), skip.bfloat16().float()
+    lr_, sr_ = low.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+    up = F.interpolate(lr_, scale_factor=2, mode="bilinear", align_corners=True)
+    dy, dx = sr_.shape[2] - up.shape[2], sr_.shape[3] - up.shape[3]
+    ref = torch.cat([sr_, F.pad(up, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])], 1)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    lg, sg = nhwc(low, dtype).requires_grad_(True), nhwc(skip, dtype).requires_grad_(True)
+    out = ops.upcat(sg, lg)
+    out.backward(nhwc(go, dtype))
+    t = tol(dtype)
+    check(nchw(out, ref.shape[1]), ref.detach(), "out", **t)
+    check(nchw(lg.grad, low.shape[1]), lr_.grad, "dlow", rtol=t["rtol"], atol=t["atol"] * 2)
+    check(nchw(sg.grad, skip.shape[1]), sr_.grad, "dskip", **t)
