@@ -19,31 +19,30 @@ class SGD(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         for group in self.param_groups:
-            for first in (True, False):           # parameters on their first step take v = g (no stale buffer read)
-                rows, keep = [], []
-                for p in group["params"]:
-                    g = self.grad_source.get(p) if self.grad_source is not None else p.grad
-                    if g is None:
-                        continue
-                    if p.dtype != torch.float32 or not p.is_contiguous():
-                        raise RuntimeError("egm_unet_amd.optim.SGD needs contiguous fp32 parameters")
-                    st = self.state[p]
-                    is_first = "momentum_buffer" not in st or st["momentum_buffer"] is None
-                    if is_first != first:
-                        continue
-                    g = g if (g.is_contiguous() and g.dtype == torch.float32) else g.contiguous().float()
-                    keep.append(g)
-                    buf = None
-                    if group["momentum"] != 0:
-                        if is_first:
-                            st["momentum_buffer"] = torch.empty_like(p)
-                        buf = st["momentum_buffer"]
-                    rows.append((p.data_ptr(), g.data_ptr(), buf.data_ptr() if buf is not None else 0, p.numel()))
-                if not rows:
+            rows = {True: [], False: []}          # first-step parameters take v = g (no stale buffer read)
+            keep = []
+            for p in group["params"]:
+                g = self.grad_source.get(p) if self.grad_source is not None else p.grad
+                if g is None:
+                    continue
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("egm_unet_amd.optim.SGD needs contiguous fp32 parameters")
+                st = self.state[p]
+                is_first = st.get("momentum_buffer") is None
+                g = g if (g.is_contiguous() and g.dtype == torch.float32) else g.contiguous().float()
+                keep.append(g)
+                buf = None
+                if group["momentum"] != 0:
+                    if is_first:
+                        st["momentum_buffer"] = torch.empty_like(p)
+                    buf = st["momentum_buffer"]
+                rows[is_first].append((p.data_ptr(), g.data_ptr(), buf.data_ptr() if buf is not None else 0, p.numel()))
+            for first in (True, False):
+                if not rows[first]:
                     continue
                 dev = group["params"][0].device
-                table = torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=False)
-                lib().call("egm_sgd_multi", ptr(table), len(rows), None, float(group["lr"]), float(group["momentum"]),
+                table = torch.tensor(rows[first], dtype=torch.int64).to(dev)
+                lib().call("egm_sgd_multi", ptr(table), len(rows[first]), None, float(group["lr"]), float(group["momentum"]),
                            float(group["weight_decay"]), float(self.grad_scale), 1 if first else 0, stream())
         ops.bump_weight_generation()
         return loss

@@ -36,7 +36,8 @@ def check(a, b, what, rtol, atol):
     a, b = a.double(), b.double()
     err = (a - b).abs()
     lim = atol + rtol * b.abs()
-    assert (err <= lim).all(), f"{what}: max err {err.max():.3e} (allowed {lim[err.argmax()] if err.numel() else 0:.3e}), rel-L2 {((a-b).norm()/(b.norm()+1e-30)):.3e}"
+    assert (err <= lim).all(), (f"{what}: {int((err > lim).sum())}/{err.numel()} bad, max err {err.max():.3e} "
+                                f"(allowed {lim.flatten()[err.argmax()]:.3e}), rel-L2 {((a-b).norm()/(b.norm()+1e-30)):.3e}")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -141,28 +142,44 @@ def test_bn_act(dtype, act, train, C):
     assert int(bn_gpu.num_batches_tracked) == int(bn_ref.num_batches_tracked)
 
 
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_bn_stats_fused(dtype):
-    """BN statistics from the conv epilogue == statistics of the stored conv output."""
+    """conv -> BN(train, statistics from the conv epilogue) -> ReLU, forward and backward."""
     ops = _ops()
     from egm_unet_amd._lib import ACT_RELU
+    import copy
     g = torch.Generator().manual_seed(9)
     x = torch.randn(2, 16, 19, 37, generator=g)
     conv = torch.nn.Conv2d(16, 24, 3, padding=1, bias=False)
     bn = torch.nn.BatchNorm2d(24)
+    gz = torch.randn(2, 24, 19, 37, generator=g)
+    if dtype == torch.bfloat16:
+        x, gz = x.bfloat16().float(), gz.bfloat16().float()
+        with torch.no_grad():
+            conv.weight.copy_(conv.weight.bfloat16().float())
     xr = x.clone().requires_grad_(True)
-    zr = torch.relu(bn(conv(xr))); zr.sum().backward()
-    import copy
+    zr = torch.relu(bn(conv(xr))); zr.backward(gz)
     conv_g, bn_g = copy.deepcopy(conv).to(DEV), torch.nn.BatchNorm2d(24).to(DEV)
     conv_g.weight.grad = None
     xg = nhwc(x, dtype).requires_grad_(True)
     z = ops.conv_bn_act(xg, conv_g, bn_g, ACT_RELU)
-    z.float().sum().backward()
-    t = tol(dtype, 3.0)
-    check(nchw(z, 24), zr.detach(), "z", **t)
-    check(bn_g.running_var.cpu(), bn.running_var, "running_var", rtol=2e-2 if dtype == torch.bfloat16 else 1e-4, atol=1e-4)
-    check(nchw(xg.grad, 16), xr.grad, "dx", rtol=t["rtol"], atol=t["atol"] * 3)
-    check(conv_g.weight.grad.cpu(), conv.weight.grad, "dw", rtol=t["rtol"], atol=t["atol"] * 40)
+    z.backward(nhwc(gz, dtype))
+    if dtype == torch.float32:
+        t = tol(dtype, 3.0)
+        check(nchw(z, 24), zr.detach(), "z", **t)
+        check(bn_g.running_var.cpu(), bn.running_var, "running_var", rtol=1e-4, atol=1e-4)
+        check(nchw(xg.grad, 16), xr.grad, "dx", rtol=t["rtol"], atol=t["atol"] * 3)
+        check(conv_g.weight.grad.cpu(), conv.weight.grad, "dw", rtol=t["rtol"], atol=t["atol"] * 40)
+    else:   # bf16 storage: ReLU masks of borderline elements may flip, so compare in the aggregate
+        assert rel_l2(nchw(z, 24), zr.detach()) < 1e-2
+        assert rel_l2(bn_g.running_var.cpu(), bn.running_var) < 1e-2
+        assert rel_l2(nchw(xg.grad, 16), xr.grad) < 4e-2
+        assert rel_l2(conv_g.weight.grad.cpu(), conv.weight.grad) < 4e-2
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

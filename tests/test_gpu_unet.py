@@ -211,4 +211,4 @@ def test_unet_train_steps_vs_oracle():
     sd = m.state_dict()
     for k in ["in_conv.0.weight", "down4.1.3.weight", "up1.conv.0.weight", "out_conv.0.bias", "down2.1.1.running_var"]:
         ref = params[k] if k in params else state[k]
-        assert_close(sd[k].cpu(), ref, rtol=2e-3, atol=2e-5, what=k)
+        assert_close(sd[k].cpu(), ref, rtol=2e-3, atol=2e-4, what=k)
