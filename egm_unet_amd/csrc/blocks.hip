@@ -1,0 +1,689 @@
+// Streaming (HBM-bound) pieces of the EGM-UNet blocks that sit between the matrix-core convolutions:
+//   EdgeAwareFeatureEnhancer   src/EGM-UNet.py:872-886   high-pass (x - avgpool3) and x*(1+w) gate
+//   FusionConv                 src/EGM-UNet.py:1202-1236 spatial attention (channel mean/max), channel attention
+//                                                        (global avg/max pool), res + s*sa*ca combine, weight folds
+//   EdgeEnhancedGRFB tail      src/EGM-UNet.py:1315-1321 relu(scale*out + shortcut), 3-map sigmoid target gate
+//   RecursiveGatedAttention    src/EGM-UNet.py:531-544   GELU, broadcast sigmoid gate
+// One lane = 8 channels of one pixel (16 B bf16 / 32 B fp32); per-pixel cross-channel sums use lane shuffles inside the
+// group of lanes that shares a pixel; per-channel sums over pixels are two-stage with plain stores (deterministic).
+#include "common.h"
+
+namespace {
+
+inline int stream_grid(long long total_threads) {
+    long long b = (total_threads + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+__device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); }
+
+#define PIX_LOOP(total_expr)                                                                           \
+    const int ncv = C >> 3;                                                                            \
+    const long long total = (total_expr);                                                              \
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+
+// ---- out = x - avgpool3x3(x)  (zero pad, divisor 9: count_include_pad=True); self-adjoint ------------
+template <typename T>
+__global__ void highpass3_kernel(const T* __restrict__ x, int ldx, T* __restrict__ out, int ldo, int N, int H, int W, int C) {
+    PIX_LOOP((long long)N * H * W * ncv) {
+        const int cv = (int)(i % ncv); const long long p = i / ncv;
+        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        float s[8], c[8], v[8];
+        zero8(s);
+        load8(x + p * ldx + cv * 8, c);
+#pragma unroll
+        for (int r = -1; r <= 1; ++r)
+#pragma unroll
+            for (int q = -1; q <= 1; ++q) {
+                if (yy + r < 0 || yy + r >= H || xx + q < 0 || xx + q >= W) continue;
+                load8(x + (p + (long long)r * W + q) * ldx + cv * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += v[j];
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] -= s[j] * (1.f / 9.f);
+        store8(out + p * ldo + cv * 8, c);
+    }
+}
+
+// ---- out = x*(1+w) ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void gate_mul_fwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ w, int ldw, T* __restrict__ out, int ldo,
+                                    long long npix, int C) {
+    PIX_LOOP(npix * ncv) {
+        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        float a[8], b[8];
+        load8(x + p * ldx + cv * 8, a); load8(w + p * ldw + cv * 8, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] *= (1.f + b[j]);
+        store8(out + p * ldo + cv * 8, a);
+    }
+}
+template <typename T>
+__global__ void gate_mul_bwd_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ x, int ldx, const T* __restrict__ w, int ldw,
+                                    T* __restrict__ dx, int lddx, T* __restrict__ dw, int lddw, long long npix, int C) {
+    PIX_LOOP(npix * ncv) {
+        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        float gg[8], a[8], b[8], o1[8], o2[8];
+        load8(g + p * ldg + cv * 8, gg); load8(x + p * ldx + cv * 8, a); load8(w + p * ldw + cv * 8, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { o1[j] = gg[j] * (1.f + b[j]); o2[j] = gg[j] * a[j]; }
+        store8(dx + p * lddx + cv * 8, o1); store8(dw + p * lddw + cv * 8, o2);
+    }
+}
+
+// ---- out = relu(alpha*a + b) -----------------------------------------------------------------------------
+template <typename T>
+__global__ void scale_add_relu_fwd_kernel(const T* __restrict__ a, int lda, float alpha, const T* __restrict__ b, int ldb,
+                                          T* __restrict__ out, int ldo, long long npix, int C) {
+    PIX_LOOP(npix * ncv) {
+        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        float u[8], v[8];
+        load8(a + p * lda + cv * 8, u); load8(b + p * ldb + cv * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u[j] = fmaxf(alpha * u[j] + v[j], 0.f);
+        store8(out + p * ldo + cv * 8, u);
+    }
+}
+template <typename T>   // mask from the stored output (> 0)
+__global__ void scale_add_relu_bwd_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ out, int ldo, float alpha,
+                                          T* __restrict__ da, int ldda, T* __restrict__ db, int lddb, long long npix, int C) {
+    PIX_LOOP(npix * ncv) {
+        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        float gg[8], o[8], u[8];
+        load8(g + p * ldg + cv * 8, gg); load8(out + p * ldo + cv * 8, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { gg[j] = o[j] > 0.f ? gg[j] : 0.f; u[j] = alpha * gg[j]; }
+        store8(da + p * ldda + cv * 8, u); store8(db + p * lddb + cv * 8, gg);
+    }
+}
+
+// ---- sum over the channels of one pixel: the ncv lanes of a pixel are consecutive lanes -----------------
+// GROUP = power of two >= ncv lanes per pixel (<= 64); lanes beyond ncv contribute 0.
+template <int GROUP>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = GROUP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- target gate: out = x*(1 + mean_k sigmoid(t[k])), k < 3 ------------------------------------------------
+template <typename T>
+__global__ void gate3_fwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ t, int ldt, T* __restrict__ out, int ldo,
+                                 long long npix, int C) {
+    PIX_LOOP(npix * ncv) {
+        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        float a[8], tv[8];
+        load8(x + p * ldx + cv * 8, a); load8(t + p * ldt, tv);
+        const float m = 1.f + (sigm(tv[0]) + sigm(tv[1]) + sigm(tv[2])) * (1.f / 3.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] *= m;
+        store8(out + p * ldo + cv * 8, a);
+    }
+}
+// one block row of GROUP lanes per pixel; dt[k] = (sum_c g*x)/3 * s_k(1-s_k)
+template <typename T, int GROUP>
+__global__ void gate3_bwd_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ x, int ldx, const T* __restrict__ t, int ldt,
+                                 T* __restrict__ dx, int lddx, T* __restrict__ dt, int lddt, long long npix, int C) {
+    const int ncv = C >> 3;
+    const int ppb = 256 / GROUP;                          // pixels per block iteration
+    const int lane_in = threadIdx.x % GROUP, slot = threadIdx.x / GROUP;
+    for (long long p0 = (long long)blockIdx.x * ppb; p0 < npix; p0 += (long long)gridDim.x * ppb) {
+        const long long p = p0 + slot;
+        float dot = 0.f, tv[8];
+        zero8(tv);
+        if (p < npix) {
+            load8(t + p * ldt, tv);
+            const float m = 1.f + (sigm(tv[0]) + sigm(tv[1]) + sigm(tv[2])) * (1.f / 3.f);
+            for (int cv = lane_in; cv < ncv; cv += GROUP) {
+                float gg[8], a[8], o[8];
+                load8(g + p * ldg + cv * 8, gg); load8(x + p * ldx + cv * 8, a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { o[j] = gg[j] * m; dot += gg[j] * a[j]; }
+                store8(dx + p * lddx + cv * 8, o);
+            }
+        }
+        dot = group_sum<GROUP>(dot);
+        if (p < npix && lane_in == 0) {
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float s = sigm(tv[k]); o[k] = k < 3 ? dot * (1.f / 3.f) * s * (1.f - s) : 0.f; }
+            store8(dt + p * lddt, o);
+        }
+    }
+}
+
+// ---- broadcast gate: out = a * sigmoid(gl[...,0]) ----------------------------------------------------------
+template <typename T>
+__global__ void bcast_gate_fwd_kernel(const T* __restrict__ a, int lda, const T* __restrict__ gl, int ldgl, T* __restrict__ out, int ldo,
+                                      long long npix, int C) {
+    PIX_LOOP(npix * ncv) {
+        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        float u[8];
+        load8(a + p * lda + cv * 8, u);
+        const float s = sigm(to_f32(gl[p * ldgl]));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u[j] *= s;
+        store8(out + p * ldo + cv * 8, u);
+    }
+}
+template <typename T, int GROUP>
+__global__ void bcast_gate_bwd_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ a, int lda, const T* __restrict__ gl, int ldgl,
+                                      T* __restrict__ da, int ldda, T* __restrict__ dgl, int lddgl, long long npix, int C) {
+    const int ncv = C >> 3;
+    const int ppb = 256 / GROUP;
+    const int lane_in = threadIdx.x % GROUP, slot = threadIdx.x / GROUP;
+    for (long long p0 = (long long)blockIdx.x * ppb; p0 < npix; p0 += (long long)gridDim.x * ppb) {
+        const long long p = p0 + slot;
+        float dot = 0.f, s = 0.f;
+        if (p < npix) {
+            s = sigm(to_f32(gl[p * ldgl]));
+            for (int cv = lane_in; cv < ncv; cv += GROUP) {
+                float gg[8], u[8], o[8];
+                load8(g + p * ldg + cv * 8, gg); load8(a + p * lda + cv * 8, u);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { o[j] = gg[j] * s; dot += gg[j] * u[j]; }
+                store8(da + p * ldda + cv * 8, o);
+            }
+        }
+        dot = group_sum<GROUP>(dot);
+        if (p < npix && lane_in == 0) {
+            float o[8]; zero8(o);
+            o[0] = dot * s * (1.f - s);
+            store8(dgl + p * lddgl, o);
+        }
+    }
+}
+
+// ---- GELU (erf form, nn.GELU default) -----------------------------------------------------------------------
+template <typename T>
+__global__ void gelu_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ out, int ldo, long long npix, int C) {
+    PIX_LOOP(npix * ncv) {
+        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        float v[8];
+        load8(x + p * ldx + cv * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.5f * v[j] * (1.f + erff(v[j] * 0.70710678118654752f));
+        store8(out + p * ldo + cv * 8, v);
+    }
+}
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ x, int ldx, T* __restrict__ dx, int lddx,
+                                long long npix, int C) {
+    PIX_LOOP(npix * ncv) {
+        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        float gg[8], v[8];
+        load8(g + p * ldg + cv * 8, gg); load8(x + p * ldx + cv * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float cdf = 0.5f * (1.f + erff(v[j] * 0.70710678118654752f));
+            const float pdf = 0.3989422804014327f * expf(-0.5f * v[j] * v[j]);
+            gg[j] *= cdf + v[j] * pdf;
+        }
+        store8(dx + p * lddx + cv * 8, gg);
+    }
+}
+
+// ---- per-pixel channel mean / max -> 8-channel map (ch0 = mean, ch1 = max, rest 0) ---------------------------
+template <typename T, int GROUP>
+__global__ void chan_meanmax_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ out, int ldo, long long npix, int C, int Creal) {
+    const int ncv = C >> 3;
+    const int ppb = 256 / GROUP;
+    const int lane_in = threadIdx.x % GROUP, slot = threadIdx.x / GROUP;
+    for (long long p0 = (long long)blockIdx.x * ppb; p0 < npix; p0 += (long long)gridDim.x * ppb) {
+        const long long p = p0 + slot;
+        float s = 0.f, m = -INFINITY;
+        if (p < npix)
+            for (int cv = lane_in; cv < ncv; cv += GROUP) {
+                float v[8];
+                load8(x + p * ldx + cv * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (cv * 8 + j < Creal) { s += v[j]; m = fmaxf(m, v[j]); }
+            }
+        s = group_sum<GROUP>(s);
+#pragma unroll
+        for (int o = GROUP / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (p < npix && lane_in == 0) {
+            float o[8]; zero8(o);
+            o[0] = s / (float)Creal; o[1] = m;
+            store8(out + p * ldo, o);
+        }
+    }
+}
+// dx[c] = gmean/Creal + gmax*[c == first argmax]
+template <typename T, int GROUP>
+__global__ void chan_meanmax_bwd_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ x, int ldx, T* __restrict__ dx, int lddx,
+                                        long long npix, int C, int Creal) {
+    const int ncv = C >> 3;
+    const int ppb = 256 / GROUP;
+    const int lane_in = threadIdx.x % GROUP, slot = threadIdx.x / GROUP;
+    for (long long p0 = (long long)blockIdx.x * ppb; p0 < npix; p0 += (long long)gridDim.x * ppb) {
+        const long long p = p0 + slot;
+        float m = -INFINITY; int am = 0x7fffffff;
+        if (p < npix)
+            for (int cv = lane_in; cv < ncv; cv += GROUP) {
+                float v[8];
+                load8(x + p * ldx + cv * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (cv * 8 + j < Creal && v[j] > m) { m = v[j]; am = cv * 8 + j; }
+            }
+        // argmax across the group, lowest channel index wins ties (torch.max(dim) returns the first maximum)
+#pragma unroll
+        for (int o = GROUP / 2; o > 0; o >>= 1) {
+            const float m2 = __shfl_xor(m, o, 64); const int a2 = __shfl_xor(am, o, 64);
+            if (m2 > m || (m2 == m && a2 < am)) { m = m2; am = a2; }
+        }
+        if (p < npix) {
+            const float gm = to_f32(g[p * ldg]) / (float)Creal, gx = to_f32(g[p * ldg + 1]);
+            for (int cv = lane_in; cv < ncv; cv += GROUP) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (cv * 8 + j < Creal) ? gm + ((cv * 8 + j == am) ? gx : 0.f) : 0.f;
+                store8(dx + p * lddx + cv * 8, o);
+            }
+        }
+    }
+}
+
+// ---- global average / max pool per image: partial stage [N][nblk][2][C] (sum, max) + argmax position ------------
+template <typename T>
+__global__ __launch_bounds__(256) void global_pool_partial_kernel(const T* __restrict__ x, int ldx, long long HW, int C,
+                                                                  float* __restrict__ part, int* __restrict__ part_idx) {
+    __shared__ float rs[256 * 8];
+    __shared__ float rm[256 * 8];
+    __shared__ int ri[256 * 8];
+    const int n = blockIdx.y, ncv = C >> 3, rows = 256 / ncv;
+    const int tid = threadIdx.x, cv = tid % ncv, row = tid / ncv;
+    float s[8], m[8]; int ix[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; m[j] = -INFINITY; ix[j] = 0x7fffffff; }
+    if (row < rows)
+        for (long long p = (long long)blockIdx.x * rows + row; p < HW; p += (long long)gridDim.x * rows) {
+            float v[8];
+            load8(x + ((long long)n * HW + p) * ldx + cv * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[j] += v[j]; if (v[j] > m[j]) { m[j] = v[j]; ix[j] = (int)p; } }
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { rs[tid * 8 + j] = s[j]; rm[tid * 8 + j] = m[j]; ri[tid * 8 + j] = ix[j]; }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float ss = 0.f, mm = -INFINITY; int ii = 0x7fffffff;
+        for (int r = 0; r < rows; ++r) {
+            const int k = (r * ncv + (c >> 3)) * 8 + (c & 7);
+            ss += rs[k];
+            if (rm[k] > mm || (rm[k] == mm && ri[k] < ii)) { mm = rm[k]; ii = ri[k]; }
+        }
+        const long long o = ((long long)n * gridDim.x + blockIdx.x) * 2 * C;
+        part[o + c] = ss; part[o + C + c] = mm;
+        part_idx[((long long)n * gridDim.x + blockIdx.x) * C + c] = ii;
+    }
+}
+// out rows [0,N) = average, rows [N,2N) = max, dtype T, [2N][C]; argidx [N][C] = first position of the max
+template <typename T>
+__global__ void global_pool_final_kernel(const float* __restrict__ part, const int* __restrict__ part_idx, int nblk, int N, long long HW,
+                                         int C, T* __restrict__ out, int* __restrict__ argidx) {
+    const int n = blockIdx.y;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        double ss = 0.0; float mm = -INFINITY; int ii = 0x7fffffff;
+        for (int b = 0; b < nblk; ++b) {
+            const long long o = ((long long)n * nblk + b) * 2 * C;
+            ss += (double)part[o + c];
+            const float m = part[o + C + c]; const int k = part_idx[((long long)n * nblk + b) * C + c];
+            if (m > mm || (m == mm && k < ii)) { mm = m; ii = k; }
+        }
+        out[(long long)n * C + c] = from_f32<T>((float)(ss / (double)HW));
+        out[(long long)(N + n) * C + c] = from_f32<T>(mm);
+        argidx[(long long)n * C + c] = ii;
+    }
+}
+// dx[n,p,c] = gavg[n,c]/HW + gmax[n,c]*[p == argidx[n,c]]
+template <typename T>
+__global__ void global_pool_bwd_kernel(const T* __restrict__ gout, const int* __restrict__ argidx, T* __restrict__ dx, int lddx, int N,
+                                       long long HW, int C) {
+    PIX_LOOP((long long)N * HW * ncv) {
+        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        const long long n = p / HW, pp = p - n * HW;
+        float ga[8], gm[8], o[8];
+        load8(gout + n * C + cv * 8, ga); load8(gout + (N + n) * C + cv * 8, gm);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = ga[j] / (float)HW + ((long long)argidx[n * C + cv * 8 + j] == pp ? gm[j] : 0.f);
+        store8(dx + p * lddx + cv * 8, o);
+    }
+}
+
+// ---- FusionConv combine: out = f + s*sigmoid(sa[...,0]) * sigmoid(ca[n,c] + ca[N+n,c]) ------------------------------
+template <typename T>
+__global__ void fusion_combine_fwd_kernel(const T* __restrict__ f, int ldf, const T* __restrict__ sv, int lds, const T* __restrict__ sa,
+                                          int ldsa, const T* __restrict__ ca, T* __restrict__ out, int ldo, int N, long long HW, int C) {
+    PIX_LOOP((long long)N * HW * ncv) {
+        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        const long long n = p / HW;
+        float a[8], b[8], c1[8], c2[8];
+        load8(f + p * ldf + cv * 8, a); load8(sv + p * lds + cv * 8, b);
+        load8(ca + n * C + cv * 8, c1); load8(ca + (N + n) * C + cv * 8, c2);
+        const float ss = sigm(to_f32(sa[p * ldsa]));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += b[j] * ss * sigm(c1[j] + c2[j]);
+        store8(out + p * ldo + cv * 8, a);
+    }
+}
+// ds = g*ssa*sca ; dsa[p] = sum_c g*s*sca * ssa(1-ssa) ; dca partial[n][blk][C] = sum_p g*s*ssa * sca(1-sca)
+template <typename T, int GROUP>
+__global__ __launch_bounds__(256) void fusion_combine_bwd_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ sv, int lds,
+                                                                 const T* __restrict__ sa, int ldsa, const T* __restrict__ ca,
+                                                                 T* __restrict__ ds, int ldds, T* __restrict__ dsa, int lddsa,
+                                                                 float* __restrict__ part, int N, long long HW, int C) {
+    __shared__ float red[256 * 8];
+    const int n = blockIdx.y, ncv = C >> 3;
+    const int ppb = 256 / GROUP;
+    const int lane_in = threadIdx.x % GROUP, slot = threadIdx.x / GROUP;
+    // each lane owns channel vectors lane_in, lane_in+GROUP, ...; GROUP >= ncv is guaranteed by the launcher, so one vector
+    const int cv = lane_in;
+    float sca[8], acc[8];
+    zero8(acc); zero8(sca);
+    if (cv < ncv) {
+        float c1[8], c2[8];
+        load8(ca + (long long)n * C + cv * 8, c1); load8(ca + (long long)(N + n) * C + cv * 8, c2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sca[j] = sigm(c1[j] + c2[j]);
+    }
+    for (long long p0 = (long long)blockIdx.x * ppb; p0 < HW; p0 += (long long)gridDim.x * ppb) {
+        const long long pl = p0 + slot, p = (long long)n * HW + pl;
+        float dot = 0.f, ss = 0.f;
+        if (pl < HW && cv < ncv) {
+            float gg[8], b[8], o[8];
+            ss = sigm(to_f32(sa[p * ldsa]));
+            load8(g + p * ldg + cv * 8, gg); load8(sv + p * lds + cv * 8, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o[j] = gg[j] * ss * sca[j];
+                dot += gg[j] * b[j] * sca[j];
+                acc[j] += gg[j] * b[j] * ss * sca[j] * (1.f - sca[j]);
+            }
+            store8(ds + p * ldds + cv * 8, o);
+        }
+        dot = group_sum<GROUP>(dot);
+        if (pl < HW && lane_in == 0) {
+            float o[8]; zero8(o);
+            o[0] = dot * ss * (1.f - ss);
+            store8(dsa + p * lddsa, o);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = acc[j];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float v = 0.f;
+        for (int sl = 0; sl < ppb; ++sl) v += red[(sl * GROUP + (c >> 3)) * 8 + (c & 7)];
+        const long long o = ((long long)n * gridDim.x + blockIdx.x) * 2 * C;
+        part[o + c] = v; part[o + C + c] = 0.f;
+    }
+}
+
+// ---- tiny parameter transforms (FusionConv algebraic folds) ---------------------------------------------------------
+// down conv sees cat([x, x]): fold W[:, :K] + W[:, K:]  (and its gradient: both halves receive dWf)
+__global__ void fold2_fwd_kernel(const float* __restrict__ w, float* __restrict__ out, int rows, int K) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * K; i += gridDim.x * blockDim.x) {
+        const int r = i / K, k = i - r * K;
+        out[i] = w[(long long)r * 2 * K + k] + w[(long long)r * 2 * K + K + k];
+    }
+}
+__global__ void fold2_bwd_kernel(const float* __restrict__ g, float* __restrict__ dw, int rows, int K) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * K; i += gridDim.x * blockDim.x) {
+        const int r = i / K, k = i - r * K;
+        dw[(long long)r * 2 * K + k] = g[i]; dw[(long long)r * 2 * K + K + k] = g[i];
+    }
+}
+// conv3 + conv5 + conv7 of the same input == one 7x7 conv with the zero-padded kernels summed
+__global__ void merge357_fwd_kernel(const float* __restrict__ w3, const float* __restrict__ w5, const float* __restrict__ w7,
+                                    const float* __restrict__ b3, const float* __restrict__ b5, const float* __restrict__ b7,
+                                    float* __restrict__ w, float* __restrict__ b, int Co, int Ci) {
+    const int total = Co * Ci * 49;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int t = i % 49, oc = i / 49, r = t / 7, s = t % 7;
+        float v = w7[i];
+        if (r >= 1 && r <= 5 && s >= 1 && s <= 5) v += w5[oc * 25 + (r - 1) * 5 + (s - 1)];
+        if (r >= 2 && r <= 4 && s >= 2 && s <= 4) v += w3[oc * 9 + (r - 2) * 3 + (s - 2)];
+        w[i] = v;
+        if (i < Co) b[i] = b3[i] + b5[i] + b7[i];
+    }
+}
+__global__ void merge357_bwd_kernel(const float* __restrict__ gw, float* __restrict__ d3, float* __restrict__ d5, float* __restrict__ d7,
+                                    int Co, int Ci) {
+    const int total = Co * Ci * 49;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int t = i % 49, oc = i / 49, r = t / 7, s = t % 7;
+        const float v = gw[i];
+        d7[i] = v;
+        if (r >= 1 && r <= 5 && s >= 1 && s <= 5) d5[oc * 25 + (r - 1) * 5 + (s - 1)] = v;
+        if (r >= 2 && r <= 4 && s >= 2 && s <= 4) d3[oc * 9 + (r - 2) * 3 + (s - 2)] = v;
+    }
+}
+
+inline int group_for(int ncv) { int g = 1; while (g < ncv) g <<= 1; return g; }
+
+}  // namespace
+
+#define EGM_REQ_VEC(name, ptr, ld, C)                                                                      \
+    EGM_REQUIRE((ptr) != nullptr && egm_aligned16(ptr) && (C) > 0 && (C) % 8 == 0 && (ld) >= (C) && (ld) % 8 == 0, \
+                name ": bad tensor (ptr/alignment/C=%d/ld=%d)", (int)(C), (int)(ld))
+#define EGM_GROUP_SWITCH(G, ...)                                                                \
+    switch (G) { case 1: { constexpr int GROUP = 1; __VA_ARGS__; break; } case 2: { constexpr int GROUP = 2; __VA_ARGS__; break; } \
+                 case 4: { constexpr int GROUP = 4; __VA_ARGS__; break; } case 8: { constexpr int GROUP = 8; __VA_ARGS__; break; } \
+                 case 16: { constexpr int GROUP = 16; __VA_ARGS__; break; } case 32: { constexpr int GROUP = 32; __VA_ARGS__; break; } \
+                 default: { constexpr int GROUP = 64; __VA_ARGS__; break; } }
+
+extern "C" int egm_highpass3(int dtype, const void* x, int ldx, void* out, int ldo, int N, int H, int W, int C, egm_stream_t s) {
+    EGM_REQ_VEC("highpass3", x, ldx, C); EGM_REQ_VEC("highpass3", out, ldo, C);
+    EGM_REQUIRE(N > 0 && H > 0 && W > 0, "highpass3: bad shape");
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((highpass3_kernel<T>), dim3(stream_grid((long long)N * H * W * (C / 8))), dim3(256), 0,
+                                                 (hipStream_t)s, (const T*)x, ldx, (T*)out, ldo, N, H, W, C));
+    EGM_CHECK_LAUNCH("highpass3");
+    return EGM_OK;
+}
+extern "C" int egm_gate_mul_fwd(int dtype, const void* x, int ldx, const void* w, int ldw, void* out, int ldo, long long npix, int C,
+                                egm_stream_t s) {
+    EGM_REQ_VEC("gate_mul_fwd", x, ldx, C); EGM_REQ_VEC("gate_mul_fwd", w, ldw, C); EGM_REQ_VEC("gate_mul_fwd", out, ldo, C);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gate_mul_fwd_kernel<T>), dim3(stream_grid(npix * (C / 8))), dim3(256), 0, (hipStream_t)s,
+                                                 (const T*)x, ldx, (const T*)w, ldw, (T*)out, ldo, npix, C));
+    EGM_CHECK_LAUNCH("gate_mul_fwd");
+    return EGM_OK;
+}
+extern "C" int egm_gate_mul_bwd(int dtype, const void* g, int ldg, const void* x, int ldx, const void* w, int ldw, void* dx, int lddx,
+                                void* dw, int lddw, long long npix, int C, egm_stream_t s) {
+    EGM_REQ_VEC("gate_mul_bwd", g, ldg, C); EGM_REQ_VEC("gate_mul_bwd", x, ldx, C); EGM_REQ_VEC("gate_mul_bwd", w, ldw, C);
+    EGM_REQ_VEC("gate_mul_bwd", dx, lddx, C); EGM_REQ_VEC("gate_mul_bwd", dw, lddw, C);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gate_mul_bwd_kernel<T>), dim3(stream_grid(npix * (C / 8))), dim3(256), 0, (hipStream_t)s,
+                                                 (const T*)g, ldg, (const T*)x, ldx, (const T*)w, ldw, (T*)dx, lddx, (T*)dw, lddw, npix, C));
+    EGM_CHECK_LAUNCH("gate_mul_bwd");
+    return EGM_OK;
+}
+extern "C" int egm_scale_add_relu_fwd(int dtype, const void* a, int lda, float alpha, const void* b, int ldb, void* out, int ldo,
+                                      long long npix, int C, egm_stream_t s) {
+    EGM_REQ_VEC("scale_add_relu_fwd", a, lda, C); EGM_REQ_VEC("scale_add_relu_fwd", b, ldb, C); EGM_REQ_VEC("scale_add_relu_fwd", out, ldo, C);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((scale_add_relu_fwd_kernel<T>), dim3(stream_grid(npix * (C / 8))), dim3(256), 0,
+                                                 (hipStream_t)s, (const T*)a, lda, alpha, (const T*)b, ldb, (T*)out, ldo, npix, C));
+    EGM_CHECK_LAUNCH("scale_add_relu_fwd");
+    return EGM_OK;
+}
+extern "C" int egm_scale_add_relu_bwd(int dtype, const void* g, int ldg, const void* out, int ldo, float alpha, void* da, int ldda,
+                                      void* db, int lddb, long long npix, int C, egm_stream_t s) {
+    EGM_REQ_VEC("scale_add_relu_bwd", g, ldg, C); EGM_REQ_VEC("scale_add_relu_bwd", out, ldo, C);
+    EGM_REQ_VEC("scale_add_relu_bwd", da, ldda, C); EGM_REQ_VEC("scale_add_relu_bwd", db, lddb, C);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((scale_add_relu_bwd_kernel<T>), dim3(stream_grid(npix * (C / 8))), dim3(256), 0,
+                                                 (hipStream_t)s, (const T*)g, ldg, (const T*)out, ldo, alpha, (T*)da, ldda, (T*)db, lddb, npix, C));
+    EGM_CHECK_LAUNCH("scale_add_relu_bwd");
+    return EGM_OK;
+}
+extern "C" int egm_gate3_fwd(int dtype, const void* x, int ldx, const void* t, int ldt, void* out, int ldo, long long npix, int C,
+                             egm_stream_t s) {
+    EGM_REQ_VEC("gate3_fwd", x, ldx, C); EGM_REQ_VEC("gate3_fwd", t, ldt, 8); EGM_REQ_VEC("gate3_fwd", out, ldo, C);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gate3_fwd_kernel<T>), dim3(stream_grid(npix * (C / 8))), dim3(256), 0, (hipStream_t)s,
+                                                 (const T*)x, ldx, (const T*)t, ldt, (T*)out, ldo, npix, C));
+    EGM_CHECK_LAUNCH("gate3_fwd");
+    return EGM_OK;
+}
+extern "C" int egm_gate3_bwd(int dtype, const void* g, int ldg, const void* x, int ldx, const void* t, int ldt, void* dx, int lddx,
+                             void* dt, int lddt, long long npix, int C, egm_stream_t s) {
+    EGM_REQ_VEC("gate3_bwd", g, ldg, C); EGM_REQ_VEC("gate3_bwd", x, ldx, C); EGM_REQ_VEC("gate3_bwd", t, ldt, 8);
+    EGM_REQ_VEC("gate3_bwd", dx, lddx, C); EGM_REQ_VEC("gate3_bwd", dt, lddt, 8);
+    const int G = group_for(C / 8 > 64 ? 64 : C / 8);
+    const int grid = stream_grid(npix * G);
+    EGM_DISPATCH_DTYPE(dtype, EGM_GROUP_SWITCH(G, hipLaunchKernelGGL((gate3_bwd_kernel<T, GROUP>), dim3(grid), dim3(256), 0, (hipStream_t)s,
+                                                                     (const T*)g, ldg, (const T*)x, ldx, (const T*)t, ldt, (T*)dx, lddx,
+                                                                     (T*)dt, lddt, npix, C)));
+    EGM_CHECK_LAUNCH("gate3_bwd");
+    return EGM_OK;
+}
+extern "C" int egm_bcast_gate_fwd(int dtype, const void* a, int lda, const void* gl, int ldgl, void* out, int ldo, long long npix, int C,
+                                  egm_stream_t s) {
+    EGM_REQ_VEC("bcast_gate_fwd", a, lda, C); EGM_REQ_VEC("bcast_gate_fwd", gl, ldgl, 8); EGM_REQ_VEC("bcast_gate_fwd", out, ldo, C);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bcast_gate_fwd_kernel<T>), dim3(stream_grid(npix * (C / 8))), dim3(256), 0, (hipStream_t)s,
+                                                 (const T*)a, lda, (const T*)gl, ldgl, (T*)out, ldo, npix, C));
+    EGM_CHECK_LAUNCH("bcast_gate_fwd");
+    return EGM_OK;
+}
+extern "C" int egm_bcast_gate_bwd(int dtype, const void* g, int ldg, const void* a, int lda, const void* gl, int ldgl, void* da, int ldda,
+                                  void* dgl, int lddgl, long long npix, int C, egm_stream_t s) {
+    EGM_REQ_VEC("bcast_gate_bwd", g, ldg, C); EGM_REQ_VEC("bcast_gate_bwd", a, lda, C); EGM_REQ_VEC("bcast_gate_bwd", gl, ldgl, 8);
+    EGM_REQ_VEC("bcast_gate_bwd", da, ldda, C); EGM_REQ_VEC("bcast_gate_bwd", dgl, lddgl, 8);
+    const int G = group_for(C / 8 > 64 ? 64 : C / 8);
+    const int grid = stream_grid(npix * G);
+    EGM_DISPATCH_DTYPE(dtype, EGM_GROUP_SWITCH(G, hipLaunchKernelGGL((bcast_gate_bwd_kernel<T, GROUP>), dim3(grid), dim3(256), 0,
+                                                                     (hipStream_t)s, (const T*)g, ldg, (const T*)a, lda, (const T*)gl, ldgl,
+                                                                     (T*)da, ldda, (T*)dgl, lddgl, npix, C)));
+    EGM_CHECK_LAUNCH("bcast_gate_bwd");
+    return EGM_OK;
+}
+extern "C" int egm_gelu_fwd(int dtype, const void* x, int ldx, void* out, int ldo, long long npix, int C, egm_stream_t s) {
+    EGM_REQ_VEC("gelu_fwd", x, ldx, C); EGM_REQ_VEC("gelu_fwd", out, ldo, C);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gelu_fwd_kernel<T>), dim3(stream_grid(npix * (C / 8))), dim3(256), 0, (hipStream_t)s,
+                                                 (const T*)x, ldx, (T*)out, ldo, npix, C));
+    EGM_CHECK_LAUNCH("gelu_fwd");
+    return EGM_OK;
+}
+extern "C" int egm_gelu_bwd(int dtype, const void* g, int ldg, const void* x, int ldx, void* dx, int lddx, long long npix, int C,
+                            egm_stream_t s) {
+    EGM_REQ_VEC("gelu_bwd", g, ldg, C); EGM_REQ_VEC("gelu_bwd", x, ldx, C); EGM_REQ_VEC("gelu_bwd", dx, lddx, C);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gelu_bwd_kernel<T>), dim3(stream_grid(npix * (C / 8))), dim3(256), 0, (hipStream_t)s,
+                                                 (const T*)g, ldg, (const T*)x, ldx, (T*)dx, lddx, npix, C));
+    EGM_CHECK_LAUNCH("gelu_bwd");
+    return EGM_OK;
+}
+extern "C" int egm_chan_meanmax_fwd(int dtype, const void* x, int ldx, void* out, int ldo, long long npix, int C, int C_real,
+                                    egm_stream_t s) {
+    EGM_REQ_VEC("chan_meanmax_fwd", x, ldx, C); EGM_REQ_VEC("chan_meanmax_fwd", out, ldo, 8);
+    EGM_REQUIRE(C_real > 0 && C_real <= C, "chan_meanmax_fwd: bad C_real");
+    const int G = group_for(C / 8 > 64 ? 64 : C / 8);
+    EGM_DISPATCH_DTYPE(dtype, EGM_GROUP_SWITCH(G, hipLaunchKernelGGL((chan_meanmax_fwd_kernel<T, GROUP>), dim3(stream_grid(npix * G)), dim3(256),
+                                                                     0, (hipStream_t)s, (const T*)x, ldx, (T*)out, ldo, npix, C, C_real)));
+    EGM_CHECK_LAUNCH("chan_meanmax_fwd");
+    return EGM_OK;
+}
+extern "C" int egm_chan_meanmax_bwd(int dtype, const void* g, int ldg, const void* x, int ldx, void* dx, int lddx, long long npix, int C,
+                                    int C_real, egm_stream_t s) {
+    EGM_REQ_VEC("chan_meanmax_bwd", g, ldg, 8); EGM_REQ_VEC("chan_meanmax_bwd", x, ldx, C); EGM_REQ_VEC("chan_meanmax_bwd", dx, lddx, C);
+    EGM_REQUIRE(C_real > 0 && C_real <= C, "chan_meanmax_bwd: bad C_real");
+    const int G = group_for(C / 8 > 64 ? 64 : C / 8);
+    EGM_DISPATCH_DTYPE(dtype, EGM_GROUP_SWITCH(G, hipLaunchKernelGGL((chan_meanmax_bwd_kernel<T, GROUP>), dim3(stream_grid(npix * G)), dim3(256),
+                                                                     0, (hipStream_t)s, (const T*)g, ldg, (const T*)x, ldx, (T*)dx, lddx, npix,
+                                                                     C, C_real)));
+    EGM_CHECK_LAUNCH("chan_meanmax_bwd");
+    return EGM_OK;
+}
+
+static int pool_blocks(long long HW, int C) {
+    const int rows = 256 / (C >> 3);
+    long long b = (HW + rows - 1) / rows;
+    if (b > 128) b = 128;
+    return (int)(b < 1 ? 1 : b);
+}
+extern "C" long long egm_global_pool_workspace(int N, long long HW, int C) {
+    if (N <= 0 || HW <= 0 || C <= 0 || C % 8 || C > 2048) return -1;
+    return (long long)N * pool_blocks(HW, C) * 3 * C * 4;
+}
+extern "C" int egm_global_avgmax_fwd(int dtype, const void* x, int ldx, void* out, int* argidx, void* workspace, int N, long long HW,
+                                     int C, egm_stream_t s) {
+    EGM_REQ_VEC("global_avgmax_fwd", x, ldx, C);
+    EGM_REQUIRE(out && argidx && workspace && egm_aligned16(out) && N > 0 && HW > 0 && C <= 2048, "global_avgmax_fwd: bad args");
+    const int nb = pool_blocks(HW, C);
+    float* part = (float*)workspace;
+    int* pidx = (int*)(part + (long long)N * nb * 2 * C);
+    EGM_DISPATCH_DTYPE(dtype, {
+        hipLaunchKernelGGL((global_pool_partial_kernel<T>), dim3(nb, N), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, HW, C, part, pidx);
+        hipLaunchKernelGGL((global_pool_final_kernel<T>), dim3((C + 255) / 256, N), dim3(256), 0, (hipStream_t)s, part, pidx, nb, N, HW, C,
+                           (T*)out, argidx);
+    });
+    EGM_CHECK_LAUNCH("global_avgmax_fwd");
+    return EGM_OK;
+}
+extern "C" int egm_global_avgmax_bwd(int dtype, const void* gout, const int* argidx, void* dx, int lddx, int N, long long HW, int C,
+                                     egm_stream_t s) {
+    EGM_REQ_VEC("global_avgmax_bwd", dx, lddx, C);
+    EGM_REQUIRE(gout && argidx && egm_aligned16(gout) && N > 0 && HW > 0, "global_avgmax_bwd: bad args");
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((global_pool_bwd_kernel<T>), dim3(stream_grid((long long)N * HW * (C / 8))), dim3(256), 0,
+                                                 (hipStream_t)s, (const T*)gout, argidx, (T*)dx, lddx, N, HW, C));
+    EGM_CHECK_LAUNCH("global_avgmax_bwd");
+    return EGM_OK;
+}
+
+extern "C" int egm_fusion_combine_fwd(int dtype, const void* f, int ldf, const void* sv, int lds, const void* sa, int ldsa, const void* ca,
+                                      void* out, int ldo, int N, long long HW, int C, egm_stream_t s) {
+    EGM_REQ_VEC("fusion_combine_fwd", f, ldf, C); EGM_REQ_VEC("fusion_combine_fwd", sv, lds, C); EGM_REQ_VEC("fusion_combine_fwd", sa, ldsa, 8);
+    EGM_REQ_VEC("fusion_combine_fwd", out, ldo, C);
+    EGM_REQUIRE(ca && egm_aligned16(ca) && N > 0 && HW > 0, "fusion_combine_fwd: bad args");
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((fusion_combine_fwd_kernel<T>), dim3(stream_grid((long long)N * HW * (C / 8))), dim3(256), 0,
+                                                 (hipStream_t)s, (const T*)f, ldf, (const T*)sv, lds, (const T*)sa, ldsa, (const T*)ca, (T*)out,
+                                                 ldo, N, HW, C));
+    EGM_CHECK_LAUNCH("fusion_combine_fwd");
+    return EGM_OK;
+}
+extern "C" int egm_fusion_combine_blocks(long long HW, int C) {
+    if (C <= 0 || C % 8 || C > 512) return -1;
+    const int G = group_for(C / 8);
+    long long b = (HW + 256 / G - 1) / (256 / G);
+    if (b > 256) b = 256;
+    return (int)(b < 1 ? 1 : b);
+}
+/* partials: fp32 [N][nblk][2][C] (tile format; reduce with egm_reduce_tiles per image -> dca[n][c] in row 0) */
+extern "C" int egm_fusion_combine_bwd(int dtype, const void* g, int ldg, const void* sv, int lds, const void* sa, int ldsa, const void* ca,
+                                      void* ds, int ldds, void* dsa, int lddsa, float* partials, int N, long long HW, int C, egm_stream_t s) {
+    EGM_REQ_VEC("fusion_combine_bwd", g, ldg, C); EGM_REQ_VEC("fusion_combine_bwd", sv, lds, C); EGM_REQ_VEC("fusion_combine_bwd", sa, ldsa, 8);
+    EGM_REQ_VEC("fusion_combine_bwd", ds, ldds, C); EGM_REQ_VEC("fusion_combine_bwd", dsa, lddsa, 8);
+    EGM_REQUIRE(ca && partials && N > 0 && HW > 0 && C <= 512, "fusion_combine_bwd: bad args (C <= 512)");
+    const int G = group_for(C / 8);
+    const int nb = egm_fusion_combine_blocks(HW, C);
+    EGM_DISPATCH_DTYPE(dtype, EGM_GROUP_SWITCH(G, hipLaunchKernelGGL((fusion_combine_bwd_kernel<T, GROUP>), dim3(nb, N), dim3(256), 0,
+                                                                     (hipStream_t)s, (const T*)g, ldg, (const T*)sv, lds, (const T*)sa, ldsa,
+                                                                     (const T*)ca, (T*)ds, ldds, (T*)dsa, lddsa, partials, N, HW, C)));
+    EGM_CHECK_LAUNCH("fusion_combine_bwd");
+    return EGM_OK;
+}
+
+extern "C" int egm_fold2_fwd(const float* w, float* out, int rows, int K, egm_stream_t s) {
+    EGM_REQUIRE(w && out && rows > 0 && K > 0, "fold2_fwd: bad args");
+    hipLaunchKernelGGL(fold2_fwd_kernel, dim3((rows * K + 255) / 256), dim3(256), 0, (hipStream_t)s, w, out, rows, K);
+    EGM_CHECK_LAUNCH("fold2_fwd");
+    return EGM_OK;
+}
+extern "C" int egm_fold2_bwd(const float* g, float* dw, int rows, int K, egm_stream_t s) {
+    EGM_REQUIRE(g && dw && rows > 0 && K > 0, "fold2_bwd: bad args");
+    hipLaunchKernelGGL(fold2_bwd_kernel, dim3((rows * K + 255) / 256), dim3(256), 0, (hipStream_t)s, g, dw, rows, K);
+    EGM_CHECK_LAUNCH("fold2_bwd");
+    return EGM_OK;
+}
+extern "C" int egm_merge357_fwd(const float* w3, const float* w5, const float* w7, const float* b3, const float* b5, const float* b7,
+                                float* w, float* b, int Co, int Ci, egm_stream_t s) {
+    EGM_REQUIRE(w3 && w5 && w7 && b3 && b5 && b7 && w && b && Co > 0 && Ci > 0, "merge357_fwd: bad args");
+    hipLaunchKernelGGL(merge357_fwd_kernel, dim3((Co * Ci * 49 + 255) / 256), dim3(256), 0, (hipStream_t)s, w3, w5, w7, b3, b5, b7, w, b, Co, Ci);
+    EGM_CHECK_LAUNCH("merge357_fwd");
+    return EGM_OK;
+}
+extern "C" int egm_merge357_bwd(const float* gw, float* d3, float* d5, float* d7, int Co, int Ci, egm_stream_t s) {
+    EGM_REQUIRE(gw && d3 && d5 && d7 && Co > 0 && Ci > 0, "merge357_bwd: bad args");
+    hipLaunchKernelGGL(merge357_bwd_kernel, dim3((Co * Ci * 49 + 255) / 256), dim3(256), 0, (hipStream_t)s, gw, d3, d5, d7, Co, Ci);
+    EGM_CHECK_LAUNCH("merge357_bwd");
+    return EGM_OK;
+}

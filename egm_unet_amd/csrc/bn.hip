@@ -91,6 +91,8 @@ __device__ __forceinline__ void tiles_reduce(const float* __restrict__ st, int n
 __global__ __launch_bounds__(1024) void reduce_tiles_kernel(const float* __restrict__ st, int ntiles, int C, float* __restrict__ out) {
     __shared__ double red[2048];
     double s, q;
+    st += (long long)blockIdx.y * ntiles * 2 * C;                 // batched: one independent reduction per blockIdx.y
+    out += (long long)blockIdx.y * 2 * C;
     tiles_reduce(st, ntiles, C, blockIdx.x * 8, s, q, red);
     const int c = blockIdx.x * 8 + (threadIdx.x & 7);
     if (threadIdx.x < 8 && c < C) { out[c] = (float)s; out[C + c] = (float)q; }
@@ -218,9 +220,15 @@ extern "C" int egm_channel_sums(int dtype, const void* x, int ld, long long npix
     return EGM_OK;
 }
 
+extern "C" int egm_reduce_tiles_batched(const float* tiles, int batch, int ntiles, int C, float* out, egm_stream_t s) {
+    EGM_REQUIRE(tiles && out && batch > 0 && ntiles > 0 && C > 0, "reduce_tiles_batched: bad args");
+    hipLaunchKernelGGL(reduce_tiles_kernel, dim3((C + 7) / 8, batch), dim3(1024), 0, (hipStream_t)s, tiles, ntiles, C, out);
+    EGM_CHECK_LAUNCH("reduce_tiles_batched");
+    return EGM_OK;
+}
 extern "C" int egm_reduce_tiles(const float* tiles, int ntiles, int C, float* out, egm_stream_t s) {
     EGM_REQUIRE(tiles && out && ntiles > 0 && C > 0, "reduce_tiles: bad args");
-    hipLaunchKernelGGL(reduce_tiles_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)s, tiles, ntiles, C, out);
+    hipLaunchKernelGGL(reduce_tiles_kernel, dim3((C + 7) / 8, 1), dim3(1024), 0, (hipStream_t)s, tiles, ntiles, C, out);
     EGM_CHECK_LAUNCH("reduce_tiles");
     return EGM_OK;
 }

@@ -1,0 +1,313 @@
+"""EGM-UNet ("GRFBUNet") with the reference's constructor, forward() and state_dict() surface
+(src/EGM-UNet.py:1503-1541 and the live blocks it instantiates), computed by the HIP library.
+
+Every nn.Conv2d / nn.BatchNorm2d / nn.Parameter below is a PARAMETER HOLDER laid out exactly like the reference module
+tree (same attribute names, same construction order, so `torch.manual_seed(s); GRFBUNet(...)` gives the reference's
+initial weights and reference checkpoints load with strict=True).  The holders' own forward is never called: each
+block's forward() below runs NHWC tensors through egm_unet_amd.ops.
+"""
+import math
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID
+from .unet import DoubleConv, OutConv, Up, _SegNetBase
+
+
+# --------------------------------------------------------------------------------------------------------------
+# MCALayer (src/EGM-UNet.py:686-791)
+# --------------------------------------------------------------------------------------------------------------
+class StdPool(nn.Module):
+    """Holder only (src/EGM-UNet.py:827-834); the statistics come from egm_mca_reduce."""
+
+
+class MCAGate(nn.Module):
+    def __init__(self, k_size, pool_types=("avg", "std")):
+        super().__init__()
+        self.pools = nn.ModuleList([nn.AdaptiveAvgPool2d(1) if p == "avg" else StdPool() for p in pool_types])
+        self.conv = nn.Conv2d(1, 1, kernel_size=(1, k_size), stride=1, padding=(0, (k_size - 1) // 2), bias=False)
+        self.sigmoid = nn.Sigmoid()
+        self.weight = nn.Parameter(torch.rand(2))
+
+
+class MCALayer(nn.Module):
+    def __init__(self, inp, no_spatial=False):
+        super().__init__()
+        if no_spatial:
+            raise NotImplementedError("egm_unet_amd: MCALayer(no_spatial=True) is not used by EGM-UNet")
+        self.no_spatial = no_spatial
+        self.inp = inp
+        temp = round(abs((math.log2(inp) - 1) / 1.5))
+        kernel = temp if temp % 2 else temp - 1
+        self.h_cw = MCAGate(3)
+        self.w_hc = MCAGate(3)
+        self.c_hw = MCAGate(kernel)
+
+    def forward(self, x):
+        return ops.mca_layer(x, self, self.training and torch.is_grad_enabled())
+
+
+# --------------------------------------------------------------------------------------------------------------
+# EdgeAwareFeatureEnhancer (src/EGM-UNet.py:872-886)
+# --------------------------------------------------------------------------------------------------------------
+class EdgeAwareFeatureEnhancer(nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        self.edge_extractor = nn.AvgPool2d(kernel_size=3, stride=1, padding=1)
+        self.weight_generator = nn.Sequential(nn.Conv2d(in_channels, in_channels, kernel_size=1), nn.BatchNorm2d(in_channels),
+                                              nn.Sigmoid())
+
+    def forward(self, x):
+        xa, xb = ops.fork(x, 2)
+        e = ops.highpass3(xa)                                                   # x - avgpool3(x)
+        w = ops.conv_bn_act(e, self.weight_generator[0], self.weight_generator[1], ACT_SIGMOID)
+        return ops.gate_mul(xb, w)                                              # w*x + x
+
+
+class BasicConv(nn.Module):
+    """conv -> BN(eps 1e-5, momentum 0.01) -> optional ReLU (src/EGM-UNet.py:958-975)"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, relu=True, bn=True,
+                 bias=False):
+        super().__init__()
+        if stride != 1 or not bn:
+            raise NotImplementedError("egm_unet_amd: BasicConv is used with stride 1 and BN only")
+        self.out_channels = out_channels
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding, dilation=dilation,
+                              groups=groups, bias=bias)
+        self.bn = nn.BatchNorm2d(out_channels, eps=1e-5, momentum=0.01, affine=True)
+        self.relu = nn.ReLU(inplace=True) if relu else None
+        self._dil, self._groups = dilation, groups
+
+    def forward(self, x):
+        return ops.conv_bn_act(x, self.conv, self.bn, ACT_RELU if self.relu is not None else ACT_NONE, dil=self._dil,
+                               groups=self._groups)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# FusionConv with its attention modules (src/EGM-UNet.py:1171-1236)
+# --------------------------------------------------------------------------------------------------------------
+class ChannelAttentionModule(nn.Module):
+    def __init__(self, in_channels, reduction=4):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.max_pool = nn.AdaptiveMaxPool2d(1)
+        self.fc = nn.Sequential(nn.Conv2d(in_channels, in_channels // reduction, 1, bias=False), nn.ReLU(inplace=True),
+                                nn.Conv2d(in_channels // reduction, in_channels, 1, bias=False))
+        self.sigmoid = nn.Sigmoid()
+
+    def logits(self, f):
+        """-> [2N,1,1,C]: fc(avg_pool) stacked over fc(max_pool); the sigmoid of their sum is applied in fusion_combine."""
+        pooled = ops.global_avgmax(f)
+        h = ops.act(ops.conv2d(pooled, self.fc[0].weight), ACT_RELU)
+        return ops.conv2d(h, self.fc[2].weight)
+
+
+class SpatialAttentionModule(nn.Module):
+    def __init__(self, kernel_size=7):
+        super().__init__()
+        self.conv1 = nn.Conv2d(2, 1, kernel_size, padding=kernel_size // 2, bias=False)
+        self.sigmoid = nn.Sigmoid()
+
+    def logits(self, s, c_real):
+        """-> [N,H,W,8] whose channel 0 is conv7x7([mean_c s, max_c s]) (pre-sigmoid)."""
+        return ops.conv2d(ops.chan_meanmax(s, c_real), self.conv1.weight)
+
+
+class FusionConv(nn.Module):
+    def __init__(self, in_channels, out_channels, factor=4.0):
+        super().__init__()
+        dim = int(out_channels // factor)
+        self.down = nn.Conv2d(2 * in_channels, dim, kernel_size=1, stride=1)
+        self.conv_3x3 = nn.Conv2d(dim, dim, kernel_size=3, stride=1, padding=1)
+        self.conv_5x5 = nn.Conv2d(dim, dim, kernel_size=5, stride=1, padding=2)
+        self.conv_7x7 = nn.Conv2d(dim, dim, kernel_size=7, stride=1, padding=3)
+        self.spatial_attention = SpatialAttentionModule()
+        self.channel_attention = ChannelAttentionModule(dim)
+        self.up = nn.Conv2d(dim, out_channels, kernel_size=1, stride=1)
+        self._dim = dim
+
+    def forward(self, x1, x2=None):
+        """x2 is None (or x1 itself) == the reference call fusion_conv(concat, concat): cat([x, x]) is never built, the two
+        halves of `down.weight` are summed instead; conv3+conv5+conv7 run as one 7x7 conv with the summed kernels."""
+        if x2 is not None and x2 is not x1:
+            x1 = ops.cat_channels([x1, x2])
+            wdown = self.down.weight
+        else:
+            wdown = ops.fold2(self.down.weight)
+        f = ops.conv2d(x1, wdown, self.down.bias)
+        f_res, f_ms, f_ca = ops.fork(f, 3)
+        w7, b7 = ops.merge357(self.conv_3x3.weight, self.conv_5x5.weight, self.conv_7x7.weight, self.conv_3x3.bias,
+                              self.conv_5x5.bias, self.conv_7x7.bias)
+        s = ops.conv2d(f_ms, w7, b7)
+        s_a, s_b = ops.fork(s, 2)
+        sa = self.spatial_attention.logits(s_a, self._dim)
+        ca = self.channel_attention.logits(f_ca)
+        return ops.conv2d(ops.fusion_combine(f_res, s_b, sa, ca), self.up.weight, self.up.bias)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# EdgeEnhancedGRFB (src/EGM-UNet.py:1238-1323)
+# --------------------------------------------------------------------------------------------------------------
+class EdgeEnhancedGRFB(nn.Module):
+    def __init__(self, in_channels, out_channels, stride=1, scale=0.1, visual=12, fusion_factor=4.0):
+        super().__init__()
+        self.scale = scale
+        self.out_channels = out_channels
+        self.inter_planes = i = max(in_channels // 8, 4)
+        self.edge_enhancer = EdgeAwareFeatureEnhancer(in_channels)
+        self.branch_dir = nn.Sequential(
+            BasicConv(in_channels, 2 * i, 1),
+            BasicConv(2 * i, 2 * i, 3, padding=visual, dilation=visual, relu=False),
+            BasicConv(2 * i, 2 * i, 1))
+        self.branch_edge = nn.Sequential(
+            BasicConv(in_channels, i, 1),
+            EdgeAwareFeatureEnhancer(i),
+            BasicConv(i, 2 * i, (3, 3), stride, padding=1, groups=i),
+            BasicConv(2 * i, 2 * i, 3, padding=2 * visual, dilation=2 * visual, relu=False),
+            BasicConv(2 * i, 2 * i, 1))
+        self.branch_ctx = nn.Sequential(
+            BasicConv(in_channels, i, 3, padding=1),
+            BasicConv(i, 2 * i, 3, stride=stride, padding=1, groups=2),
+            BasicConv(2 * i, 2 * i, 3, padding=3 * visual, dilation=3 * visual, relu=False),
+            BasicConv(2 * i, 2 * i, 1))
+        self.concat_channels = in_channels + 6 * i
+        self.fusion_conv = FusionConv(self.concat_channels, out_channels, factor=fusion_factor)
+        self.shortcut = BasicConv(in_channels, out_channels, 1, stride, relu=False)
+        self.relu = nn.ReLU(inplace=False)
+        self.target_enhancer = nn.Sequential(nn.Conv2d(out_channels, 3, 3, padding=1), nn.Sigmoid())
+
+    def forward(self, x):
+        x_e, x_cat, x_sc = ops.fork(x, 3)
+        xe = self.edge_enhancer(x_e)
+        xe_d, xe_e, xe_c = ops.fork(xe, 3)
+        d = self.branch_dir(xe_d)
+        e = self.branch_edge(xe_e)
+        c = self.branch_ctx(xe_c)
+        cat = ops.cat_channels([x_cat, d, e, c])
+        out = self.fusion_conv(cat)
+        out = ops.scale_add_relu(out, self.scale, self.shortcut(x_sc))          # relu(out*scale + short)
+        o_a, o_b = ops.fork(out, 2)
+        t = ops.conv2d(o_a, self.target_enhancer[0].weight, self.target_enhancer[0].bias)
+        return ops.gate3(o_b, t)                                                # out*(1 + mean_c sigmoid(t))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# RecursiveGatedAttention (src/EGM-UNet.py:458-547)
+# --------------------------------------------------------------------------------------------------------------
+class RecursiveGatedAttention(nn.Module):
+    def __init__(self, dim, order=2, reduction=8, kernel_size=3):
+        super().__init__()
+        if order != 2 or kernel_size != 3:
+            raise NotImplementedError("egm_unet_amd: RecursiveGatedAttention is built for order=2, kernel 3 (as EGM-UNet uses it)")
+        self.order, self.dim = order, dim
+        self.split_sizes = [dim // (2 ** i) for i in range(1, order)]
+        self.split_sizes.append(dim // (2 ** (order - 1)))
+        self.split_sizes.reverse()
+        total = sum(self.split_sizes)
+        if total > dim:
+            self.split_sizes[-1] = dim - sum(self.split_sizes[:-1])
+        if any(s % 8 for s in self.split_sizes):
+            raise NotImplementedError("egm_unet_amd: RGA split sizes must be multiples of 8")
+        self.proj_in = nn.Conv2d(dim, self.split_sizes[0] + sum(self.split_sizes), 1)
+        self.gate_convs = nn.ModuleList()
+        for i in range(order):
+            in_ch = self.split_sizes[i]
+            self.gate_convs.append(nn.Sequential(nn.Conv2d(in_ch, max(in_ch // reduction, 8), 1), nn.GELU(),
+                                                 nn.Conv2d(max(in_ch // reduction, 8), 1, 1), nn.Sigmoid()))
+        self.transform_convs = nn.ModuleList()
+        for i in range(order - 1):
+            self.transform_convs.append(nn.Conv2d(self.split_sizes[i], self.split_sizes[i + 1], 1))
+        self.dwconv = nn.Conv2d(sum(self.split_sizes), sum(self.split_sizes), kernel_size, padding=kernel_size // 2,
+                                groups=sum(self.split_sizes))
+        self.proj_out = nn.Conv2d(self.split_sizes[-1], dim, 1)
+        self.scale = nn.Parameter(torch.tensor(1.0))
+        print(f"[RGA] order={order}, split_sizes={self.split_sizes}")
+
+    def _gate(self, i, g):
+        seq = self.gate_convs[i]
+        h = ops.gelu(ops.conv2d(g, seq[0].weight, seq[0].bias))
+        return ops.conv2d(h, seq[2].weight, seq[2].bias)                        # pre-sigmoid, 8-channel map (1 real)
+
+    def forward(self, x):
+        s0 = self.split_sizes[0]
+        fused = ops.conv2d(x, self.proj_in.weight, self.proj_in.bias)
+        base, gates = ops.split_channels(fused, s0)
+        gates = ops.dwconv3(gates, self.dwconv.weight, self.dwconv.bias, self.scale)
+        g0, g1 = ops.split_channels(gates, s0)
+        out = ops.bcast_gate(base, self._gate(0, g0))
+        out = ops.conv2d(out, self.transform_convs[0].weight, self.transform_convs[0].bias)
+        out = ops.bcast_gate(out, self._gate(1, g1))
+        return ops.conv2d(out, self.proj_out.weight, self.proj_out.bias)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Encoder stage and the network
+# --------------------------------------------------------------------------------------------------------------
+class DoubleConv1(nn.Sequential):
+    """conv-BN-ReLU -> MCALayer -> conv-BN-ReLU -> EdgeEnhancedGRFB (src/EGM-UNet.py:888-904)"""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None):
+        if mid_channels is None:
+            mid_channels = out_channels
+        super().__init__(
+            nn.Conv2d(in_channels, mid_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(mid_channels),
+            nn.ReLU(inplace=True),
+            MCALayer(mid_channels),
+            nn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True),
+            EdgeEnhancedGRFB(mid_channels, out_channels, stride=1, scale=0.1, visual=12),
+        )
+
+    def forward(self, x):
+        x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU)
+        x = self[3](x)
+        x = ops.conv_bn_act(x, self[4], self[5], ACT_RELU)
+        return self[7](x)
+
+
+class Down(nn.Sequential):
+    def __init__(self, in_channels, out_channels):
+        super().__init__(nn.MaxPool2d(2, stride=2), DoubleConv1(in_channels, out_channels))
+
+    def forward(self, x):
+        return self[1](ops.maxpool2(x))
+
+
+class GRFBUNet(_SegNetBase):
+    def __init__(self, in_channels: int = 1, num_classes: int = 2, bilinear: bool = True, base_c: int = 64,
+                 use_attention: bool = False):
+        super().__init__()
+        self.in_channels = in_channels
+        self.num_classes = num_classes
+        self.bilinear = bilinear
+        self.in_conv = DoubleConv(in_channels, base_c)
+        self.down1 = Down(base_c, base_c * 2)
+        self.down2 = Down(base_c * 2, base_c * 4)
+        self.down3 = Down(base_c * 4, base_c * 8)
+        factor = 2 if bilinear else 1
+        self.down4 = Down(base_c * 8, base_c * 16 // factor)
+        self.attn1 = RecursiveGatedAttention(base_c * 16 // factor)
+        self.up1 = Up(base_c * 16, base_c * 8 // factor, bilinear)
+        self.up2 = Up(base_c * 8, base_c * 4 // factor, bilinear)
+        self.up3 = Up(base_c * 4, base_c * 2 // factor, bilinear)
+        self.up4 = Up(base_c * 2, base_c, bilinear)
+        self.out_conv = OutConv(base_c, num_classes)
+
+    def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        x = self._enter(x)
+        x1, x1s = ops.fork(self.in_conv(x), 2)
+        x2, x2s = ops.fork(self.down1(x1), 2)
+        x3, x3s = ops.fork(self.down2(x2), 2)
+        x4, x4s = ops.fork(self.down3(x3), 2)
+        x5 = self.attn1(self.down4(x4))
+        y = self.up1(x5, x4s)
+        y = self.up2(y, x3s)
+        y = self.up3(y, x2s)
+        y = self.up4(y, x1s)
+        return self._exit(self.out_conv(y))

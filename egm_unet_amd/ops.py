@@ -337,3 +337,518 @@ class _Fork2(Function):
 
 def fork2(x):
     return _Fork2.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# fan-out / channel split / concat (gradient plumbing done by the HIP axpby kernel, never by autograd's add)
+# ----------------------------------------------------------------------------------------------------------
+def _axpby(a, alpha, b, beta, out=None):
+    a, lda = _nhwc(a)
+    ldb = 0
+    if b is not None:
+        b, ldb = _nhwc(b)
+    if out is None:
+        out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+    o, ldo = _nhwc(out)
+    assert o.data_ptr() == out.data_ptr(), "axpby: output view must be kernel-addressable"
+    lib().call("egm_axpby", dtype_code(a.dtype), ptr(a), lda, float(alpha), ptr(b), ldb, float(beta), ptr(o), ldo, _npix(a),
+               a.shape[3], stream())
+    return out
+
+
+class _Fork(Function):
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        acc = gs[0]
+        for g in gs[1:]:
+            acc = _axpby(acc, 1.0, g, 1.0)
+        return acc, None
+
+
+def fork(x, n):
+    return _Fork.apply(x, n)
+
+
+class _SplitC(Function):
+    """x[..., :c0], x[..., c0:] as views (c0 multiple of 8); backward re-assembles one dense gradient."""
+
+    @staticmethod
+    def forward(ctx, x, c0):
+        ctx.c0 = c0
+        return x[..., :c0], x[..., c0:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        c0 = ctx.c0
+        ref = ga if ga is not None else gb
+        N, H, W = ref.shape[:3]
+        Ca = c0
+        Cb = (gb.shape[3] if gb is not None else 0)
+        if ga is None or gb is None:
+            raise RuntimeError("split_channels: both halves must receive a gradient")
+        out = torch.empty((N, H, W, Ca + Cb), dtype=ref.dtype, device=ref.device)
+        _axpby(ga, 1.0, None, 0.0, out[..., :Ca])
+        _axpby(gb, 1.0, None, 0.0, out[..., Ca:])
+        return out, None
+
+
+def split_channels(x, c0):
+    return _SplitC.apply(x, c0)
+
+
+class _CatC(Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        N, H, W = xs[0].shape[:3]
+        cs = [x.shape[3] for x in xs]
+        out = torch.empty((N, H, W, sum(cs)), dtype=xs[0].dtype, device=xs[0].device)
+        off = 0
+        for x, c in zip(xs, cs):
+            _axpby(x, 1.0, None, 0.0, out[..., off:off + c])
+            off += c
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for c in ctx.cs:
+            outs.append(g[..., off:off + c])
+            off += c
+        return tuple(outs)
+
+
+def cat_channels(xs):
+    return _CatC.apply(*xs)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# elementwise pieces of the EGM blocks
+# ----------------------------------------------------------------------------------------------------------
+def _hp(x):
+    x, ldx = _nhwc(x)
+    N, H, W, C = x.shape
+    out = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+    lib().call("egm_highpass3", dtype_code(x.dtype), ptr(x), ldx, ptr(out), C, N, H, W, C, stream())
+    return out
+
+
+class _Highpass3(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _hp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _hp(g)           # x - avg3(x) with zero padding is self-adjoint
+
+
+def highpass3(x):
+    return _Highpass3.apply(x)
+
+
+class _GateMul(Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x, ldx = _nhwc(x)
+        w, ldw = _nhwc(w)
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        lib().call("egm_gate_mul_fwd", dtype_code(x.dtype), ptr(x), ldx, ptr(w), ldw, ptr(out), x.shape[3], _npix(x), x.shape[3], stream())
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        x, ldx = _nhwc(x); w, ldw = _nhwc(w); g, ldg = _nhwc(g)
+        C = x.shape[3]
+        dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        dw = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        lib().call("egm_gate_mul_bwd", dtype_code(x.dtype), ptr(g), ldg, ptr(x), ldx, ptr(w), ldw, ptr(dx), C, ptr(dw), C, _npix(x), C, stream())
+        return dx, dw
+
+
+def gate_mul(x, w):
+    return _GateMul.apply(x, w)
+
+
+class _ScaleAddRelu(Function):
+    @staticmethod
+    def forward(ctx, a, alpha, b):
+        a, lda = _nhwc(a); b, ldb = _nhwc(b)
+        C = a.shape[3]
+        out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+        lib().call("egm_scale_add_relu_fwd", dtype_code(a.dtype), ptr(a), lda, float(alpha), ptr(b), ldb, ptr(out), C, _npix(a), C, stream())
+        ctx.save_for_backward(out)
+        ctx.alpha = float(alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        out, ldo = _nhwc(out); g, ldg = _nhwc(g)
+        C = out.shape[3]
+        da = torch.empty(out.shape, dtype=out.dtype, device=out.device)
+        db = torch.empty(out.shape, dtype=out.dtype, device=out.device)
+        lib().call("egm_scale_add_relu_bwd", dtype_code(out.dtype), ptr(g), ldg, ptr(out), ldo, ctx.alpha, ptr(da), C, ptr(db), C, _npix(out), C,
+                   stream())
+        return da, None, db
+
+
+def scale_add_relu(a, alpha, b):
+    return _ScaleAddRelu.apply(a, alpha, b)
+
+
+class _Gate3(Function):
+    @staticmethod
+    def forward(ctx, x, t):
+        x, ldx = _nhwc(x); t, ldt = _nhwc(t)
+        C = x.shape[3]
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        lib().call("egm_gate3_fwd", dtype_code(x.dtype), ptr(x), ldx, ptr(t), ldt, ptr(out), C, _npix(x), C, stream())
+        ctx.save_for_backward(x, t)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t = ctx.saved_tensors
+        x, ldx = _nhwc(x); t, ldt = _nhwc(t); g, ldg = _nhwc(g)
+        C = x.shape[3]
+        dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        dt = torch.empty(t.shape[:3] + (8,), dtype=x.dtype, device=x.device)
+        lib().call("egm_gate3_bwd", dtype_code(x.dtype), ptr(g), ldg, ptr(x), ldx, ptr(t), ldt, ptr(dx), C, ptr(dt), 8, _npix(x), C, stream())
+        return dx, dt
+
+
+def gate3(x, t):
+    return _Gate3.apply(x, t)
+
+
+class _BcastGate(Function):
+    @staticmethod
+    def forward(ctx, a, gl):
+        a, lda = _nhwc(a); gl, ldg = _nhwc(gl)
+        C = a.shape[3]
+        out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+        lib().call("egm_bcast_gate_fwd", dtype_code(a.dtype), ptr(a), lda, ptr(gl), ldg, ptr(out), C, _npix(a), C, stream())
+        ctx.save_for_backward(a, gl)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, gl = ctx.saved_tensors
+        a, lda = _nhwc(a); gl, ldgl = _nhwc(gl); g, ldg = _nhwc(g)
+        C = a.shape[3]
+        da = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+        dgl = torch.empty(gl.shape[:3] + (8,), dtype=a.dtype, device=a.device)
+        lib().call("egm_bcast_gate_bwd", dtype_code(a.dtype), ptr(g), ldg, ptr(a), lda, ptr(gl), ldgl, ptr(da), C, ptr(dgl), 8, _npix(a), C,
+                   stream())
+        return da, dgl
+
+
+def bcast_gate(a, gl):
+    return _BcastGate.apply(a, gl)
+
+
+class _Gelu(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x, ldx = _nhwc(x)
+        C = x.shape[3]
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        lib().call("egm_gelu_fwd", dtype_code(x.dtype), ptr(x), ldx, ptr(out), C, _npix(x), C, stream())
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        x, ldx = _nhwc(x); g, ldg = _nhwc(g)
+        C = x.shape[3]
+        dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        lib().call("egm_gelu_bwd", dtype_code(x.dtype), ptr(g), ldg, ptr(x), ldx, ptr(dx), C, _npix(x), C, stream())
+        return dx
+
+
+def gelu(x):
+    return _Gelu.apply(x)
+
+
+class _Act(Function):
+    """Standalone activation (the ReLU inside ChannelAttentionModule.fc) through the BN-apply kernels with unit scale."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        x, ldx = _nhwc(x)
+        C = x.shape[3]
+        coef = torch.zeros((4, C), dtype=torch.float32, device=x.device)
+        lib().call("egm_fill_f32", ptr(coef[0]), 1.0, C, stream())
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        lib().call("egm_bn_act_fwd", dtype_code(x.dtype), ptr(x), ldx, ptr(coef[0]), ptr(coef[1]), act, ptr(out), C, _npix(x), C, stream())
+        ctx.save_for_backward(x, coef)
+        ctx.act = act
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, coef = ctx.saved_tensors
+        x, ldx = _nhwc(x); g, ldg = _nhwc(g)
+        C = x.shape[3]
+        dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        lib().call("egm_bn_act_bwd_apply", dtype_code(x.dtype), ptr(g), ldg, ptr(x), ldx, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]),
+                   ptr(coef[3]), ctx.act, 0, ptr(coef[2]), ptr(dx), C, _npix(x), C, stream())
+        return dx, None
+
+
+def act(x, code):
+    return _Act.apply(x, code)
+
+
+class _ChanMeanMax(Function):
+    @staticmethod
+    def forward(ctx, x, c_real):
+        x, ldx = _nhwc(x)
+        out = torch.empty(x.shape[:3] + (8,), dtype=x.dtype, device=x.device)
+        lib().call("egm_chan_meanmax_fwd", dtype_code(x.dtype), ptr(x), ldx, ptr(out), 8, _npix(x), x.shape[3], c_real, stream())
+        ctx.save_for_backward(x)
+        ctx.c_real = c_real
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        x, ldx = _nhwc(x); g, ldg = _nhwc(g)
+        dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        lib().call("egm_chan_meanmax_bwd", dtype_code(x.dtype), ptr(g), ldg, ptr(x), ldx, ptr(dx), x.shape[3], _npix(x), x.shape[3], ctx.c_real,
+                   stream())
+        return dx, None
+
+
+def chan_meanmax(x, c_real):
+    return _ChanMeanMax.apply(x, c_real)
+
+
+class _GlobalAvgMax(Function):
+    """-> [2N, 1, 1, C]: rows 0..N-1 adaptive_avg_pool2d(x, 1), rows N..2N-1 adaptive_max_pool2d(x, 1)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x, ldx = _nhwc(x)
+        N, H, W, C = x.shape
+        L = lib()
+        out = torch.empty((2 * N, 1, 1, C), dtype=x.dtype, device=x.device)
+        argidx = torch.empty((N, C), dtype=torch.int32, device=x.device)
+        ws = torch.empty(L.query("egm_global_pool_workspace", N, H * W, C) // 4 + 4, dtype=torch.float32, device=x.device)
+        L.call("egm_global_avgmax_fwd", dtype_code(x.dtype), ptr(x), ldx, ptr(out), ptr(argidx), ptr(ws), N, H * W, C, stream())
+        ctx.save_for_backward(argidx)
+        ctx.shape = (N, H, W, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (argidx,) = ctx.saved_tensors
+        N, H, W, C = ctx.shape
+        g = g.contiguous()
+        dx = torch.empty((N, H, W, C), dtype=g.dtype, device=g.device)
+        lib().call("egm_global_avgmax_bwd", dtype_code(g.dtype), ptr(g), ptr(argidx), ptr(dx), C, N, H * W, C, stream())
+        return dx
+
+
+def global_avgmax(x):
+    return _GlobalAvgMax.apply(x)
+
+
+class _FusionCombine(Function):
+    """f + s*sigmoid(sa[...,0])*sigmoid(ca_avg + ca_max); ca: [2N,1,1,C]."""
+
+    @staticmethod
+    def forward(ctx, f, s, sa, ca):
+        f, ldf = _nhwc(f); s, lds = _nhwc(s); sa, ldsa = _nhwc(sa)
+        ca = ca.contiguous()
+        N, H, W, C = f.shape
+        out = torch.empty(f.shape, dtype=f.dtype, device=f.device)
+        lib().call("egm_fusion_combine_fwd", dtype_code(f.dtype), ptr(f), ldf, ptr(s), lds, ptr(sa), ldsa, ptr(ca), ptr(out), C, N, H * W, C,
+                   stream())
+        ctx.save_for_backward(s, sa, ca)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        s, sa, ca = ctx.saved_tensors
+        s, lds = _nhwc(s); sa, ldsa = _nhwc(sa); g, ldg = _nhwc(g)
+        N, H, W, C = s.shape
+        L, dev = lib(), s.device
+        ds = torch.empty(s.shape, dtype=s.dtype, device=dev)
+        dsa = torch.empty((N, H, W, 8), dtype=s.dtype, device=dev)
+        nb = L.query("egm_fusion_combine_blocks", H * W, C)
+        part = _f32((N, nb, 2, C), dev)
+        L.call("egm_fusion_combine_bwd", dtype_code(s.dtype), ptr(g), ldg, ptr(s), lds, ptr(sa), ldsa, ptr(ca), ptr(ds), C, ptr(dsa), 8,
+               ptr(part), N, H * W, C, stream())
+        red = _f32((N, 2, C), dev)
+        L.call("egm_reduce_tiles_batched", ptr(part), N, nb, C, ptr(red), stream())
+        # d(ca_avg) = d(ca_max) = dca  ->  [2N,1,1,C] in the activation dtype
+        dca = torch.empty((2 * N, 1, 1, C), dtype=s.dtype, device=dev)
+        _f32_rows_to_act(red, dca, N, C)
+        return g, ds, dsa, dca
+
+
+def _f32_rows_to_act(red, dca, N, C):
+    """red fp32 [N][2][C] (row 0 = dca) -> dca[n] and dca[N+n] in the activation dtype (layout conversion kernel)."""
+    L, st = lib(), stream()
+    src = red[:, 0, :].contiguous()                       # [N, C] fp32 viewed as NCHW [N, C, 1, 1]
+    for half in (dca[:N], dca[N:]):
+        L.call("egm_nchw_to_nhwc", dtype_code(dca.dtype), ptr(src), ptr(half), C, N, C, 1, 1, st)
+
+
+def fusion_combine(f, s, sa, ca):
+    return _FusionCombine.apply(f, s, sa, ca)
+
+
+class _Fold2(Function):
+    @staticmethod
+    def forward(ctx, w):                                   # [rows, 2K, 1, 1] -> [rows, K, 1, 1]
+        rows, K2 = w.shape[0], w.shape[1]
+        out = torch.empty((rows, K2 // 2, 1, 1), dtype=torch.float32, device=w.device)
+        lib().call("egm_fold2_fwd", ptr(w.detach().contiguous()), ptr(out), rows, K2 // 2, stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, K = g.shape[0], g.shape[1]
+        dw = torch.empty((rows, 2 * K, 1, 1), dtype=torch.float32, device=g.device)
+        lib().call("egm_fold2_bwd", ptr(g.contiguous()), ptr(dw), rows, K, stream())
+        return dw
+
+
+def fold2(w):
+    return _Fold2.apply(w)
+
+
+class _Merge357(Function):
+    @staticmethod
+    def forward(ctx, w3, w5, w7, b3, b5, b7):
+        Co, Ci = w7.shape[0], w7.shape[1]
+        w = torch.empty((Co, Ci, 7, 7), dtype=torch.float32, device=w7.device)
+        b = torch.empty((Co,), dtype=torch.float32, device=w7.device)
+        lib().call("egm_merge357_fwd", ptr(w3.detach().contiguous()), ptr(w5.detach().contiguous()), ptr(w7.detach().contiguous()),
+                   ptr(b3.detach()), ptr(b5.detach()), ptr(b7.detach()), ptr(w), ptr(b), Co, Ci, stream())
+        ctx.shape = (Co, Ci)
+        return w, b
+
+    @staticmethod
+    def backward(ctx, gw, gb):
+        Co, Ci = ctx.shape
+        dev = gw.device
+        d3 = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=dev)
+        d5 = torch.empty((Co, Ci, 5, 5), dtype=torch.float32, device=dev)
+        d7 = torch.empty((Co, Ci, 7, 7), dtype=torch.float32, device=dev)
+        lib().call("egm_merge357_bwd", ptr(gw.contiguous()), ptr(d3), ptr(d5), ptr(d7), Co, Ci, stream())
+        return d3, d5, d7, gb, gb, gb
+
+
+def merge357(w3, w5, w7, b3, b5, b7):
+    return _Merge357.apply(w3, w5, w7, b3, b5, b7)
+
+
+class _DwConv3(Function):
+    """(depthwise3x3(x, w) + b) * scale   (RecursiveGatedAttention.dwconv and the learnable scale)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, scale):
+        x, ldx = _nhwc(x)
+        N, H, W, C = x.shape
+        y = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+        wd, bd, sd = w.detach().contiguous(), b.detach().contiguous(), scale.detach().reshape(1).contiguous()
+        lib().call("egm_dwconv3_fwd", dtype_code(x.dtype), ptr(x), ldx, ptr(wd), ptr(bd), ptr(sd), ptr(y), C, N, H, W, C, stream())
+        ctx.save_for_backward(x, wd, bd, sd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, b, sc = ctx.saved_tensors
+        x, ldx = _nhwc(x); g, ldg = _nhwc(g)
+        N, H, W, C = x.shape
+        L, dev = lib(), x.device
+        dx = torch.empty(x.shape, dtype=x.dtype, device=dev)
+        dw = torch.empty((C, 1, 3, 3), dtype=torch.float32, device=dev)
+        db = torch.empty((C,), dtype=torch.float32, device=dev)
+        ds = torch.empty((1,), dtype=torch.float32, device=dev)
+        ws = torch.empty(L.query("egm_dwconv3_bwd_workspace", N, H, W, C) // 4 + 4, dtype=torch.float32, device=dev)
+        L.call("egm_dwconv3_bwd", dtype_code(x.dtype), ptr(x), ldx, ptr(g), ldg, ptr(w), ptr(b), ptr(sc), ptr(dx), C, ptr(dw), ptr(db), ptr(ds),
+               ptr(ws), N, H, W, C, stream())
+        return dx, dw, db, ds.reshape(())
+
+
+def dwconv3(x, w, b, scale):
+    return _DwConv3.apply(x, w, b, scale)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# MCALayer
+# ----------------------------------------------------------------------------------------------------------
+class _MCALayer(Function):
+    @staticmethod
+    def forward(ctx, x, wh, kh, ww, kw, wc, kc, training):
+        x, ldx = _nhwc(x)
+        N, H, W, C = x.shape
+        L, dt, st, dev = lib(), dtype_code(x.dtype), stream(), x.device
+        Lax = H + W + C
+        ws = torch.empty(L.query("egm_mca_reduce_workspace", N, H, W, C) // 4 + 4, dtype=torch.float32, device=dev)
+        sums = _f32((N, Lax, 2), dev)
+        L.call("egm_mca_reduce", dt, 0, ptr(x), ldx, None, 0, ptr(sums), ptr(ws), N, H, W, C, st)
+        stats, o, gates = _f32((N, Lax, 2), dev), _f32((N, Lax), dev), _f32((N, Lax), dev)
+        ps = [t.detach().contiguous() for t in (wh, kh, ww, kw, wc, kc)]
+        ks = (kh.numel(), kw.numel(), kc.numel())
+        L.call("egm_mca_gates_fwd", ptr(sums), ptr(ps[0]), ptr(ps[1]), ks[0], ptr(ps[2]), ptr(ps[3]), ks[1], ptr(ps[4]), ptr(ps[5]), ks[2],
+               ptr(stats), ptr(o), ptr(gates), N, H, W, C, st)
+        xo = torch.empty((N, H, W, C), dtype=x.dtype, device=dev)
+        L.call("egm_mca_xout", dt, ptr(x), ldx, ptr(gates), ptr(xo), C, N, H, W, C, st)
+        r1 = torch.empty_like(xo)
+        u2 = torch.empty_like(xo)
+        codes = torch.empty((N, H, W, C), dtype=torch.uint8, device=dev) if training else None
+        L.call("egm_mca_stencil1", dt, ptr(xo), C, ptr(r1), C, ptr(u2), C, ptr(codes), N, H, W, C, st)
+        out = torch.empty_like(xo)
+        L.call("egm_add_avg3", dt, ptr(r1), C, ptr(u2), C, 0.2, ptr(out), C, N, H, W, C, st)
+        if training:
+            ctx.save_for_backward(x, xo, codes, stats, o, gates, *ps)
+            ctx.ks = ks
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xo, codes, stats, o, gates, wh, kh, ww, kw, wc, kc = ctx.saved_tensors
+        ks = ctx.ks
+        x, ldx = _nhwc(x); g, ldg = _nhwc(g)
+        N, H, W, C = x.shape
+        L, dt, st, dev = lib(), dtype_code(x.dtype), stream(), x.device
+        Lax = H + W + C
+        du = torch.empty_like(xo)
+        L.call("egm_mca_bwd_du", dt, ptr(xo), C, ptr(g), ldg, ptr(du), C, N, H, W, C, st)
+        dxo = torch.empty_like(xo)
+        L.call("egm_mca_bwd_dxo", dt, ptr(codes), ptr(g), ldg, ptr(du), C, ptr(dxo), C, N, H, W, C, st)
+        ws = torch.empty(L.query("egm_mca_reduce_workspace", N, H, W, C) // 4 + 4, dtype=torch.float32, device=dev)
+        dG = _f32((N, Lax, 2), dev)
+        L.call("egm_mca_reduce", dt, 1, ptr(dxo), C, ptr(x), ldx, ptr(dG), ptr(ws), N, H, W, C, st)
+        dz = _f32((N, Lax), dev)
+        coef = _f32((N, Lax, 2), dev)
+        dwts = _f32((3, 2), dev)
+        dks = _f32((3, 8), dev, zero=True)
+        L.call("egm_mca_gates_bwd", ptr(dG), ptr(stats), ptr(o), ptr(gates), ptr(wh), ptr(kh), ks[0], ptr(ww), ptr(kw), ks[1], ptr(wc), ptr(kc),
+               ks[2], ptr(dz), ptr(coef), ptr(dwts), ptr(dks), N, H, W, C, st)
+        dx = torch.empty((N, H, W, C), dtype=x.dtype, device=dev)
+        L.call("egm_mca_bwd_dx", dt, ptr(dxo), C, ptr(x), ldx, ptr(gates), ptr(coef), ptr(dx), C, N, H, W, C, st)
+        gk = [dks[a, :ks[a]].reshape(1, 1, 1, ks[a]).clone() for a in range(3)]
+        return dx, dwts[0].clone(), gk[0], dwts[1].clone(), gk[1], dwts[2].clone(), gk[2], None
+
+
+def mca_layer(x, layer, training):
+    """layer: an MCALayer parameter holder with gates h_cw, w_hc, c_hw (each: .weight [2], .conv.weight [1,1,1,k])."""
+    return _MCALayer.apply(x, layer.h_cw.weight, layer.h_cw.conv.weight, layer.w_hc.weight, layer.w_hc.conv.weight,
+                           layer.c_hw.weight, layer.c_hw.conv.weight, training)

@@ -86,6 +86,8 @@ int egm_dwconv3_bwd(int dtype, const void* x, int ldx, const void* dy, int lddy,
 int egm_channel_partials_blocks(long long npix, int C);
 int egm_channel_sums(int dtype, const void* x, int ld, long long npix, int C, float* partials, egm_stream_t s);
 int egm_reduce_tiles(const float* tiles, int ntiles, int C, float* out_2xC, egm_stream_t s);
+/* batch independent reductions: tiles [batch][ntiles][2][C] -> out [batch][2][C] */
+int egm_reduce_tiles_batched(const float* tiles, int batch, int ntiles, int C, float* out, egm_stream_t s);
 
 /* ---- BatchNorm2d (train-mode batch statistics / eval-mode running statistics) + activation -----
  * (nn.BatchNorm2d + ReLU/Sigmoid: src/EGM-UNet.py:50-51,878-879,966-973) */
@@ -133,6 +135,101 @@ int egm_axpby(int dtype, const void* a, int lda, float alpha, const void* b, int
 /* fp32 vector add: y[i] += x[i] (parameter-gradient accumulation) */
 int egm_vec_add_f32(float* y, const float* x, long long n, egm_stream_t s);
 int egm_fill_f32(float* y, float v, long long n, egm_stream_t s);
+
+/* ---- EdgeAwareFeatureEnhancer pieces (src/EGM-UNet.py:872-886) -------------------------------------------------- */
+/* out = x - avgpool3x3(x) (zero pad, divisor 9).  Self-adjoint: the same call is its own backward. */
+int egm_highpass3(int dtype, const void* x, int ldx, void* out, int ldo, int N, int H, int W, int C, egm_stream_t s);
+/* out = x*(1+w);  backward: dx = g*(1+w), dw = g*x */
+int egm_gate_mul_fwd(int dtype, const void* x, int ldx, const void* w, int ldw, void* out, int ldo, long long npix, int C,
+                     egm_stream_t s);
+int egm_gate_mul_bwd(int dtype, const void* g, int ldg, const void* x, int ldx, const void* w, int ldw, void* dx, int lddx,
+                     void* dw, int lddw, long long npix, int C, egm_stream_t s);
+
+/* ---- EdgeEnhancedGRFB tail (src/EGM-UNet.py:1315-1321) ----------------------------------------------------------- */
+/* out = relu(alpha*a + b);  backward (mask = out > 0): da = alpha*g*mask, db = g*mask */
+int egm_scale_add_relu_fwd(int dtype, const void* a, int lda, float alpha, const void* b, int ldb, void* out, int ldo,
+                           long long npix, int C, egm_stream_t s);
+int egm_scale_add_relu_bwd(int dtype, const void* g, int ldg, const void* out, int ldo, float alpha, void* da, int ldda,
+                           void* db, int lddb, long long npix, int C, egm_stream_t s);
+/* out = x*(1 + mean_k sigmoid(t[..,k])), k<3 (t: 8-channel map, 3 real);  backward writes dx and dt (8 channels) */
+int egm_gate3_fwd(int dtype, const void* x, int ldx, const void* t, int ldt, void* out, int ldo, long long npix, int C,
+                  egm_stream_t s);
+int egm_gate3_bwd(int dtype, const void* g, int ldg, const void* x, int ldx, const void* t, int ldt, void* dx, int lddx,
+                  void* dt, int lddt, long long npix, int C, egm_stream_t s);
+
+/* ---- RecursiveGatedAttention pieces (src/EGM-UNet.py:531-544) ---------------------------------------------------- */
+/* out = a * sigmoid(gl[..,0]) (gl: 8-channel map, 1 real);  backward writes da and dgl (8 channels) */
+int egm_bcast_gate_fwd(int dtype, const void* a, int lda, const void* gl, int ldgl, void* out, int ldo, long long npix, int C,
+                       egm_stream_t s);
+int egm_bcast_gate_bwd(int dtype, const void* g, int ldg, const void* a, int lda, const void* gl, int ldgl, void* da, int ldda,
+                       void* dgl, int lddgl, long long npix, int C, egm_stream_t s);
+/* nn.GELU (erf form) */
+int egm_gelu_fwd(int dtype, const void* x, int ldx, void* out, int ldo, long long npix, int C, egm_stream_t s);
+int egm_gelu_bwd(int dtype, const void* g, int ldg, const void* x, int ldx, void* dx, int lddx, long long npix, int C,
+                 egm_stream_t s);
+
+/* ---- FusionConv pieces (src/EGM-UNet.py:1171-1236) ---------------------------------------------------------------- */
+/* SpatialAttentionModule input: out[..,0] = mean_c x, out[..,1] = max_c x over the C_real real channels (8-channel map) */
+int egm_chan_meanmax_fwd(int dtype, const void* x, int ldx, void* out, int ldo, long long npix, int C, int C_real,
+                         egm_stream_t s);
+int egm_chan_meanmax_bwd(int dtype, const void* g, int ldg, const void* x, int ldx, void* dx, int lddx, long long npix, int C,
+                         int C_real, egm_stream_t s);
+/* ChannelAttentionModule pools: out [2N][C] (rows 0..N-1 = global average, N..2N-1 = global max), argidx int32 [N][C] =
+ * first position of the maximum; workspace egm_global_pool_workspace() bytes. */
+long long egm_global_pool_workspace(int N, long long HW, int C);
+int egm_global_avgmax_fwd(int dtype, const void* x, int ldx, void* out, int* argidx, void* workspace, int N, long long HW,
+                          int C, egm_stream_t s);
+int egm_global_avgmax_bwd(int dtype, const void* gout, const int* argidx, void* dx, int lddx, int N, long long HW, int C,
+                          egm_stream_t s);
+/* out = f + s*sigmoid(sa[..,0])*sigmoid(ca[n][c] + ca[N+n][c])   (x_out = up(res + x_fused_s * x_fused_c), :1232-1235).
+ * backward: ds, dsa (8-channel map) and per-image partial tiles [N][nblk][2][C] of dca (row 0; reduce with
+ * egm_reduce_tiles per image); nblk = egm_fusion_combine_blocks(HW, C).  df is g itself. */
+int egm_fusion_combine_fwd(int dtype, const void* f, int ldf, const void* sv, int lds, const void* sa, int ldsa, const void* ca,
+                           void* out, int ldo, int N, long long HW, int C, egm_stream_t s);
+int egm_fusion_combine_blocks(long long HW, int C);
+int egm_fusion_combine_bwd(int dtype, const void* g, int ldg, const void* sv, int lds, const void* sa, int ldsa, const void* ca,
+                           void* ds, int ldds, void* dsa, int lddsa, float* partials, int N, long long HW, int C, egm_stream_t s);
+/* Algebraic folds of FusionConv parameters (fp32, tiny): down(cat[x,x]) == conv with W[:, :K] + W[:, K:];
+ * conv3(f)+conv5(f)+conv7(f) == one 7x7 conv with the zero-padded kernels (and biases) summed. */
+int egm_fold2_fwd(const float* w, float* out, int rows, int K, egm_stream_t s);
+int egm_fold2_bwd(const float* g, float* dw, int rows, int K, egm_stream_t s);
+int egm_merge357_fwd(const float* w3, const float* w5, const float* w7, const float* b3, const float* b5, const float* b7,
+                     float* w, float* b, int Co, int Ci, egm_stream_t s);
+int egm_merge357_bwd(const float* gw, float* d3, float* d5, float* d7, int Co, int Ci, egm_stream_t s);
+
+/* ---- MCALayer (src/EGM-UNet.py:686-791, MCAGate :836-869, StdPool :827-834) ---------------------------------------- */
+/* Three-axis sums in one pass: sums fp32 [N][H+W+C][2] laid out per image as [H rows | W columns | C channels];
+ * mode 0: (sum a, sum a^2); mode 1: (sum a*b, -).  workspace egm_mca_reduce_workspace() bytes. C: power of two <= 512. */
+long long egm_mca_reduce_workspace(int N, int H, int W, int C);
+int egm_mca_reduce(int dtype, int mode, const void* a, int lda, const void* b, int ldb, float* sums, void* workspace, int N,
+                   int H, int W, int C, egm_stream_t s);
+/* sums -> stats [N][L][2] (mean, unbiased std), o [N][L] (pre-conv gate input), gates [N][L] (sigmoid outputs); L=H+W+C.
+ * w_*: MCAGate.weight (2 floats); k_*: the 1 x ks conv kernel of each gate (h_cw, w_hc, c_hw). */
+int egm_mca_gates_fwd(const float* sums, const float* w_h, const float* k_h, int ks_h, const float* w_w, const float* k_w,
+                      int ks_w, const float* w_c, const float* k_c, int ks_c, float* stats, float* o, float* gates, int N, int H,
+                      int W, int C, egm_stream_t s);
+/* dG [N][L][2] (slot 0 = sum over each slice of dx_out*x) -> coef [N][L][2] (A, B with dx += A + B*x along each axis),
+ * dwts [3][2] (gradients of the three MCAGate.weight), dks [3][8] (gradients of the conv kernels). */
+int egm_mca_gates_bwd(const float* dG, const float* stats, const float* o, const float* gates, const float* w_h, const float* k_h,
+                      int ks_h, const float* w_w, const float* k_w, int ks_w, const float* w_c, const float* k_c, int ks_c,
+                      float* dz_scratch, float* coef, float* dwts, float* dks, int N, int H, int W, int C, egm_stream_t s);
+/* x_out = x*(g_h+g_w+g_c)/3 */
+int egm_mca_xout(int dtype, const void* x, int ldx, const float* gates, void* xo, int ldo, int N, int H, int W, int C,
+                 egm_stream_t s);
+/* r1 = 0.51*xo + 0.2*(max3-min3)(xo) + 0.1*shuffle4(xo); u2 = (xo - avg3 xo)^2; codes (optional, N*H*W*C bytes) = window
+ * positions of the first max / first min, for the backward.  Then out = r1 + 0.2*avg3(u2) via egm_add_avg3. */
+int egm_mca_stencil1(int dtype, const void* xo, int ld, void* r1, int ldr, void* u2, int ldu, unsigned char* codes, int N, int H,
+                     int W, int C, egm_stream_t s);
+int egm_add_avg3(int dtype, const void* a, int lda, const void* b, int ldb, float scale, void* out, int ldo, int N, int H, int W,
+                 int C, egm_stream_t s);
+/* backward chain: du = 0.4*(xo - avg3 xo)*avg3(g); dxo = 0.51 g + 0.1 unshuffle(g) + du - avg3(du) + 0.2*range_bwd(codes, g);
+ * dx = dxo*(g_h+g_w+g_c)/3 + sum_axes(A + B*x) */
+int egm_mca_bwd_du(int dtype, const void* xo, int ld, const void* g, int ldg, void* du, int ldd, int N, int H, int W, int C,
+                   egm_stream_t s);
+int egm_mca_bwd_dxo(int dtype, const unsigned char* codes, const void* g, int ldg, const void* du, int ldd, void* dxo, int ldo,
+                    int N, int H, int W, int C, egm_stream_t s);
+int egm_mca_bwd_dx(int dtype, const void* dxo, int ldd, const void* x, int ldx, const float* gates, const float* coef, void* dx,
+                   int ldo, int N, int H, int W, int C, egm_stream_t s);
 
 /* ---- criterion, metrics, optimizer --------------------------------------------------------------
  * criterion(): train_utils/train_and_eval.py:7-19 + dice_coefficient_loss.py:7-108 (five terms; reference quirks kept:
