@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark: EGM-UNet training throughput (BASELINE.json: "train images/sec at 3x512x512 bs=8/GPU").
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+One step = forward + 5-term criterion + backward + fused SGD of GRFBUNet(3, 2, base_c=32) on a device-resident synthetic
+batch of 8 x 3 x 512 x 512 per GPU, bf16 activation storage / MFMA, fp32 accumulation and master weights.
+Prints ONE JSON line (rank 0) with the extra `roofline` (dominant kernel, timed with HIP events on the launch stream in an
+instrumented step outside the timed region) and `cpu_baseline` (CPU oracle on a bounded sample) objects.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def synth_batch(n, h, w, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 3, h, w, generator=g)
+    t = torch.zeros(n, h, w, dtype=torch.int64)
+    for i in range(n):                                   # one random quadrilateral-ish blob of foreground (~15 %)
+        cy, cx = torch.randint(h // 4, 3 * h // 4, (2,), generator=g).tolist()
+        hh, ww = torch.randint(h // 6, h // 3, (2,), generator=g).tolist()
+        t[i, max(0, cy - hh // 2):cy + hh // 2, max(0, cx - ww // 2):cx + ww // 2] = 1
+    t[torch.rand(n, h, w, generator=g) < 0.01] = 255     # 1 % ignore pixels
+    return x.to(device), t.to(device)
+
+
+class KernelTimer:
+    """Times every C-ABI call with HIP events recorded on the stream the kernels are launched on (torch's current
+    stream, which is the stream handed to the library)."""
+
+    def __init__(self, lib):
+        self.lib, self.records, self._orig = lib, [], lib.call
+
+    def __enter__(self):
+        def timed(name, *args):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._orig(name, *args)
+            e1.record()
+            self.records.append((name, args, e0, e1))
+        self.lib.call = timed
+        return self
+
+    def __exit__(self, *a):
+        self.lib.call = self._orig
+        torch.cuda.synchronize()
+
+    def summary(self):
+        agg = {}
+        for name, args, e0, e1 in self.records:
+            key = name
+            flops = 0.0
+            if name == "egm_conv_fwd":
+                # (dtype, x, ldx, wf, bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, KH, KW, dil, stream)
+                N, H, W, Cin, Cout, KH, KW = args[9:16]
+                flops = 2.0 * N * H * W * Cin * Cout * KH * KW
+                key = f"egm_conv_fwd[{KH}x{KW}]"
+            elif name == "egm_conv_wgrad":
+                N, H, W, Cin, Cout = args[7:12]
+                KH, KW = args[14:16]
+                flops = 2.0 * N * H * W * Cin * Cout * KH * KW
+                key = f"egm_conv_wgrad[{KH}x{KW}]"
+            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += flops
+        return agg
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The CPU oracle (oracle/*.py, PyTorch fp32, the reference's algorithm) on a bounded sample of the same workload:
+    train steps (fwd + criterion + bwd + SGD) of EGM-UNet(3,2,32) at bs 2 x 3 x 512 x 512."""
+    from oracle import egm_ref as R, loss_ref as L
+    threads = torch.get_num_threads()
+    st = R.make_egm_unet_state(3, 2, 32, seed=0)
+    params = {k: v.clone() for k, v in st.items() if v.is_floating_point() and "running_" not in k}
+    bufs, lw = {}, torch.tensor([1.0, 2.0])
+    x, t = synth_batch(2, 512, 512, 0, "cpu")
+    times = []
+    t_start = time.time()
+    for step in range(3):
+        t0 = time.time()
+        work = dict(st)
+        for k in params:
+            work[k] = params[k].detach().clone().requires_grad_(True)
+        loss = L.criterion(R.egm_unet_forward(work, x, True), t, lw, num_classes=2, ignore_index=255)
+        loss.backward()
+        with torch.no_grad():
+            L.sgd_step(params, {k: work[k].grad for k in params}, bufs, lr=0.02)
+        times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget:
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": round(2.0 / best, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} train steps (fwd+loss+bwd+SGD) of EGM-UNet(3,2,32) at bs 2x3x512x512 fp32 on the CPU oracle; best of steps after the first"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from egm_unet_amd import GRFBUNet
+    from egm_unet_amd._lib import lib, require_gpu
+    from egm_unet_amd.optim import SGD
+    from egm_unet_amd.parallel import GradAllReducer
+    from egm_unet_amd.train_utils import criterion
+    require_gpu()
+
+    torch.manual_seed(0)                                   # identical initial weights on every rank
+    model = GRFBUNet(3, 2, base_c=32).to(dev).train()
+    model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    opt = SGD(model.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+    reducer = GradAllReducer(model, world_size=world) if world > 1 else None
+    if reducer is not None:
+        opt.grad_scale = 1.0 / world
+    x, t = synth_batch(args.batch, args.size, args.size, 1000 + rank, dev)
+    lw = torch.tensor([1.0, 2.0], device=dev)
+
+    def step():
+        out = model(x)
+        loss = criterion(out, t, lw, num_classes=2, ignore_index=255)
+        opt.zero_grad()
+        loss.backward()
+        if reducer is not None:
+            opt.grad_source = reducer.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final_loss = float(loss.detach())
+
+    roofline = None
+    cpu = None
+    if rank == 0:
+        with KernelTimer(lib()) as kt:
+            step()
+        agg = kt.summary()
+        total_ms = sum(v[1] for v in agg.values())
+        dom_key, dom = max(((k, v) for k, v in agg.items() if v[2] > 0), key=lambda kv: kv[1][1])
+        achieved = dom[2] / (dom[1] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3,
+                    "unit": "TFLOP/s", "frac": round(achieved / (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3), 4),
+                    "traffic": None, "kernel": dom_key, "launches_per_step": dom[0],
+                    "avg_launch_ms": round(dom[1] / dom[0], 4), "algorithmic_gflop_per_launch": round(dom[2] / dom[0] / 1e9, 3),
+                    "share_of_step_kernel_time": round(dom[1] / total_ms, 3)}
+        top = sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]
+        print("[bench] kernel time by C-ABI entry (instrumented step, ms): " +
+              ", ".join(f"{k}={v[1]:.2f}({v[0]})" for k, v in top) + f"; total {total_ms:.2f}", file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        line = {
+            "metric": "train images/sec at 3x512x512 bs=8/GPU", "value": round(imgs / elapsed, 3), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"EGM-UNet GRFBUNet(3,2,base_c=32) fwd+5-term-loss+bwd+SGD, {args.batch}x3x{args.size}x{args.size} per GPU "
+                                   "(BASELINE.json configs[1])",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

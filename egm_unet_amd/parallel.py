@@ -1,0 +1,108 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL all-reduce over xGMI via torch.distributed ("nccl").
+
+The reference never wires DDP (train.py is single-device; only the metric reducers of
+train_utils/distributed_utils.py:107-167 use collectives), so this is new functionality built for MI355X:
+
+ * the 333 parameter gradients (6.30 M fp32 = 25.2 MB for EGM-UNet base_c=32) are packed into TWO flat buckets in
+   backward order - bucket 0 = out_conv, up4..up1, attn1 (ready first), bucket 1 = down4..down1, in_conv;
+ * as soon as the last gradient of a bucket has been accumulated (post-accumulate-grad hooks) the bucket is gathered by
+   one multi-tensor HIP copy and all-reduced (SUM) on a SIDE stream, so bucket 0's exchange overlaps the encoder
+   backward; 25 MB over 7 x ~153 GB/s xGMI links is latency-bound (~0.1-0.3 ms), hence few large messages;
+ * the optimizer reads the reduced gradients straight from the buckets (no scatter back) with grad_scale = 1/world.
+BatchNorm statistics stay per-rank (bs 8/GPU reproduces the reference's bs 8 regime; the reference has no SyncBN).
+"""
+import torch
+import torch.distributed as dist
+
+from ._lib import lib, ptr
+
+BUCKET0_PREFIXES = ("out_conv", "up4", "up3", "up2", "up1", "attn1")
+
+
+def _hip_gather(entries, device, stream_handle):
+    """entries: [(dst_view, src_grad)] -> one multi-tensor copy on the given stream."""
+    rows = [(d.data_ptr(), s.data_ptr(), s.numel()) for d, s in entries]
+    table = torch.tensor(rows, dtype=torch.int64).to(device)
+    lib().call("egm_copy_multi", ptr(table), len(rows), stream_handle)
+    return table       # keep alive until the stream has consumed it
+
+
+class GradAllReducer:
+    def __init__(self, model, world_size=None, gather_fn=None, use_side_stream=None):
+        self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        self.buckets = [[], []]
+        for n, p in named:
+            self.buckets[0 if n.startswith(BUCKET0_PREFIXES) else 1].append(p)
+        if not self.buckets[0] or not self.buckets[1]:          # models without that naming: one bucket
+            self.buckets = [[p for _, p in named]]
+        dev = named[0][1].device
+        self.device = dev
+        self.flat, self.views, self.bucket_of = [], {}, {}
+        for b, ps in enumerate(self.buckets):
+            flat = torch.zeros(sum(p.numel() for p in ps), dtype=torch.float32, device=dev)
+            off = 0
+            for p in ps:
+                self.views[p] = flat[off:off + p.numel()].view_as(p)
+                self.bucket_of[p] = b
+                off += p.numel()
+            self.flat.append(flat)
+        self.gather_fn = gather_fn
+        cuda = dev.type == "cuda"
+        self.side = torch.cuda.Stream(device=dev) if (cuda and (use_side_stream is None or use_side_stream)) else None
+        self._pending = [len(ps) for ps in self.buckets]
+        self._works, self._keep = [], []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for _, p in named]
+
+    # ---- called by autograd as each parameter's gradient lands
+    def _on_grad(self, p):
+        b = self.bucket_of[p]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        entries = [(self.views[p], p.grad) for p in self.buckets[b]]
+        if self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                self._gather(entries)
+                if self.world > 1:
+                    self._works.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self._gather(entries)
+            if self.world > 1:
+                self._works.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
+
+    def _gather(self, entries):
+        if self.gather_fn is not None:
+            self.gather_fn(entries)
+        else:
+            import ctypes
+            h = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            self._keep.append(_hip_gather(entries, self.device, h))
+
+    def finish(self):
+        """After loss.backward(): make the reduced buckets visible to the current stream; returns {param: reduced grad}."""
+        for b, n in enumerate(self._pending):
+            if n != 0 and n != len(self.buckets[b]):
+                raise RuntimeError("GradAllReducer: some parameters of a bucket received no gradient")
+            if n == len(self.buckets[b]):
+                raise RuntimeError("GradAllReducer: backward() did not reach bucket %d" % b)
+        if self.side is not None:
+            with torch.cuda.stream(self.side):
+                for w in self._works:
+                    w.wait()
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+        else:
+            for w in self._works:
+                w.wait()
+        self._works, self._keep = [], []
+        self._pending = [len(ps) for ps in self.buckets]
+        return self.views
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
