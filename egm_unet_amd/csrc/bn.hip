@@ -139,11 +139,27 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
     }
 }
 
+// Streaming kernels below: when C/8 divides 256 a thread keeps the same 8 channels for its whole grid-stride loop, so the
+// per-channel coefficients are loaded once into registers and the loop body is pure 16-byte loads/stores.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int act, T* __restrict__ z, int ldz,
                                                          long long npix, int C) {
     const int ncv = C >> 3;
+    if (256 % ncv == 0) {
+        const int cv = threadIdx.x % ncv, ppb = 256 / ncv;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = scale[cv * 8 + j]; sh[j] = shift[cv * 8 + j]; }
+        for (long long p = (long long)blockIdx.x * ppb + threadIdx.x / ncv; p < npix; p += (long long)gridDim.x * ppb) {
+            float v[8];
+            load8(y + p * ldy + cv * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j] * sc[j] + sh[j], act);
+            store8(z + p * ldz + cv * 8, v);
+        }
+        return;
+    }
     const long long total = npix * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long p = i / ncv; const int cv = (int)(i - p * ncv);
@@ -156,6 +172,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
 }
 
 // dy = scale * (dzp - mean(dzp) - xhat * mean(dzp*xhat))   (train)   |   dy = scale * dzp   (eval)
+//    = ca*dzp + cb + cc*y   with per-channel ca = scale, cb = -scale*(m0 - mean*rstd*m1), cc = -scale*rstd*m1   (train)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
@@ -163,6 +180,29 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
                                                                int train, const float* __restrict__ sums, float inv_count,
                                                                T* __restrict__ dy, int lddy, long long npix, int C) {
     const int ncv = C >> 3;
+    if (256 % ncv == 0) {
+        const int cv = threadIdx.x % ncv, ppb = 256 / ncv;
+        float sc[8], sh[8], cb[8], cc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cv * 8 + j;
+            sc[j] = scale[c]; sh[j] = shift[c];
+            if (train) {
+                const float m0 = sums[c] * inv_count, m1 = sums[C + c] * inv_count;
+                cc[j] = -sc[j] * rstd[c] * m1;
+                cb[j] = -sc[j] * m0 - cc[j] * mean[c];
+            } else { cb[j] = 0.f; cc[j] = 0.f; }
+        }
+        for (long long p = (long long)blockIdx.x * ppb + threadIdx.x / ncv; p < npix; p += (long long)gridDim.x * ppb) {
+            float g[8], yv[8];
+            load8(dz + p * lddz + cv * 8, g);
+            load8(y + p * ldy + cv * 8, yv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = sc[j] * g[j] * act_grad(yv[j] * sc[j] + sh[j], act) + cb[j] + cc[j] * yv[j];
+            store8(dy + p * lddy + cv * 8, g);
+        }
+        return;
+    }
     const long long total = npix * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long p = i / ncv; const int cv = (int)(i - p * ncv);

@@ -18,7 +18,7 @@
 //     the whole pixel loop, so dy fragments are read once per k-step and reused by every tap.
 //   * LDS images are [32-channel block][pixel][32 channels] (64-byte bf16 rows) -> every tr-read/row read touches
 //     4 consecutive rows = all 64 banks once: conflict-free, no padding.
-//   * partial blocks go to a slab [split*C][tap][CoutP][CinP] with plain stores; a second kernel sums the slabs in
+//   * the C waves sharing a dW block are summed through LDS; partial blocks go to a slab [split][tap][CoutP][CinP] with plain stores; a second kernel sums the slabs in
 //     fixed order (bitwise reproducible) and scatters into the fp32 OIHW gradient.
 #include "common.h"
 
@@ -157,12 +157,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         }
     }
 
-    // ---- write the partial block: slab[(split*C + wc)][tap][co][ci]; D layout: col(ci) = lane&31, row(co) = f(reg, lane>>5)
+    // ---- reduce the C pixel-row waves of each (wa, wb) pair through LDS (fixed order), then one slab per workgroup
+    for (int r = 1; r < p.C; ++r) {
+        __syncthreads();
+        float* buf = reinterpret_cast<float*>(smem) + (wb * p.A + wa) * (NTAPS * 16 * 64);
+        if (wc == r) {
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) buf[(t * 16 + i) * 64 + lane] = acc[t][i];
+        }
+        __syncthreads();
+        if (wc == 0) {
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] += buf[(t * 16 + i) * 64 + lane];
+        }
+    }
+    // ---- write the partial block: slab[split][tap][co][ci]; D layout: col(ci) = lane&31, row(co) = f(reg, lane>>5)
     const int h = lane >> 5, r31 = lane & 31;
     const int ci = ci_base + wb * 32 + r31;
     const long long taps = (long long)p.KH * p.KW;
-    float* slab = p.slab + ((long long)(split * p.C + wc) * taps) * p.Cout * p.Cin;
-    if (ci < p.Cin) {
+    float* slab = p.slab + ((long long)split * taps) * p.Cout * p.Cin;
+    if (wc == 0 && ci < p.Cin) {
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t) {
 #pragma unroll
@@ -174,18 +192,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     }
 }
 
-// sum slabs in fixed order and scatter to fp32 OIHW (real, possibly grouped, shape)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslab, int taps, int CoutP,
-                                    int CinP, int CoutR, int CinR, int groups, int accumulate) {
+// sum slabs in fixed order and scatter to fp32 OIHW (real, possibly grouped, shape).
+// block = 64 consecutive packed elements (tap, co, ci) x 4 slab lanes: every slab row read is a 256-byte segment.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslab, int taps,
+                                                           int CoutP, int CinP, int CoutR, int CinR, int groups, int accumulate) {
+    __shared__ float red[256];
     const long long total = (long long)taps * CoutP * CinP;
     const int cin_g = CinR / groups, cout_g = CoutR / groups;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;
+    float s = 0.f;
+    if (i < total)
+        for (int k = sl; k < nslab; k += 4) s += slab[(long long)k * total + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+        s = (red[e] + red[64 + e]) + (red[128 + e] + red[192 + e]);
         const int ci = (int)(i % CinP), co = (int)((i / CinP) % CoutP), tap = (int)(i / ((long long)CinP * CoutP));
-        if (co >= CoutR || ci >= CinR || (co / cout_g) != (ci / cin_g)) continue;
-        float s = 0.f;
-        for (int k = 0; k < nslab; ++k) s += slab[(long long)k * total + i];
-        const long long o = ((long long)co * cin_g + (ci % cin_g)) * taps + tap;
-        dw[o] = accumulate ? dw[o] + s : s;
+        if (co < CoutR && ci < CinR && (co / cout_g) == (ci / cin_g)) {
+            const long long o = ((long long)co * cin_g + (ci % cin_g)) * taps + tap;
+            dw[o] = accumulate ? dw[o] + s : s;
+        }
     }
 }
 
@@ -206,14 +233,16 @@ int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW
     pl->nco_tiles = egm_cdiv(Cout, 32 * A); pl->nci_tiles = egm_cdiv(Cin, 32 * B);
     pl->tiles_y = egm_cdiv(H, TH); pl->tiles_x = egm_cdiv(W, TW); pl->npt = N * pl->tiles_y * pl->tiles_x;
     const int blocks_per_split = pl->nco_tiles * pl->nci_tiles * pl->ngroups;
-    int nsplit = 512 / blocks_per_split;
+    int nsplit = 256 / blocks_per_split;          // ~one workgroup per CU
     if (nsplit < 1) nsplit = 1;
     if (nsplit > pl->npt) nsplit = pl->npt;
     pl->nsplit = nsplit;
     const int rb = dtype == EGM_BF16 ? 64 : 128;
     const int wh = pl->ntaps == 9 ? 3 : 1, ww = pl->ntaps == 9 ? 3 : pl->ntaps;
     pl->smem = (size_t)A * TH * TW * rb + (size_t)B * (TH + wh - 1) * (TW + ww - 1) * rb;
-    pl->slab_bytes = (long long)nsplit * pl->C * KH * KW * Cout * Cin * (long long)sizeof(float);
+    const size_t red_bytes = pl->C > 1 ? (size_t)A * B * pl->ntaps * 16 * 64 * sizeof(float) : 0;   // cross-wave reduction buffer
+    if (pl->smem < red_bytes) pl->smem = red_bytes;
+    pl->slab_bytes = (long long)nsplit * KH * KW * Cout * Cin * (long long)sizeof(float);
     return EGM_OK;
 }
 
@@ -286,8 +315,8 @@ extern "C" int egm_conv_wgrad(int dtype, const void* x, int ldx, const void* dy,
     else EGM_FAIL(EGM_ERR_ARG, "conv_wgrad: unknown dtype %d", dtype);
     if (rc != EGM_OK) return rc;
     const long long total = (long long)KH * KW * Cout * Cin;
-    const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)workspace, dw, pl.nsplit * pl.C,
+    const int grid = (int)((total + 63) / 64);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)workspace, dw, pl.nsplit,
                        KH * KW, Cout, Cin, CoutR, CinR, groups, accumulate);
     EGM_CHECK_LAUNCH("wgrad_reduce");
     return EGM_OK;
