@@ -85,12 +85,19 @@ def lib() -> _Lib:
     return _lib
 
 
+_gpu_ok = False
+
+
 def require_gpu():
-    """Fail loudly unless a gfx950 device is usable through the HIP library."""
+    """Fail loudly unless a gfx950 device is usable through the HIP library (checked once per process)."""
+    global _gpu_ok
+    if _gpu_ok:
+        return
     if not torch.cuda.is_available():
         raise RuntimeError("egm_unet_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False")
     if not lib().cdll.egm_device_ok():
         raise RuntimeError("egm_unet_amd: " + lib().cdll.egm_last_error().decode())
+    _gpu_ok = True
 
 
 def stream():

@@ -14,11 +14,31 @@ class SGD(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self.grad_scale = 1.0          # e.g. 1/world_size when gradients arrive as an all-reduced SUM
         self.grad_source = None        # optional {param: fp32 tensor view} overriding p.grad (DDP buckets)
+        self._tables = {}              # (group index, first) -> (key, pinned host table, device table)
+
+    def _device_table(self, slot, rows, dev):
+        """Pointer table on the device.  Re-uploaded only when a pointer changed; the upload is an async copy from a
+        pinned staging buffer, so it is legal inside hipGraph capture (and replays re-copy the same bytes)."""
+        key = tuple(rows)
+        hit = self._tables.get(slot)
+        if hit is not None and hit[0] == key:
+            return hit[2]
+        n = len(rows)
+        if hit is None or hit[1].shape[0] < n:
+            cap = max(n, 512)
+            pinned = torch.empty((cap, 4), dtype=torch.int64).pin_memory()
+            device = torch.empty((cap, 4), dtype=torch.int64, device=dev)
+        else:
+            pinned, device = hit[1], hit[2]
+        pinned[:n] = torch.tensor(rows, dtype=torch.int64)
+        device[:n].copy_(pinned[:n], non_blocking=True)
+        self._tables[slot] = (key, pinned, device)
+        return device
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             rows = {True: [], False: []}          # first-step parameters take v = g (no stale buffer read)
             keep = []
             for p in group["params"]:
@@ -40,8 +60,7 @@ class SGD(torch.optim.Optimizer):
             for first in (True, False):
                 if not rows[first]:
                     continue
-                dev = group["params"][0].device
-                table = torch.tensor(rows[first], dtype=torch.int64).to(dev)
+                table = self._device_table((gi, first), rows[first], group["params"][0].device)
                 lib().call("egm_sgd_multi", ptr(table), len(rows[first]), None, float(group["lr"]), float(group["momentum"]),
                            float(group["weight_decay"]), float(self.grad_scale), 1 if first else 0, stream())
         ops.bump_weight_generation()

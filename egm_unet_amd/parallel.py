@@ -19,12 +19,20 @@ from ._lib import lib, ptr
 BUCKET0_PREFIXES = ("out_conv", "up4", "up3", "up2", "up1", "attn1")
 
 
+_gather_tables = {}
+
+
 def _hip_gather(entries, device, stream_handle):
     """entries: [(dst_view, src_grad)] -> one multi-tensor copy on the given stream."""
-    rows = [(d.data_ptr(), s.data_ptr(), s.numel()) for d, s in entries]
-    table = torch.tensor(rows, dtype=torch.int64).to(device)
-    lib().call("egm_copy_multi", ptr(table), len(rows), stream_handle)
-    return table       # keep alive until the stream has consumed it
+    rows = tuple((d.data_ptr(), s.data_ptr(), s.numel()) for d, s in entries)
+    hit = _gather_tables.get(rows[0][0])
+    if hit is None or hit[0] != rows:            # pointers changed: re-upload through a pinned staging buffer (async)
+        pinned = torch.tensor(rows, dtype=torch.int64).pin_memory()
+        table = torch.empty(pinned.shape, dtype=torch.int64, device=device)
+        table.copy_(pinned, non_blocking=True)
+        _gather_tables[rows[0][0]] = hit = (rows, pinned, table)
+    lib().call("egm_copy_multi", ptr(hit[2]), len(rows), stream_handle)
+    return hit[2]
 
 
 class GradAllReducer:
@@ -83,6 +91,13 @@ class GradAllReducer:
             import ctypes
             h = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             self._keep.append(_hip_gather(entries, self.device, h))
+
+    def reduce_now(self):
+        """Gradients already complete (e.g. after a captured fwd+bwd graph replay): exchange every bucket now."""
+        for b in range(len(self.buckets)):
+            self._pending[b] = 0
+            self._launch(b)
+        return self.finish()
 
     def finish(self):
         """After loss.backward(): make the reduced buckets visible to the current stream; returns {param: reduced grad}."""
