@@ -219,6 +219,237 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// Pipelined bf16 kernel (the throughput path).  Same tiling as above, plus:
+//   * persistent: grid = G pixel-groups x nct cout tiles; a workgroup keeps its cout tile and walks pixel tiles
+//     g, g+G, ...; its flat stage list is (pixel tile, tap group, Cin chunk);
+//   * register prefetch (issue-early / write-late): the global loads of stage s+1 (patch, and weights when they change)
+//     are issued before the MFMAs of stage s and written to LDS after them, so HBM/L2 latency hides under compute;
+//     weights that never change (one chunk, one tap group: every Cin<=32 layer) are staged once per workgroup;
+//   * operands swapped (A = weights: rows = couts, B = patch: cols = pixels) so a lane ends up with 4 consecutive couts
+//     of one pixel per register group -> 8-byte LDS writes into a wave-private tile, read back as whole 16-byte channel
+//     vectors and stored with fully coalesced 16-byte stores (+bias);
+//   * BatchNorm partial statistics accumulate in registers over ALL pixel tiles of the workgroup: one partial per
+//     pixel-group instead of one per tile.
+template <int WIN> struct PipeGeom {
+    static constexpr int PH = TH + WIN - 1, PW = TW + WIN - 1, NTAPS = WIN * WIN;
+    static constexpr int PVEC = (PH * PW * 4 + 255) / 256;                 // patch 16-byte vectors per thread
+};
+
+template <int NT, int WIN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvParams p, int G) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using Gm = PipeGeom<WIN>;
+    using M = Mma<bf16_t>;
+    constexpr int PS = 80;                                                   // LDS row: 32 ch bf16 + 16 B pad
+    constexpr int PH = Gm::PH, PW = Gm::PW, NTAPS = Gm::NTAPS, PVEC = Gm::PVEC;
+    constexpr int WROWS = NTAPS * NT * 32;
+    constexpr int WVEC = (WROWS * 4 + 255) / 256;
+    constexpr int OROW = NT * 64 + 16;                                        // out-tile row bytes (NT*32 bf16 + pad)
+    constexpr int NV = NT * 4;                                                // 16-byte vectors per output pixel
+
+    const int b = blockIdx.x, q = b >> 3;
+    const int ct = q % p.nct;
+    const int grp = (q / p.nct) * 8 + (b & 7);                                // pixel group; b % 8 == grp % 8 (same XCD)
+    if (grp >= G) return;
+    const int co0 = ct * NT * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r31 = lane & 31, h = lane >> 5;
+    const bf16_t* __restrict__ xg = reinterpret_cast<const bf16_t*>(p.x);
+    const bf16_t* __restrict__ wg = reinterpret_cast<const bf16_t*>(p.w);
+    bf16_t* __restrict__ yg = reinterpret_cast<bf16_t*>(p.y);
+    unsigned char* patch = smem;
+    unsigned char* wts = smem + p.patch_bytes;
+
+    const int tpi = p.tiles_y * p.tiles_x;
+    const int ngroups = (p.dil == 1) ? 1 : p.KH * p.KW;                     // WIN == 1 for dilated convs
+    const int nchunks = (p.Cin + KC - 1) / KC;
+    const bool w_static = (ngroups == 1 && nchunks == 1);
+
+    // ---- per-thread staging slots (fixed for the whole kernel)
+    int pv_off[PVEC], pv_py[PVEC], pv_px[PVEC];
+#pragma unroll
+    for (int k = 0; k < PVEC; ++k) {
+        const int i = tid + k * 256;
+        const int pix = i >> 2;
+        pv_off[k] = (i < PH * PW * 4) ? pix * PS + (i & 3) * 16 : -1;
+        pv_py[k] = pix / PW; pv_px[k] = pix - (pix / PW) * PW;
+    }
+    uint4 pre_p[PVEC], pre_w[WVEC];
+
+    // ---- stage iterator: (pixel tile, tap group, chunk) with wholly-out-of-image dilated groups skipped
+    struct Stage { int pt, g, c0, n, oy0, ox0, offy, offx, tap0; bool valid; };
+    auto locate = [&](Stage& st) {
+        // normalise (pt, g, c0): advance until a contributing group is found or the tile list ends
+        while (true) {
+            if (st.pt >= p.npt) { st.valid = false; return; }
+            st.n = st.pt / tpi; const int trem = st.pt - st.n * tpi;
+            st.oy0 = (trem / p.tiles_x) * TH; st.ox0 = (trem % p.tiles_x) * TW;
+            if (p.dil == 1) { st.offy = -(p.KH / 2); st.offx = -(p.KW / 2); st.tap0 = 0; st.valid = true; return; }
+            st.offy = (st.g / p.KW - p.KH / 2) * p.dil; st.offx = (st.g % p.KW - p.KW / 2) * p.dil; st.tap0 = st.g;
+            const bool out = st.oy0 + st.offy >= p.H || st.oy0 + st.offy + TH <= 0 || st.ox0 + st.offx >= p.W || st.ox0 + st.offx + TW <= 0;
+            // the centre tap (offset 0) always contributes, so every tile keeps at least one group
+            if (!out) { st.valid = true; return; }
+            st.c0 = 0; st.g += 1;
+            if (st.g >= ngroups) { st.g = 0; st.pt += G; }
+        }
+    };
+    auto advance = [&](Stage st) {
+        st.c0 += KC;
+        if (st.c0 >= p.Cin) { st.c0 = 0; st.g += 1; if (st.g >= ngroups) { st.g = 0; st.pt += G; } }
+        locate(st);
+        return st;
+    };
+    auto issue_loads = [&](const Stage& st, bool with_weights) {
+#pragma unroll
+        for (int k = 0; k < PVEC; ++k) {
+            const int iy = st.oy0 + st.offy + pv_py[k], ix = st.ox0 + st.offx + pv_px[k];
+            const int c = st.c0 + ((tid + k * 256) & 3) * 8;
+            const bool ok = pv_off[k] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.Cin;
+            pre_p[k] = make_uint4(0, 0, 0, 0);
+            if (ok) pre_p[k] = *reinterpret_cast<const uint4*>(xg + ((long long)(st.n * p.H + iy) * p.W + ix) * p.ldx + c);
+        }
+        if (with_weights) {
+#pragma unroll
+            for (int k = 0; k < WVEC; ++k) {
+                const int i = tid + k * 256, row = i >> 2, t = row / (NT * 32), j = row - t * (NT * 32);
+                const int co = co0 + j, c = st.c0 + (i & 3) * 8;
+                const bool ok = i < WROWS * 4 && co < p.Cout && c < p.Cin;
+                pre_w[k] = make_uint4(0, 0, 0, 0);
+                if (ok) pre_w[k] = *reinterpret_cast<const uint4*>(wg + ((long long)(st.tap0 + t) * p.Cout + co) * p.Cin + c);
+            }
+        }
+    };
+    auto write_lds = [&](bool with_weights) {
+#pragma unroll
+        for (int k = 0; k < PVEC; ++k) if (pv_off[k] >= 0) *reinterpret_cast<uint4*>(patch + pv_off[k]) = pre_p[k];
+        if (with_weights) {
+#pragma unroll
+            for (int k = 0; k < WVEC; ++k) {
+                const int i = tid + k * 256;
+                if (i < WROWS * 4) *reinterpret_cast<uint4*>(wts + (i >> 2) * PS + (i & 3) * 16) = pre_w[k];
+            }
+        }
+    };
+
+    f32x16_t acc[2][NT];
+    float ssum[8], ssq[8];
+    zero8(ssum); zero8(ssq);
+    float bias8[8];
+    {
+        const int cv = lane % NV;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int co = co0 + cv * 8 + j; bias8[j] = (p.bias != nullptr && co < p.bias_n) ? p.bias[co] : 0.f; }
+    }
+
+    Stage cur; cur.pt = grp; cur.g = 0; cur.c0 = 0;
+    locate(cur);
+    if (!cur.valid) return;
+    issue_loads(cur, true);
+    bool first_of_item = true;
+    bool need_w = true;
+
+    while (true) {
+        if (first_of_item) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.f;
+        }
+        __syncthreads();                                      // LDS free: previous compute / epilogue finished everywhere
+        write_lds(need_w);
+        __syncthreads();
+        const Stage nxt = advance(cur);
+        const bool nxt_w = nxt.valid && !w_static;
+        if (nxt.valid) issue_loads(nxt, nxt_w);              // in flight during the MFMAs below
+        // ---- MFMA: A = weights (rows = couts), B = patch (cols = pixels)
+        {
+            const int kc = min(KC, p.Cin - cur.c0);
+            const int nks = (kc + 15) >> 4;
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                const int wr = t / WIN, ws = t - wr * WIN;
+                const unsigned char* b0 = patch + ((2 * wv + 0 + wr) * PW + r31 + ws) * PS;
+                const unsigned char* b1 = patch + ((2 * wv + 1 + wr) * PW + r31 + ws) * PS;
+                const unsigned char* a0 = wts + (t * NT * 32 + r31) * PS;
+                for (int ks = 0; ks < nks; ++ks) {
+                    const M::Frag fb0 = M::load(b0, ks, h), fb1 = M::load(b1, ks, h);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const M::Frag fa = M::load(a0 + nt * 32 * PS, ks, h);
+                        acc[0][nt] = M::mma(fa, fb0, acc[0][nt]);
+                        acc[1][nt] = M::mma(fa, fb1, acc[1][nt]);
+                    }
+                }
+            }
+        }
+        const bool last_of_item = !nxt.valid || nxt.pt != cur.pt;
+        if (last_of_item) {
+            __syncthreads();                                  // everyone done reading patch/weights: reuse LDS as out tiles
+            unsigned char* ot = smem + wv * 64 * OROW;        // wave-private 64 px x NT*32 couts
+            // D layout: col (pixel) = lane&31, row (cout) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        uint2 pk;
+                        pk.x = (uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 0]) | ((uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 1]) << 16);
+                        pk.y = (uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 2]) | ((uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 3]) << 16);
+                        *reinterpret_cast<uint2*>(ot + (m * 32 + r31) * OROW + (nt * 32 + gq * 8 + h * 4) * 2) = pk;
+                    }
+            // read back whole channel vectors (same wave: LDS ops of one wave complete in order) and store coalesced
+            const int cv = lane % NV, slot = lane / NV;
+#pragma unroll
+            for (int it = 0; it < NV; ++it) {                 // 64 pixels / (64/NV lanes-slots) = NV iterations
+                const int pl = it * (64 / NV) + slot;         // pixel within the wave's 2x32 rows
+                const int oy = cur.oy0 + 2 * wv + (pl >> 5), ox = cur.ox0 + (pl & 31);
+                const int co = co0 + cv * 8;
+                float v[8];
+                load8(reinterpret_cast<const bf16_t*>(ot + pl * OROW + cv * 16), v);
+                if (oy < p.H && ox < p.W && co < p.Cout) {
+                    if (p.bias != nullptr) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<bf16_t>(v[j] + bias8[j]));
+                    }
+                    store8(yg + ((long long)(cur.n * p.H + oy) * p.W + ox) * p.ldy + co, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
+                }
+            }
+        }
+        if (!nxt.valid) break;
+        first_of_item = last_of_item;
+        need_w = nxt_w;
+        cur = nxt;
+    }
+
+    if (p.stats != nullptr) {
+        // lanes with equal cv (cv, cv+NV, ...) hold partial sums of the same 8 channels
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            for (int o = NV; o < 64; o <<= 1) { ssum[j] += __shfl_xor(ssum[j], o, 64); ssq[j] += __shfl_xor(ssq[j], o, 64); }
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);           // [4 waves][2][NT*32]
+        if (lane < NV) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { red[(wv * 2 + 0) * NT * 32 + lane * 8 + j] = ssum[j]; red[(wv * 2 + 1) * NT * 32 + lane * 8 + j] = ssq[j]; }
+        }
+        __syncthreads();
+        if (tid < 2 * NT * 32) {
+            const int which = tid / (NT * 32), j = tid - which * NT * 32;
+            const int co = co0 + j;
+            if (co < p.Cout) {
+                float v = 0.f;
+                for (int w4 = 0; w4 < 4; ++w4) v += red[(w4 * 2 + which) * NT * 32 + j];
+                p.stats[((long long)grp * 2 + which) * p.Cout + co] = v;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // weight packing: fp32 OIHW (grouped) -> dense T [taps][CoutP][CinP] (fwd) and [taps flipped][CinP][CoutP] (dgrad)
 template <typename T>
 __global__ void conv_pack_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Cout, int Cin,
@@ -257,9 +488,46 @@ int launch_conv(const ConvParams& p, size_t smem, hipStream_t st) {
     return EGM_OK;
 }
 
+
+// pixel groups of the pipelined kernel: ~2 resident workgroups per CU, multiple of 8 (XCD round-robin)
+int pipe_groups(int npt, int nct) {
+    int g = (512 / nct) / 8 * 8;
+    if (g < 8) g = 8;
+    if (g > npt) g = npt;
+    return g;
+}
+bool pipe_eligible(int dtype, int KH, int KW, int dil) {
+    return dtype == EGM_BF16 && KH == KW && ((KH == 3 && dil == 1) || KH == 1 || (KH == 3 && dil > 1));
+}
+
+template <int NT, int WIN>
+int launch_pipe(ConvParams& p, hipStream_t st) {
+    using Gm = PipeGeom<WIN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_pipe_kernel<NT, WIN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_igemm_pipe: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    p.patch_bytes = (Gm::PH * Gm::PW * 80 + 15) / 16 * 16;
+    size_t smem = (size_t)p.patch_bytes + (size_t)Gm::NTAPS * NT * 32 * 80;
+    const size_t otile = (size_t)4 * 64 * (NT * 64 + 16);
+    if (smem < otile) smem = otile;
+    const int G = pipe_groups(p.npt, p.nct);
+    const int grid = ((G + 7) / 8) * 8 * p.nct;
+    hipLaunchKernelGGL((conv_igemm_pipe_kernel<NT, WIN>), dim3(grid), dim3(256), smem, st, p, G);
+    EGM_CHECK_LAUNCH("conv_igemm_pipe");
+    return EGM_OK;
+}
 }  // namespace
 
-extern "C" int egm_conv_stats_tiles(int N, int H, int W) { return N * egm_cdiv(H, TH) * egm_cdiv(W, TW); }
+extern "C" int egm_conv_stats_tiles(int dtype, int N, int H, int W, int Cout, int KH, int KW, int dil) {
+    const int npt = N * egm_cdiv(H, TH) * egm_cdiv(W, TW);
+    if (KH == 1 && KW == 1) dil = 1;
+    if (pipe_eligible(dtype, KH, KW, dil)) return pipe_groups(npt, egm_cdiv(Cout, Cout > 32 ? 64 : 32));
+    return npt;
+}
 
 extern "C" int egm_conv_pack(int dtype, const void* w, void* wf, void* wd, int Cout, int Cin, int KH, int KW, int groups,
                              egm_stream_t s) {
@@ -293,6 +561,12 @@ extern "C" int egm_conv_fwd(int dtype, const void* x, int ldx, const void* wf, c
     p.tiles_y = egm_cdiv(H, TH); p.tiles_x = egm_cdiv(W, TW); p.npt = N * p.tiles_y * p.tiles_x;
     const int NT = (Cout > 32) ? 2 : 1;
     p.nct = egm_cdiv(Cout, NT * 32);
+    if (pipe_eligible(dtype, KH, KW, dil)) {
+        hipStream_t st = (hipStream_t)s;
+        const int win = (KH == 3 && dil == 1) ? 3 : 1;
+        if (win == 3) return NT == 2 ? launch_pipe<2, 3>(p, st) : launch_pipe<1, 3>(p, st);
+        return NT == 2 ? launch_pipe<2, 1>(p, st) : launch_pipe<1, 1>(p, st);
+    }
     const int ps = (dtype == EGM_BF16) ? Mma<bf16_t>::kPixStride : Mma<float>::kPixStride;
     const bool halo = (dil == 1);
     const int wh = halo ? KH : 1, ww = halo ? KW : 1;

@@ -57,11 +57,11 @@ int egm_conv_pack(int dtype, const void* w_oihw_f32, void* wf, void* wd, int Cou
                   egm_stream_t s);
 /* y = conv(x, wf) (+bias).  Cin/Cout are the PADDED counts of wf.  bias (fp32, bias_n <= Cout valid entries; the rest count as 0) may be NULL.
  * stats, when non-NULL, receives per-pixel-tile partial sums [ntiles][2][Cout] of y and y*y
- * (consumed by egm_bn_finalize); egm_conv_stats_tiles() gives ntiles.
+ * (consumed by egm_bn_finalize); egm_conv_stats_tiles() gives ntiles for the same dtype/shape/kernel.
  * The data gradient is the same call on dy with wd (Cin/Cout swapped). */
 int egm_conv_fwd(int dtype, const void* x, int ldx, const void* wf, const void* bias_f32, int bias_n, void* y, int ldy,
                  float* stats, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, egm_stream_t s);
-int egm_conv_stats_tiles(int N, int H, int W);
+int egm_conv_stats_tiles(int dtype, int N, int H, int W, int Cout, int KH, int KW, int dil);
 /* Weight gradient: dw_oihw_f32 [CoutR][CinR/groups][KH][KW] (+)= sum_pixels dy (x) x.
  * Cin/Cout are padded counts of the activation buffers, CinR/CoutR the real (unpadded) ones.
  * workspace: egm_conv_wgrad_workspace() bytes.  accumulate != 0 adds to dw. */
