@@ -78,7 +78,7 @@ template <> struct Window<5> { static constexpr int WH = 1, WW = 5; };
 template <> struct Window<1> { static constexpr int WH = 1, WW = 1; };
 
 template <typename T, int NTAPS>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using M = WMma<T>;
     constexpr int WH = Window<NTAPS>::WH, WW = Window<NTAPS>::WW;
@@ -115,31 +115,70 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
     const int tpi = p.tiles_y * p.tiles_x;
-    for (int pt = split; pt < p.npt; pt += p.nsplit) {
-        const int n = pt / tpi, trem = pt - n * tpi;
-        const int oy0 = (trem / p.tiles_x) * TH, ox0 = (trem % p.tiles_x) * TW;
-        if (p.dil > 1 &&   // shifted tile wholly outside the image: zero contribution (block-uniform)
-            (oy0 + offy >= p.H || oy0 + offy + TH <= 0 || ox0 + offx >= p.W || ox0 + offx + TW <= 0)) continue;
-        __syncthreads();
-        // ---- stage dy tile: [A blocks][256 px][32 ch]
-        for (int i = tid; i < p.A * TH * TW * VPR; i += 256) {
-            const int v = i % VPR, pix = (i / VPR) % (TH * TW), blk = i / (VPR * TH * TW);
-            const int oy = oy0 + pix / TW, ox = ox0 + pix % TW, c = co_base + blk * 32 + v * VEC;
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if (oy < p.H && ox < p.W && c < p.Cout)
-                val = *reinterpret_cast<const uint4*>(dyg + ((long long)(n * p.H + oy) * p.W + ox) * p.lddy + c);
-            *reinterpret_cast<uint4*>(dyl + (blk * TH * TW + pix) * RB + v * 16) = val;
+    // staging slots: thread handles 16-byte vectors i = tid + k*256 of the dy tile / x patch images
+    constexpr int DYVEC = (2 * TH * TW * VPR + 255) / 256;            // sized for A = 2
+    constexpr int XVEC = (2 * PH * PW * VPR + 255) / 256;             // sized for B = 2
+    constexpr bool PIPE = (sizeof(T) == 2);                           // bf16: register prefetch (issue early / write late)
+    uint4 pre_dy[PIPE ? DYVEC : 1], pre_x[PIPE ? XVEC : 1];
+    const int ndy = p.A * TH * TW * VPR, nx = p.B * PH * PW * VPR;
+
+    auto tile_ok = [&](int pt, int& n, int& oy0, int& ox0) {
+        n = pt / tpi; const int trem = pt - n * tpi;
+        oy0 = (trem / p.tiles_x) * TH; ox0 = (trem % p.tiles_x) * TW;
+        // dilated taps: shifted tile wholly outside the image contributes zero (block-uniform)
+        return !(p.dil > 1 && (oy0 + offy >= p.H || oy0 + offy + TH <= 0 || ox0 + offx >= p.W || ox0 + offx + TW <= 0));
+    };
+    auto load_dy = [&](int i, int n, int oy0, int ox0) {
+        const int v = i % VPR, pix = (i / VPR) % (TH * TW), blk = i / (VPR * TH * TW);
+        const int oy = oy0 + pix / TW, ox = ox0 + pix % TW, c = co_base + blk * 32 + v * VEC;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (i < ndy && oy < p.H && ox < p.W && c < p.Cout)
+            val = *reinterpret_cast<const uint4*>(dyg + ((long long)(n * p.H + oy) * p.W + ox) * p.lddy + c);
+        return val;
+    };
+    auto load_x = [&](int i, int n, int oy0, int ox0) {
+        const int v = i % VPR, pix = (i / VPR) % (PH * PW), blk = i / (VPR * PH * PW);
+        const int iy = oy0 + offy + pix / PW, ix = ox0 + offx + pix % PW, c = ci_base + blk * 32 + v * VEC;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (i < nx && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.Cin)
+            val = *reinterpret_cast<const uint4*>(xg + ((long long)(n * p.H + iy) * p.W + ix) * p.ldx + c);
+        return val;
+    };
+    auto dy_lds = [&](int i) { return dyl + ((i / (VPR * TH * TW)) * TH * TW + (i / VPR) % (TH * TW)) * RB + (i % VPR) * 16; };
+    auto x_lds = [&](int i) { return xl + ((i / (VPR * PH * PW)) * PH * PW + (i / VPR) % (PH * PW)) * RB + (i % VPR) * 16; };
+    auto next_tile = [&](int pt, int& n, int& oy0, int& ox0) {      // first contributing tile at or after pt (stride nsplit)
+        while (pt < p.npt && !tile_ok(pt, n, oy0, ox0)) pt += p.nsplit;
+        return pt;
+    };
+
+    int n = 0, oy0 = 0, ox0 = 0;
+    int pt = next_tile(split, n, oy0, ox0);
+    if (PIPE && pt < p.npt) {
+#pragma unroll
+        for (int k = 0; k < DYVEC; ++k) pre_dy[k] = load_dy(tid + k * 256, n, oy0, ox0);
+#pragma unroll
+        for (int k = 0; k < XVEC; ++k) pre_x[k] = load_x(tid + k * 256, n, oy0, ox0);
+    }
+    while (pt < p.npt) {
+        __syncthreads();                                              // previous tile's MFMAs done: LDS free
+        if (PIPE) {
+#pragma unroll
+            for (int k = 0; k < DYVEC; ++k) if (tid + k * 256 < ndy) *reinterpret_cast<uint4*>(dy_lds(tid + k * 256)) = pre_dy[k];
+#pragma unroll
+            for (int k = 0; k < XVEC; ++k) if (tid + k * 256 < nx) *reinterpret_cast<uint4*>(x_lds(tid + k * 256)) = pre_x[k];
+        } else {
+            for (int i = tid; i < ndy; i += 256) *reinterpret_cast<uint4*>(dy_lds(i)) = load_dy(i, n, oy0, ox0);
+            for (int i = tid; i < nx; i += 256) *reinterpret_cast<uint4*>(x_lds(i)) = load_x(i, n, oy0, ox0);
         }
-        // ---- stage x patch: [B blocks][PH*PW px][32 ch]
-        for (int i = tid; i < p.B * PH * PW * VPR; i += 256) {
-            const int v = i % VPR, pix = (i / VPR) % (PH * PW), blk = i / (VPR * PH * PW);
-            const int iy = oy0 + offy + pix / PW, ix = ox0 + offx + pix % PW, c = ci_base + blk * 32 + v * VEC;
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.Cin)
-                val = *reinterpret_cast<const uint4*>(xg + ((long long)(n * p.H + iy) * p.W + ix) * p.ldx + c);
-            *reinterpret_cast<uint4*>(xl + (blk * PH * PW + pix) * RB + v * 16) = val;
-        }
         __syncthreads();
+        int n2 = 0, oy2 = 0, ox2 = 0;
+        const int pt2 = next_tile(pt + p.nsplit, n2, oy2, ox2);
+        if (PIPE && pt2 < p.npt) {                                    // in flight during the MFMAs below
+#pragma unroll
+            for (int k = 0; k < DYVEC; ++k) pre_dy[k] = load_dy(tid + k * 256, n2, oy2, ox2);
+#pragma unroll
+            for (int k = 0; k < XVEC; ++k) pre_x[k] = load_x(tid + k * 256, n2, oy2, ox2);
+        }
         // ---- MFMA: rows wc, wc+C, ... of the tile; k runs along the row
         const unsigned char* ablk = dyl + wa * (TH * TW) * RB;
         const unsigned char* bblk = xl + wb * (PH * PW) * RB;
@@ -155,6 +194,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
                 }
             }
         }
+        pt = pt2; n = n2; oy0 = oy2; ox0 = ox2;
     }
 
     // ---- reduce the C pixel-row waves of each (wa, wb) pair through LDS (fixed order), then one slab per workgroup
