@@ -299,20 +299,22 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_param_kernel(const T* __restr
         }
     }
 }
-// out[blk][11][C] -> dw[C][9], db[C], dscale (sum over channels of k=10)
+// out[blk][11][C] -> dw[C][9], db[C], per-channel dscale terms tmp[C]; one thread per (k, c), fixed-order sum over blocks
 __global__ void dwconv3_bwd_finish_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ dw, float* __restrict__ db,
-                                          float* __restrict__ dscale) {
+                                          float* __restrict__ tmp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 11 * C) return;
+    const int k = i / C, c = i - k * C;
+    double v = 0.0;
+    for (int bk = 0; bk < nblk; ++bk) v += (double)part[((long long)bk * 11 + k) * C + c];
+    if (k < 9) dw[c * 9 + k] = (float)v;
+    else if (k == 9) { if (db) db[c] = (float)v; }
+    else tmp[c] = (float)v;
+}
+__global__ void dwconv3_bwd_scale_kernel(const float* __restrict__ tmp, int C, float* __restrict__ dscale) {
     __shared__ float red[16];
     float ds = 0.f;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        for (int k = 0; k < 11; ++k) {
-            double v = 0.0;
-            for (int bk = 0; bk < nblk; ++bk) v += (double)part[((long long)bk * 11 + k) * C + c];
-            if (k < 9) dw[c * 9 + k] = (float)v;
-            else if (k == 9) { if (db) db[c] = (float)v; }
-            else ds += (float)v;
-        }
-    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) ds += tmp[c];
     ds = block_sum(ds, red);
     if (threadIdx.x == 0 && dscale) dscale[0] = ds;
 }
@@ -434,12 +436,12 @@ extern "C" int egm_dwconv3_fwd(int dtype, const void* x, int ldx, const float* w
 static int dw_blocks(long long npix, int C) {
     const int rows = 256 / (C >> 3);
     long long b = (npix + rows - 1) / rows;
-    if (b > 256) b = 256;
+    if (b > 64) b = 64;
     return (int)(b < 1 ? 1 : b);
 }
 extern "C" long long egm_dwconv3_bwd_workspace(int N, int H, int W, int C) {
     if (C <= 0 || C % 8 || C > 2048) return -1;
-    return (long long)dw_blocks((long long)N * H * W, C) * 11 * C * (long long)sizeof(float);
+    return ((long long)dw_blocks((long long)N * H * W, C) * 11 * C + C) * (long long)sizeof(float);
 }
 extern "C" int egm_dwconv3_bwd(int dtype, const void* x, int ldx, const void* dy, int lddy, const float* w, const float* b,
                                const float* scale, void* dx, int lddx, float* dw, float* db, float* dscale, void* workspace, int N,
@@ -456,7 +458,10 @@ extern "C" int egm_dwconv3_bwd(int dtype, const void* x, int ldx, const void* dy
         hipLaunchKernelGGL((dwconv3_bwd_param_kernel<T>), dim3(nb), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)s, (const T*)x, ldx,
                            (const T*)dy, lddy, w, b, scale, (float*)workspace, N, H, W, C);
     });
-    hipLaunchKernelGGL(dwconv3_bwd_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, (const float*)workspace, nb, C, dw, db, dscale);
+    float* tmp = (float*)workspace + (long long)nb * 11 * C;
+    hipLaunchKernelGGL(dwconv3_bwd_finish_kernel, dim3((11 * C + 255) / 256), dim3(256), 0, (hipStream_t)s, (const float*)workspace, nb, C, dw,
+                       db, tmp);
+    hipLaunchKernelGGL(dwconv3_bwd_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, tmp, C, dscale);
     EGM_CHECK_LAUNCH("dwconv3_bwd");
     return EGM_OK;
 }

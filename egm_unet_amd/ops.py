@@ -175,7 +175,7 @@ class _Conv2d(Function):
             L.call("egm_conv_wgrad", dt, ptr(x), ldx, ptr(gy), ldg, ptr(gw), ptr(ws), N, H, W, CinP, CoutP, Cin, Cout, KH, KW,
                    dil, groups, 0, st)
         if has_bias and ctx.needs_input_grad[2]:
-            gb = _channel_sum(gy)[0, :Cout].clone()
+            gb = _channel_sum(gy)[0, :Cout]
         return gx, gw, gb, None, None, None
 
 
@@ -232,15 +232,15 @@ class _BnAct(Function):
             gy = torch.empty((N, H, W, CP), dtype=y.dtype, device=dev)
             L.call("egm_bn_act_bwd_apply", dt, ptr(gz), ldg, ptr(y), ldy, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), act,
                    1 if training else 0, ptr(sums), ptr(gy), CP, npix, CP, st)
-        ggamma = sums[1, :C].clone() if ctx.needs_input_grad[2] else None
-        gbeta = sums[0, :C].clone() if ctx.needs_input_grad[3] else None
+        ggamma = sums[1, :C] if ctx.needs_input_grad[2] else None
+        gbeta = sums[0, :C] if ctx.needs_input_grad[3] else None
         return gy, None, ggamma, gbeta, None, None, None, None, None, None
 
 
 def bn_act(y, bn, act, stats=None):
     """bn: an nn.BatchNorm2d used as the parameter/buffer holder."""
     training = bn.training or bn.running_mean is None
-    if bn.training and bn.num_batches_tracked is not None:
+    if bn.training and bn.num_batches_tracked is not None and not getattr(bn, "_egm_counter_managed", False):
         bn.num_batches_tracked.add_(1)                  # bookkeeping counter (int64), as nn.BatchNorm2d does
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _BnAct.apply(y, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, act, training)
@@ -844,8 +844,8 @@ class _MCALayer(Function):
                ks[2], ptr(dz), ptr(coef), ptr(dwts), ptr(dks), N, H, W, C, st)
         dx = torch.empty((N, H, W, C), dtype=x.dtype, device=dev)
         L.call("egm_mca_bwd_dx", dt, ptr(dxo), C, ptr(x), ldx, ptr(gates), ptr(coef), ptr(dx), C, N, H, W, C, st)
-        gk = [dks[a, :ks[a]].reshape(1, 1, 1, ks[a]).clone() for a in range(3)]
-        return dx, dwts[0].clone(), gk[0], dwts[1].clone(), gk[1], dwts[2].clone(), gk[2], None
+        gk = [dks[a, :ks[a]].reshape(1, 1, 1, ks[a]) for a in range(3)]
+        return dx, dwts[0], gk[0], dwts[1], gk[1], dwts[2], gk[2], None
 
 
 def mca_layer(x, layer, training):

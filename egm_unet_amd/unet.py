@@ -77,8 +77,20 @@ class _SegNetBase(nn.Module):
         self.compute_dtype = dtype
         return self
 
+    def _bump_bn_counters(self):
+        """num_batches_tracked += 1 for every BatchNorm holder in ONE multi-tensor call (instead of one tiny kernel each)."""
+        bns = getattr(self, "_bn_holders", None)
+        if bns is None:
+            bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
+            for m in bns:
+                m._egm_counter_managed = True
+            self._bn_holders = bns
+        if self.training and bns:
+            torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+
     def _enter(self, x):
         require_gpu()
+        self._bump_bn_counters()
         if not x.is_cuda:
             raise RuntimeError("egm_unet_amd models run on the GPU only: move the input (and the model) to cuda")
         if x.dim() != 4 or x.shape[1] != self.in_channels:
