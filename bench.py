@@ -59,6 +59,31 @@ class KernelTimer:
         self.lib.call = self._orig
         torch.cuda.synchronize()
 
+    def conv_table(self):
+        """Per conv shape: launches, time, achieved TFLOP/s and algorithmic GB/s (bf16 in+out+weights once)."""
+        rows = {}
+        for name, args, e0, e1 in self.records:
+            if name == "egm_conv_fwd":
+                N, H, W, Cin, Cout, KH, KW, dil = args[9:17]
+                kind = "fwd/dgrad"
+            elif name == "egm_conv_wgrad":
+                N, H, W, Cin, Cout = args[7:12]
+                KH, KW, dil = args[14:17]
+                kind = "wgrad"
+            else:
+                continue
+            key = (kind, KH, dil, Cin, Cout, H, W)
+            r = rows.setdefault(key, [0, 0.0])
+            r[0] += 1; r[1] += e0.elapsed_time(e1)
+        out = []
+        for (kind, KH, dil, Cin, Cout, H, W), (n, ms) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+            flop = 2.0 * 8 * H * W * Cin * Cout * KH * KH
+            byts = 2.0 * (8 * H * W * (Cin + Cout) + KH * KH * Cin * Cout)
+            t = ms / n * 1e-3
+            out.append(f"{kind:9s} k{KH} d{dil:<2d} {Cin:4d}->{Cout:<4d} {H:3d}x{W:<3d} n={n:2d} avg={ms / n * 1e3:7.1f}us "
+                       f"{flop / t / 1e12:7.1f} TF/s {byts / t / 1e9:7.0f} GB/s  total={ms:6.3f}ms")
+        return out
+
     def summary(self):
         agg = {}
         for name, args, e0, e1 in self.records:
@@ -203,6 +228,8 @@ def main():
         print(f"[bench] host enqueue {1e3 * t_enqueue / args.steps:.2f} ms/step vs wall {1e3 * elapsed / args.steps:.2f} ms/step", file=sys.stderr)
         print("[bench] kernel time by C-ABI entry (instrumented step, ms): " +
               ", ".join(f"{k}={v[1]:.2f}({v[0]})" for k, v in top) + f"; total {total_ms:.2f}", file=sys.stderr)
+        if os.environ.get("EGM_CONV_TABLE"):
+            print("\n".join(kt.conv_table()), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
 

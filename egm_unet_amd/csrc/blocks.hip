@@ -462,6 +462,104 @@ __global__ void merge357_bwd_kernel(const float* __restrict__ gw, float* __restr
     }
 }
 
+
+// ---- SpatialAttentionModule.conv1: 7x7, 2 -> 1 channels, no bias (src/EGM-UNet.py:1192,1195-1199) ------------------------
+// A 2->1 channel conv has no use for matrix cores: one lane per pixel reads the (mean, max) pair of its 49 neighbours
+// (4 bytes bf16 / 8 bytes fp32 each, L1-resident) and keeps the 98 weights in scalar registers.
+// in: 8-channel map (ch0, ch1 used); out: 8-channel map (ch0 = result, rest 0).
+template <typename T> __device__ __forceinline__ void load2(const T* p, float& a, float& b);
+template <> __device__ __forceinline__ void load2<float>(const float* p, float& a, float& b) { const float2 v = *reinterpret_cast<const float2*>(p); a = v.x; b = v.y; }
+template <> __device__ __forceinline__ void load2<bf16_t>(const bf16_t* p, float& a, float& b) {
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(p);
+    a = __uint_as_float(v << 16); b = __uint_as_float(v & 0xffff0000u);
+}
+template <typename T>
+__global__ void sa_conv7_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, T* __restrict__ y, int ldy, int N, int H, int W) {
+    const long long total = (long long)N * H * W;
+    for (long long p = blockIdx.x * 256LL + threadIdx.x; p < total; p += (long long)gridDim.x * 256) {
+        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int y2 = yy + r - 3;
+            if (y2 < 0 || y2 >= H) continue;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const int x2 = xx + q - 3;
+                if (x2 < 0 || x2 >= W) continue;
+                float a, b;
+                load2(x + (p + (long long)(r - 3) * W + (q - 3)) * ldx, a, b);
+                acc += a * w[r * 7 + q] + b * w[49 + r * 7 + q];
+            }
+        }
+        float o[8]; zero8(o); o[0] = acc;
+        store8(y + p * ldy, o);
+    }
+}
+// dx[q][c] = sum_taps w[c][r][s] * dy[q - (r-3, s-3)]
+template <typename T>
+__global__ void sa_conv7_bwd_data_kernel(const T* __restrict__ dy, int lddy, const float* __restrict__ w, T* __restrict__ dx, int lddx, int N,
+                                         int H, int W) {
+    const long long total = (long long)N * H * W;
+    for (long long p = blockIdx.x * 256LL + threadIdx.x; p < total; p += (long long)gridDim.x * 256) {
+        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int y2 = yy - (r - 3);
+            if (y2 < 0 || y2 >= H) continue;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const int x2 = xx - (q - 3);
+                if (x2 < 0 || x2 >= W) continue;
+                const float g = to_f32(dy[(p - (long long)(r - 3) * W - (q - 3)) * lddy]);
+                a0 += g * w[r * 7 + q]; a1 += g * w[49 + r * 7 + q];
+            }
+        }
+        float o[8]; zero8(o); o[0] = a0; o[1] = a1;
+        store8(dx + p * lddx, o);
+    }
+}
+// dw[c][r][s] = sum_p dy[p] * x[p + (r-3, s-3)][c]; per-block partials [nblk][98]
+template <typename T>
+__global__ __launch_bounds__(256) void sa_conv7_bwd_w_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
+                                                             float* __restrict__ part, int N, int H, int W) {
+    __shared__ float red[4][98];
+    float acc[98];
+#pragma unroll
+    for (int k = 0; k < 98; ++k) acc[k] = 0.f;
+    const long long total = (long long)N * H * W;
+    for (long long p = blockIdx.x * 256LL + threadIdx.x; p < total; p += (long long)gridDim.x * 256) {
+        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        const float g = to_f32(dy[p * lddy]);
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int y2 = yy + r - 3;
+            if (y2 < 0 || y2 >= H) continue;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const int x2 = xx + q - 3;
+                if (x2 < 0 || x2 >= W) continue;
+                float a, b;
+                load2(x + (p + (long long)(r - 3) * W + (q - 3)) * ldx, a, b);
+                acc[r * 7 + q] += g * a; acc[49 + r * 7 + q] += g * b;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 98; ++k) { const float v = wave_sum(acc[k]); if (lane == 0) red[wv][k] = v; }
+    __syncthreads();
+    if (threadIdx.x < 98) part[(long long)blockIdx.x * 98 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void sa_conv7_bwd_w_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dw) {
+    const int k = threadIdx.x;
+    if (k >= 98) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(long long)b * 98 + k];
+    dw[k] = (float)s;
+}
+
 inline int group_for(int ncv) { int g = 1; while (g < ncv) g <<= 1; return g; }
 
 }  // namespace
@@ -685,5 +783,35 @@ extern "C" int egm_merge357_bwd(const float* gw, float* d3, float* d5, float* d7
     EGM_REQUIRE(gw && d3 && d5 && d7 && Co > 0 && Ci > 0, "merge357_bwd: bad args");
     hipLaunchKernelGGL(merge357_bwd_kernel, dim3((Co * Ci * 49 + 255) / 256), dim3(256), 0, (hipStream_t)s, gw, d3, d5, d7, Co, Ci);
     EGM_CHECK_LAUNCH("merge357_bwd");
+    return EGM_OK;
+}
+
+static int sa_blocks(long long npix) { long long b = (npix + 255) / 256; if (b > 512) b = 512; return (int)(b < 1 ? 1 : b); }
+extern "C" int egm_sa_conv7_fwd(int dtype, const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, egm_stream_t s) {
+    EGM_REQ_VEC("sa_conv7_fwd", x, ldx, 8); EGM_REQ_VEC("sa_conv7_fwd", y, ldy, 8);
+    EGM_REQUIRE(w && N > 0 && H > 0 && W > 0, "sa_conv7_fwd: bad args");
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sa_conv7_fwd_kernel<T>), dim3(stream_grid((long long)N * H * W)), dim3(256), 0, (hipStream_t)s,
+                                                 (const T*)x, ldx, w, (T*)y, ldy, N, H, W));
+    EGM_CHECK_LAUNCH("sa_conv7_fwd");
+    return EGM_OK;
+}
+extern "C" long long egm_sa_conv7_bwd_workspace(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return -1;
+    return (long long)sa_blocks((long long)N * H * W) * 98 * 4;
+}
+extern "C" int egm_sa_conv7_bwd(int dtype, const void* x, int ldx, const void* dy, int lddy, const float* w, void* dx, int lddx, float* dw,
+                                void* workspace, int N, int H, int W, egm_stream_t s) {
+    EGM_REQ_VEC("sa_conv7_bwd", x, ldx, 8); EGM_REQ_VEC("sa_conv7_bwd", dy, lddy, 8); EGM_REQ_VEC("sa_conv7_bwd", dx, lddx, 8);
+    EGM_REQUIRE(w && dw && workspace && N > 0 && H > 0 && W > 0, "sa_conv7_bwd: bad args");
+    const long long npix = (long long)N * H * W;
+    const int nb = sa_blocks(npix);
+    EGM_DISPATCH_DTYPE(dtype, {
+        hipLaunchKernelGGL((sa_conv7_bwd_data_kernel<T>), dim3(stream_grid(npix)), dim3(256), 0, (hipStream_t)s, (const T*)dy, lddy, w, (T*)dx, lddx,
+                           N, H, W);
+        hipLaunchKernelGGL((sa_conv7_bwd_w_kernel<T>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, (const T*)dy, lddy,
+                           (float*)workspace, N, H, W);
+    });
+    hipLaunchKernelGGL(sa_conv7_bwd_w_final_kernel, dim3(1), dim3(128), 0, (hipStream_t)s, (const float*)workspace, nb, dw);
+    EGM_CHECK_LAUNCH("sa_conv7_bwd");
     return EGM_OK;
 }

@@ -151,7 +151,18 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
         float sc[8], sh[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { sc[j] = scale[cv * 8 + j]; sh[j] = shift[cv * 8 + j]; }
-        for (long long p = (long long)blockIdx.x * ppb + threadIdx.x / ncv; p < npix; p += (long long)gridDim.x * ppb) {
+        const long long stride = (long long)gridDim.x * ppb;
+        long long p = (long long)blockIdx.x * ppb + threadIdx.x / ncv;
+        for (; p + stride < npix; p += 2 * stride) {              // two independent vectors in flight
+            float v[8], u[8];
+            load8(y + p * ldy + cv * 8, v);
+            load8(y + (p + stride) * ldy + cv * 8, u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[j] = act_fwd(v[j] * sc[j] + sh[j], act); u[j] = act_fwd(u[j] * sc[j] + sh[j], act); }
+            store8(z + p * ldz + cv * 8, v);
+            store8(z + (p + stride) * ldz + cv * 8, u);
+        }
+        if (p < npix) {
             float v[8];
             load8(y + p * ldy + cv * 8, v);
 #pragma unroll
@@ -193,7 +204,23 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
                 cb[j] = -sc[j] * m0 - cc[j] * mean[c];
             } else { cb[j] = 0.f; cc[j] = 0.f; }
         }
-        for (long long p = (long long)blockIdx.x * ppb + threadIdx.x / ncv; p < npix; p += (long long)gridDim.x * ppb) {
+        const long long stride = (long long)gridDim.x * ppb;
+        long long p = (long long)blockIdx.x * ppb + threadIdx.x / ncv;
+        for (; p + stride < npix; p += 2 * stride) {              // two independent vector pairs in flight
+            float g[8], yv[8], g2[8], y2[8];
+            load8(dz + p * lddz + cv * 8, g);
+            load8(y + p * ldy + cv * 8, yv);
+            load8(dz + (p + stride) * lddz + cv * 8, g2);
+            load8(y + (p + stride) * ldy + cv * 8, y2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                g[j] = sc[j] * g[j] * act_grad(yv[j] * sc[j] + sh[j], act) + cb[j] + cc[j] * yv[j];
+                g2[j] = sc[j] * g2[j] * act_grad(y2[j] * sc[j] + sh[j], act) + cb[j] + cc[j] * y2[j];
+            }
+            store8(dy + p * lddy + cv * 8, g);
+            store8(dy + (p + stride) * lddy + cv * 8, g2);
+        }
+        if (p < npix) {
             float g[8], yv[8];
             load8(dz + p * lddz + cv * 8, g);
             load8(y + p * ldy + cv * 8, yv);

@@ -230,15 +230,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 //     vectors and stored with fully coalesced 16-byte stores (+bias);
 //   * BatchNorm partial statistics accumulate in registers over ALL pixel tiles of the workgroup: one partial per
 //     pixel-group instead of one per tile.
-template <int WIN> struct PipeGeom {
-    static constexpr int PH = TH + WIN - 1, PW = TW + WIN - 1, NTAPS = WIN * WIN;
+//   * staged window WH x WW: 3x3 (whole kernel), 1x1 (1x1 convs and each tap of a dilated conv), 1x7 (one kernel row of
+//     a 7x7 conv per stage: the 49-tap weight slab would not fit LDS).
+template <int WH, int WW> struct PipeGeom {
+    static constexpr int PH = TH + WH - 1, PW = TW + WW - 1, NTAPS = WH * WW;
     static constexpr int PVEC = (PH * PW * 4 + 255) / 256;                 // patch 16-byte vectors per thread
 };
 
-template <int NT, int WIN>
+template <int NT, int WH, int WW>
 __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvParams p, int G) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using Gm = PipeGeom<WIN>;
+    using Gm = PipeGeom<WH, WW>;
     using M = Mma<bf16_t>;
     constexpr int PS = 80;                                                   // LDS row: 32 ch bf16 + 16 B pad
     constexpr int PH = Gm::PH, PW = Gm::PW, NTAPS = Gm::NTAPS, PVEC = Gm::PVEC;
@@ -260,7 +262,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvParams p, i
     unsigned char* wts = smem + p.patch_bytes;
 
     const int tpi = p.tiles_y * p.tiles_x;
-    const int ngroups = (p.dil == 1) ? 1 : p.KH * p.KW;                     // WIN == 1 for dilated convs
+    const bool row_mode = (p.dil == 1 && WH == 1 && p.KH > 1);            // one kernel row per stage
+    const int ngroups = (p.dil == 1) ? (row_mode ? p.KH : 1) : p.KH * p.KW;  // 1x1 windows for dilated convs
     const int nchunks = (p.Cin + KC - 1) / KC;
     const bool w_static = (ngroups == 1 && nchunks == 1);
 
@@ -283,7 +286,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvParams p, i
             if (st.pt >= p.npt) { st.valid = false; return; }
             st.n = st.pt / tpi; const int trem = st.pt - st.n * tpi;
             st.oy0 = (trem / p.tiles_x) * TH; st.ox0 = (trem % p.tiles_x) * TW;
-            if (p.dil == 1) { st.offy = -(p.KH / 2); st.offx = -(p.KW / 2); st.tap0 = 0; st.valid = true; return; }
+            if (p.dil == 1) {
+                st.offy = row_mode ? st.g - p.KH / 2 : -(p.KH / 2); st.offx = -(p.KW / 2); st.tap0 = row_mode ? st.g * p.KW : 0;
+                st.valid = true; return;
+            }
             st.offy = (st.g / p.KW - p.KH / 2) * p.dil; st.offx = (st.g % p.KW - p.KW / 2) * p.dil; st.tap0 = st.g;
             const bool out = st.oy0 + st.offy >= p.H || st.oy0 + st.offy + TH <= 0 || st.ox0 + st.offx >= p.W || st.ox0 + st.offx + TW <= 0;
             // the centre tap (offset 0) always contributes, so every tile keeps at least one group
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvParams p, i
             const int nks = (kc + 15) >> 4;
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) {
-                const int wr = t / WIN, ws = t - wr * WIN;
+                const int wr = t / WW, ws = t - wr * WW;
                 const unsigned char* b0 = patch + ((2 * wv + 0 + wr) * PW + r31 + ws) * PS;
                 const unsigned char* b1 = patch + ((2 * wv + 1 + wr) * PW + r31 + ws) * PS;
                 const unsigned char* a0 = wts + (t * NT * 32 + r31) * PS;
@@ -489,6 +495,12 @@ int launch_conv(const ConvParams& p, size_t smem, hipStream_t st) {
 }
 
 
+// couts per workgroup = 32*NT: 64-wide tiles halve the patch traffic, 32-wide tiles double the workgroup count; take the
+// narrow tile when the wide one would leave CUs idle (small feature maps)
+int conv_nt(int npt, int Cout) {
+    if (Cout <= 32) return 1;
+    return ((long long)npt * egm_cdiv(Cout, 64) >= 256) ? 2 : 1;
+}
 // pixel groups of the pipelined kernel: ~2 resident workgroups per CU, multiple of 8 (XCD round-robin)
 int pipe_groups(int npt, int nct) {
     int g = (512 / nct) / 8 * 8;
@@ -497,15 +509,15 @@ int pipe_groups(int npt, int nct) {
     return g;
 }
 bool pipe_eligible(int dtype, int KH, int KW, int dil) {
-    return dtype == EGM_BF16 && KH == KW && ((KH == 3 && dil == 1) || KH == 1 || (KH == 3 && dil > 1));
+    return dtype == EGM_BF16 && KH == KW && ((KH == 3 && dil == 1) || KH == 1 || (KH == 3 && dil > 1) || (KH == 7 && dil == 1));
 }
 
-template <int NT, int WIN>
+template <int NT, int WH, int WW>
 int launch_pipe(ConvParams& p, hipStream_t st) {
-    using Gm = PipeGeom<WIN>;
+    using Gm = PipeGeom<WH, WW>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_pipe_kernel<NT, WIN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_pipe_kernel<NT, WH, WW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_igemm_pipe: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
@@ -516,7 +528,7 @@ int launch_pipe(ConvParams& p, hipStream_t st) {
     if (smem < otile) smem = otile;
     const int G = pipe_groups(p.npt, p.nct);
     const int grid = ((G + 7) / 8) * 8 * p.nct;
-    hipLaunchKernelGGL((conv_igemm_pipe_kernel<NT, WIN>), dim3(grid), dim3(256), smem, st, p, G);
+    hipLaunchKernelGGL((conv_igemm_pipe_kernel<NT, WH, WW>), dim3(grid), dim3(256), smem, st, p, G);
     EGM_CHECK_LAUNCH("conv_igemm_pipe");
     return EGM_OK;
 }
@@ -525,7 +537,7 @@ int launch_pipe(ConvParams& p, hipStream_t st) {
 extern "C" int egm_conv_stats_tiles(int dtype, int N, int H, int W, int Cout, int KH, int KW, int dil) {
     const int npt = N * egm_cdiv(H, TH) * egm_cdiv(W, TW);
     if (KH == 1 && KW == 1) dil = 1;
-    if (pipe_eligible(dtype, KH, KW, dil)) return pipe_groups(npt, egm_cdiv(Cout, Cout > 32 ? 64 : 32));
+    if (pipe_eligible(dtype, KH, KW, dil)) return pipe_groups(npt, egm_cdiv(Cout, 32 * conv_nt(npt, Cout)));
     return npt;
 }
 
@@ -559,13 +571,13 @@ extern "C" int egm_conv_fwd(int dtype, const void* x, int ldx, const void* wf, c
     p.x = x; p.w = wf; p.bias = (const float*)bias; p.y = y; p.stats = stats;
     p.ldx = ldx; p.ldy = ldy; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.dil = dil; p.bias_n = bias ? bias_n : 0;
     p.tiles_y = egm_cdiv(H, TH); p.tiles_x = egm_cdiv(W, TW); p.npt = N * p.tiles_y * p.tiles_x;
-    const int NT = (Cout > 32) ? 2 : 1;
+    const int NT = conv_nt(p.npt, Cout);
     p.nct = egm_cdiv(Cout, NT * 32);
     if (pipe_eligible(dtype, KH, KW, dil)) {
         hipStream_t st = (hipStream_t)s;
-        const int win = (KH == 3 && dil == 1) ? 3 : 1;
-        if (win == 3) return NT == 2 ? launch_pipe<2, 3>(p, st) : launch_pipe<1, 3>(p, st);
-        return NT == 2 ? launch_pipe<2, 1>(p, st) : launch_pipe<1, 1>(p, st);
+        if (KH == 3 && dil == 1) return NT == 2 ? launch_pipe<2, 3, 3>(p, st) : launch_pipe<1, 3, 3>(p, st);
+        if (KH == 7) return NT == 2 ? launch_pipe<2, 1, 7>(p, st) : launch_pipe<1, 1, 7>(p, st);
+        return NT == 2 ? launch_pipe<2, 1, 1>(p, st) : launch_pipe<1, 1, 1>(p, st);
     }
     const int ps = (dtype == EGM_BF16) ? Mma<bf16_t>::kPixStride : Mma<float>::kPixStride;
     const bool halo = (dil == 1);

@@ -114,7 +114,10 @@ class SpatialAttentionModule(nn.Module):
 
     def logits(self, s, c_real):
         """-> [N,H,W,8] whose channel 0 is conv7x7([mean_c s, max_c s]) (pre-sigmoid)."""
-        return ops.conv2d(ops.chan_meanmax(s, c_real), self.conv1.weight)
+        mm = ops.chan_meanmax(s, c_real)
+        if tuple(self.conv1.weight.shape) == (1, 2, 7, 7):
+            return ops.sa_conv7(mm, self.conv1.weight)
+        return ops.conv2d(mm, self.conv1.weight)
 
 
 class FusionConv(nn.Module):

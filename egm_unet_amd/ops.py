@@ -852,3 +852,33 @@ def mca_layer(x, layer, training):
     """layer: an MCALayer parameter holder with gates h_cw, w_hc, c_hw (each: .weight [2], .conv.weight [1,1,1,k])."""
     return _MCALayer.apply(x, layer.h_cw.weight, layer.h_cw.conv.weight, layer.w_hc.weight, layer.w_hc.conv.weight,
                            layer.c_hw.weight, layer.c_hw.conv.weight, training)
+
+
+class _SAConv7(Function):
+    """SpatialAttentionModule.conv1 (7x7, 2->1) on the (mean, max) map as a direct stencil."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x, ldx = _nhwc(x)
+        N, H, W, _ = x.shape
+        wd = w.detach().contiguous()
+        y = torch.empty((N, H, W, 8), dtype=x.dtype, device=x.device)
+        lib().call("egm_sa_conv7_fwd", dtype_code(x.dtype), ptr(x), ldx, ptr(wd), ptr(y), 8, N, H, W, stream())
+        ctx.save_for_backward(x, wd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        x, ldx = _nhwc(x); g, ldg = _nhwc(g)
+        N, H, W, _ = x.shape
+        L, dev = lib(), x.device
+        dx = torch.empty((N, H, W, 8), dtype=x.dtype, device=dev)
+        dw = torch.empty((1, 2, 7, 7), dtype=torch.float32, device=dev)
+        ws = torch.empty(L.query("egm_sa_conv7_bwd_workspace", N, H, W) // 4 + 4, dtype=torch.float32, device=dev)
+        L.call("egm_sa_conv7_bwd", dtype_code(x.dtype), ptr(x), ldx, ptr(g), ldg, ptr(w), ptr(dx), 8, ptr(dw), ptr(ws), N, H, W, stream())
+        return dx, dw
+
+
+def sa_conv7(x, w):
+    return _SAConv7.apply(x, w)

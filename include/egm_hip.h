@@ -174,6 +174,12 @@ int egm_chan_meanmax_fwd(int dtype, const void* x, int ldx, void* out, int ldo, 
                          egm_stream_t s);
 int egm_chan_meanmax_bwd(int dtype, const void* g, int ldg, const void* x, int ldx, void* dx, int lddx, long long npix, int C,
                          int C_real, egm_stream_t s);
+/* SpatialAttentionModule.conv1 (7x7, 2 -> 1, no bias, w fp32 [1][2][7][7]) as a direct stencil on the 8-channel (mean, max)
+ * map; out/dx are 8-channel maps (ch0 / ch0-1 real).  bwd: dx, dw; workspace egm_sa_conv7_bwd_workspace() bytes. */
+int egm_sa_conv7_fwd(int dtype, const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, egm_stream_t s);
+long long egm_sa_conv7_bwd_workspace(int N, int H, int W);
+int egm_sa_conv7_bwd(int dtype, const void* x, int ldx, const void* dy, int lddy, const float* w, void* dx, int lddx, float* dw,
+                     void* workspace, int N, int H, int W, egm_stream_t s);
 /* ChannelAttentionModule pools: out [2N][C] (rows 0..N-1 = global average, N..2N-1 = global max), argidx int32 [N][C] =
  * first position of the maximum; workspace egm_global_pool_workspace() bytes. */
 long long egm_global_pool_workspace(int N, long long HW, int C);
