@@ -32,12 +32,17 @@ __global__ __launch_bounds__(256) void channel_partials_kernel(const T* __restri
     const int tid = threadIdx.x, cv = tid % ncv, row = tid / ncv;
     float s[8], q[8];
     zero8(s); zero8(q);
-    if (row < rows) {
-        float sc[8], sh[8], mu[8], rs[8];
-        if (MODE == 1) {
+    if (MODE == 1) {                                           // stage the per-channel coefficients once per block
+        for (int c = tid; c < C; c += 256) { red[c] = scale[c]; red[C + c] = shift[c]; red[2 * C + c] = mean[c]; red[3 * C + c] = rstd[c]; }
+        __syncthreads();
+    }
+    float sc[8], sh[8], mu[8], rs[8];
+    if (MODE == 1) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { sc[j] = scale[cv * 8 + j]; sh[j] = shift[cv * 8 + j]; mu[j] = mean[cv * 8 + j]; rs[j] = rstd[cv * 8 + j]; }
-        }
+        for (int j = 0; j < 8; ++j) { sc[j] = red[cv * 8 + j]; sh[j] = red[C + cv * 8 + j]; mu[j] = red[2 * C + cv * 8 + j]; rs[j] = red[3 * C + cv * 8 + j]; }
+        __syncthreads();                                       // red[] is reused for the reduction below
+    }
+    if (row < rows) {
         for (long long p = (long long)blockIdx.x * rows + row; p < npix; p += (long long)gridDim.x * rows) {
             float v[8];
             load8(a + p * lda + cv * 8, v);
@@ -147,10 +152,15 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
                                                          long long npix, int C) {
     const int ncv = C >> 3;
     if (256 % ncv == 0) {
+        // per-channel coefficients: staged once per block through LDS (every thread of every block reading the same few
+        // global lines serialises on one L2 channel)
+        __shared__ float cf[2 * 2048];
+        for (int c = threadIdx.x; c < C; c += 256) { cf[c] = scale[c]; cf[C + c] = shift[c]; }
+        __syncthreads();
         const int cv = threadIdx.x % ncv, ppb = 256 / ncv;
         float sc[8], sh[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { sc[j] = scale[cv * 8 + j]; sh[j] = shift[cv * 8 + j]; }
+        for (int j = 0; j < 8; ++j) { sc[j] = cf[cv * 8 + j]; sh[j] = cf[C + cv * 8 + j]; }
         const long long stride = (long long)gridDim.x * ppb;
         long long p = (long long)blockIdx.x * ppb + threadIdx.x / ncv;
         for (; p + stride < npix; p += 2 * stride) {              // two independent vectors in flight
@@ -192,17 +202,24 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
                                                                T* __restrict__ dy, int lddy, long long npix, int C) {
     const int ncv = C >> 3;
     if (256 % ncv == 0) {
+        __shared__ float cf[4 * 2048];                     // scale | shift | cb | cc, computed once per block
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float scv = scale[c];
+            float cbv = 0.f, ccv = 0.f;
+            if (train) {
+                const float m0 = sums[c] * inv_count, m1 = sums[C + c] * inv_count;
+                ccv = -scv * rstd[c] * m1;
+                cbv = -scv * m0 - ccv * mean[c];
+            }
+            cf[c] = scv; cf[C + c] = shift[c]; cf[2 * C + c] = cbv; cf[3 * C + c] = ccv;
+        }
+        __syncthreads();
         const int cv = threadIdx.x % ncv, ppb = 256 / ncv;
         float sc[8], sh[8], cb[8], cc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = cv * 8 + j;
-            sc[j] = scale[c]; sh[j] = shift[c];
-            if (train) {
-                const float m0 = sums[c] * inv_count, m1 = sums[C + c] * inv_count;
-                cc[j] = -sc[j] * rstd[c] * m1;
-                cb[j] = -sc[j] * m0 - cc[j] * mean[c];
-            } else { cb[j] = 0.f; cc[j] = 0.f; }
+            sc[j] = cf[c]; sh[j] = cf[C + c]; cb[j] = cf[2 * C + c]; cc[j] = cf[3 * C + c];
         }
         const long long stride = (long long)gridDim.x * ppb;
         long long p = (long long)blockIdx.x * ppb + threadIdx.x / ncv;
@@ -339,7 +356,7 @@ extern "C" int egm_bn_act_bwd_reduce(int dtype, const void* dz, int lddz, const 
                                      long long npix, int C, egm_stream_t s) {
     EGM_REQ_VEC("bn_act_bwd_reduce", dz, lddz, C);
     EGM_REQ_VEC("bn_act_bwd_reduce", y, ldy, C);
-    EGM_REQUIRE(scale && shift && save_mean && save_rstd && partials && npix > 0 && C <= 2048, "bn_act_bwd_reduce: bad args");
+    EGM_REQUIRE(scale && shift && save_mean && save_rstd && partials && npix > 0 && C <= 1024, "bn_act_bwd_reduce: bad args (C <= 1024)");
     const int nb = partial_blocks(npix, C);
     EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_partials_kernel<T, 1>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const T*)dz,
                                                  lddz, (const T*)y, ldy, scale, shift, save_mean, save_rstd, act, npix, C, partials));
