@@ -15,7 +15,7 @@
 namespace {
 
 constexpr int MAXC = 16;
-constexpr int kLossBlocksPerImage = 64;
+constexpr int kLossBlocksPerImage = 256;
 
 __device__ __forceinline__ float lap4_at(const float* __restrict__ m, int y, int x, int H, int W) {
     float c = -4.f * m[(long long)y * W + x];
@@ -282,19 +282,38 @@ __global__ void metrics_finalize_kernel(const unsigned long long* __restrict__ h
 
 // ---- fused multi-tensor SGD -----------------------------------------------------------------------------
 struct SgdEntry { float* p; const float* g; float* buf; long long n; };
-__global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdEntry* __restrict__ tab, const float* __restrict__ lr_dev, float lr,
-                                                        float momentum, float wd, float gscale, int first) {
-    const SgdEntry e = tab[blockIdx.y];
-    const float rate = lr_dev ? lr_dev[0] : lr;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < e.n; i += (long long)gridDim.x * 256) {
-        const float p = e.p[i];
-        float g = e.g[i] * gscale + wd * p;
-        if (momentum != 0.f) {
-            const float v = first ? g : momentum * e.buf[i] + g;
-            e.buf[i] = v;
-            g = v;
+constexpr int kSgdChunk = 2048;                               // elements per block (8 per thread)
+// block b -> (tensor, chunk) by binary search over the running chunk count computed from the table itself
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdEntry* __restrict__ tab, int ntensors, const float* __restrict__ lr_dev,
+                                                        float lr, float momentum, float wd, float gscale, int first) {
+    __shared__ int s_t, s_c;
+    if (threadIdx.x == 0) {
+        long long b = blockIdx.x; int t = 0;
+        for (; t < ntensors; ++t) {                           // <= few hundred tensors: a linear scan by one lane is cheap
+            const long long nch = (tab[t].n + kSgdChunk - 1) / kSgdChunk;
+            if (b < nch) break;
+            b -= nch;
         }
-        e.p[i] = p - rate * g;
+        s_t = t; s_c = (int)b;
+    }
+    __syncthreads();
+    if (s_t >= ntensors) return;
+    const SgdEntry e = tab[s_t];
+    const float rate = lr_dev ? lr_dev[0] : lr;
+    const long long base = (long long)s_c * kSgdChunk;
+#pragma unroll
+    for (int k = 0; k < kSgdChunk / 256; ++k) {
+        const long long i = base + k * 256 + threadIdx.x;
+        if (i < e.n) {
+            const float p = e.p[i];
+            float g = e.g[i] * gscale + wd * p;
+            if (momentum != 0.f) {
+                const float v = first ? g : momentum * e.buf[i] + g;
+                e.buf[i] = v;
+                g = v;
+            }
+            e.p[i] = p - rate * g;
+        }
     }
 }
 // multi-tensor gather/scatter between per-parameter gradients and a flat bucket (DDP all-reduce staging)
@@ -306,6 +325,7 @@ __global__ __launch_bounds__(256) void copy_multi_kernel(const CopyEntry* __rest
 
 }  // namespace
 
+extern "C" int egm_sgd_chunk(void) { return kSgdChunk; }
 extern "C" long long egm_loss_workspace(int N, int C) {
     if (N <= 0 || C <= 0 || C > MAXC) return -1;
     return ((long long)N * kLossBlocksPerImage * (5 + 3 * C) + (long long)N * 3 * C + 1 + 8) * (long long)sizeof(float);
@@ -335,7 +355,7 @@ extern "C" int egm_loss_bwd(const float* logits, const long long* target, const 
     EGM_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C <= MAXC, "loss_bwd: bad shape");
     EGM_REQUIRE(!dice || signs, "loss_bwd: sign buffer missing");
     const float* stats = workspace + (long long)N * kLossBlocksPerImage * (5 + 3 * C);
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(kLossBlocksPerImage * 4, N), dim3(256), 0, (hipStream_t)s, logits, target, class_weight, stats,
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(kLossBlocksPerImage, N), dim3(256), 0, (hipStream_t)s, logits, target, class_weight, stats,
                        signs, grad_out, N, C, H, W, ignore_index, dice, dlogits);
     EGM_CHECK_LAUNCH("loss_bwd");
     return EGM_OK;
@@ -360,11 +380,11 @@ extern "C" int egm_metrics_finalize(const unsigned long long* hist, const unsign
     return EGM_OK;
 }
 
-extern "C" int egm_sgd_multi(const void* table_dev, int ntensors, const float* lr_dev, float lr, float momentum, float weight_decay,
-                             float grad_scale, int first_step, egm_stream_t s) {
-    EGM_REQUIRE(table_dev && ntensors > 0, "sgd_multi: bad args");
-    hipLaunchKernelGGL(sgd_multi_kernel, dim3(16, ntensors), dim3(256), 0, (hipStream_t)s, (const SgdEntry*)table_dev, lr_dev, lr, momentum,
-                       weight_decay, grad_scale, first_step);
+extern "C" int egm_sgd_multi(const void* table_dev, int ntensors, long long total_chunks, const float* lr_dev, float lr, float momentum,
+                             float weight_decay, float grad_scale, int first_step, egm_stream_t s) {
+    EGM_REQUIRE(table_dev && ntensors > 0 && total_chunks > 0 && total_chunks < (1LL << 30), "sgd_multi: bad args");
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)s, (const SgdEntry*)table_dev, ntensors,
+                       lr_dev, lr, momentum, weight_decay, grad_scale, first_step);
     EGM_CHECK_LAUNCH("sgd_multi");
     return EGM_OK;
 }

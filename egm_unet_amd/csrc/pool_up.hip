@@ -194,8 +194,13 @@ __global__ void upcat_bwd_low_kernel(const T* __restrict__ dout, int ldo, T* __r
 
 // ---- depthwise 3x3 (+bias) * scale ------------------------------------------------------------------
 template <typename T>
-__global__ void dwconv3_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ b,
+__global__ void dwconv3_fwd_kernel(const T* __restrict__ x, int ldx, const float* w, const float* b,
                                    const float* __restrict__ scale, T* __restrict__ y, int ldy, int N, int H, int W, int C) {
+    extern __shared__ float wl[];                              // [C][9] weights | [C] bias, staged once per block
+    for (int i = threadIdx.x; i < C * 9; i += 256) wl[i] = w[i];
+    for (int i = threadIdx.x; i < C; i += 256) wl[C * 9 + i] = b ? b[i] : 0.f;
+    __syncthreads();
+    w = wl; b = wl + C * 9;
     const int ncv = C >> 3;
     const long long total = (long long)N * H * W * ncv;
     const float sc = scale ? scale[0] : 1.f;
@@ -204,7 +209,7 @@ __global__ void dwconv3_fwd_kernel(const T* __restrict__ x, int ldx, const float
         const int xx = (int)(p % W), yy = (int)((p / W) % H);
         float acc[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = b ? b[cv * 8 + j] : 0.f;
+        for (int j = 0; j < 8; ++j) acc[j] = b[cv * 8 + j];
         for (int r = -1; r <= 1; ++r) {
             if (yy + r < 0 || yy + r >= H) continue;
             for (int s = -1; s <= 1; ++s) {
@@ -222,8 +227,12 @@ __global__ void dwconv3_fwd_kernel(const T* __restrict__ x, int ldx, const float
 }
 // dx[p] = scale * sum_taps dy[p - tap] * w[tap]
 template <typename T>
-__global__ void dwconv3_bwd_data_kernel(const T* __restrict__ dy, int lddy, const float* __restrict__ w, const float* __restrict__ scale,
+__global__ void dwconv3_bwd_data_kernel(const T* __restrict__ dy, int lddy, const float* w, const float* __restrict__ scale,
                                         T* __restrict__ dx, int lddx, int N, int H, int W, int C) {
+    extern __shared__ float wl[];
+    for (int i = threadIdx.x; i < C * 9; i += 256) wl[i] = w[i];
+    __syncthreads();
+    w = wl;
     const int ncv = C >> 3;
     const long long total = (long long)N * H * W * ncv;
     const float sc = scale ? scale[0] : 1.f;
@@ -250,10 +259,15 @@ __global__ void dwconv3_bwd_data_kernel(const T* __restrict__ dy, int lddy, cons
 //   y = (conv + b) * s  =>  dconv = dy*s ; dw = sum dconv * x_shift ; db = sum dconv ; ds = sum dy * (conv + b)
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3_bwd_param_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy,
-                                                                const float* __restrict__ w, const float* __restrict__ b,
+                                                                const float* w, const float* b,
                                                                 const float* __restrict__ scale, float* __restrict__ out, int N, int H,
                                                                 int W, int C) {
-    extern __shared__ float red[];                       // [rows][11][8*ncv] -> we reduce one quantity at a time
+    extern __shared__ float red[];                       // [256][8] reduction scratch | [C][9] weights | [C] bias
+    float* wl = red + 256 * 8;
+    for (int i = threadIdx.x; i < C * 9; i += 256) wl[i] = w[i];
+    for (int i = threadIdx.x; i < C; i += 256) wl[C * 9 + i] = b ? b[i] : 0.f;
+    __syncthreads();
+    w = wl; b = wl + C * 9;
     const int ncv = C >> 3, rows = 256 / ncv;
     const int tid = threadIdx.x, cv = tid % ncv, row = tid / ncv;
     const float sc = scale ? scale[0] : 1.f;
@@ -267,7 +281,7 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_param_kernel(const T* __restr
             float g[8], conv[8];
             load8(dy + p * lddy + cv * 8, g);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) conv[j] = b ? b[cv * 8 + j] : 0.f;
+            for (int j = 0; j < 8; ++j) conv[j] = b[cv * 8 + j];
 #pragma unroll
             for (int r = -1; r <= 1; ++r) {
 #pragma unroll
@@ -428,7 +442,7 @@ extern "C" int egm_dwconv3_fwd(int dtype, const void* x, int ldx, const float* w
     EGM_REQ_VEC("dwconv3_fwd", y, ldy, C);
     EGM_REQUIRE(w && N > 0 && H > 0 && W > 0, "dwconv3_fwd: bad args");
     const long long total = (long long)N * H * W * (C / 8);
-    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3_fwd_kernel<T>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)s,
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3_fwd_kernel<T>), dim3(stream_grid(total)), dim3(256), (size_t)C * 10 * sizeof(float), (hipStream_t)s,
                                                  (const T*)x, ldx, w, b, scale, (T*)y, ldy, N, H, W, C));
     EGM_CHECK_LAUNCH("dwconv3_fwd");
     return EGM_OK;
@@ -453,9 +467,9 @@ extern "C" int egm_dwconv3_bwd(int dtype, const void* x, int ldx, const void* dy
     const long long npix = (long long)N * H * W;
     const int nb = dw_blocks(npix, C);
     EGM_DISPATCH_DTYPE(dtype, {
-        hipLaunchKernelGGL((dwconv3_bwd_data_kernel<T>), dim3(stream_grid(npix * (C / 8))), dim3(256), 0, (hipStream_t)s, (const T*)dy,
+        hipLaunchKernelGGL((dwconv3_bwd_data_kernel<T>), dim3(stream_grid(npix * (C / 8))), dim3(256), (size_t)C * 9 * sizeof(float), (hipStream_t)s, (const T*)dy,
                            lddy, w, scale, (T*)dx, lddx, N, H, W, C);
-        hipLaunchKernelGGL((dwconv3_bwd_param_kernel<T>), dim3(nb), dim3(256), 256 * 8 * sizeof(float), (hipStream_t)s, (const T*)x, ldx,
+        hipLaunchKernelGGL((dwconv3_bwd_param_kernel<T>), dim3(nb), dim3(256), (256 * 8 + (size_t)C * 10) * sizeof(float), (hipStream_t)s, (const T*)x, ldx,
                            (const T*)dy, lddy, w, b, scale, (float*)workspace, N, H, W, C);
     });
     float* tmp = (float*)workspace + (long long)nb * 11 * C;

@@ -130,7 +130,7 @@ class _Conv2d(Function):
     """nn.Conv2d (stride 1, same padding) on NHWC activations; weight stays the fp32 OIHW nn.Parameter."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, dil, groups, want_stats):
+    def forward(ctx, x, weight, bias, dil, groups, want_stats, bias_grad_zero=False):
         x, ldx = _nhwc(x)
         N, H, W, CinP = x.shape
         Cout, Cin_g, KH, KW = weight.shape
@@ -149,6 +149,7 @@ class _Conv2d(Function):
                    CoutP, ptr(stats), N, H, W, CinP, CoutP, KH, KW, dil, stream())
         ctx.save_for_backward(x, weight, wd)
         ctx.meta = (dil, groups, bias is not None, Cin, Cout)
+        ctx.bias_grad_zero = bias_grad_zero
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
@@ -175,12 +176,12 @@ class _Conv2d(Function):
             L.call("egm_conv_wgrad", dt, ptr(x), ldx, ptr(gy), ldg, ptr(gw), ptr(ws), N, H, W, CinP, CoutP, Cin, Cout, KH, KW,
                    dil, groups, 0, st)
         if has_bias and ctx.needs_input_grad[2]:
-            gb = _channel_sum(gy)[0, :Cout]
-        return gx, gw, gb, None, None, None
+            gb = _f32(Cout, x.device, zero=True) if ctx.bias_grad_zero else _channel_sum(gy)[0, :Cout]
+        return gx, gw, gb, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, dil=1, groups=1, want_stats=False):
-    return _Conv2d.apply(x, weight, bias, dil, groups, want_stats)
+def conv2d(x, weight, bias=None, dil=1, groups=1, want_stats=False, bias_grad_zero=False):
+    return _Conv2d.apply(x, weight, bias, dil, groups, want_stats, bias_grad_zero)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -249,7 +250,8 @@ def bn_act(y, bn, act, stats=None):
 def conv_bn_act(x, conv, bn, act, dil=1, groups=1):
     """conv -> BatchNorm -> activation with the BN statistics produced by the conv epilogue."""
     if bn.training:
-        y, stats = conv2d(x, conv.weight, conv.bias, dil, groups, want_stats=True)
+        # a conv bias feeding a train-mode BN has an identically zero gradient (the batch mean absorbs it)
+        y, stats = conv2d(x, conv.weight, conv.bias, dil, groups, want_stats=True, bias_grad_zero=True)
         return bn_act(y, bn, act, stats)
     return bn_act(conv2d(x, conv.weight, conv.bias, dil, groups), bn, act)
 

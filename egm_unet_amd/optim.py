@@ -61,7 +61,9 @@ class SGD(torch.optim.Optimizer):
                 if not rows[first]:
                     continue
                 table = self._device_table((gi, first), rows[first], group["params"][0].device)
-                lib().call("egm_sgd_multi", ptr(table), len(rows[first]), None, float(group["lr"]), float(group["momentum"]),
+                ch = lib().cdll.egm_sgd_chunk()
+                chunks = sum((r[3] + ch - 1) // ch for r in rows[first])
+                lib().call("egm_sgd_multi", ptr(table), len(rows[first]), chunks, None, float(group["lr"]), float(group["momentum"]),
                            float(group["weight_decay"]), float(self.grad_scale), 1 if first else 0, stream())
         ops.bump_weight_generation()
         return loss

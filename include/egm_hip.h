@@ -259,8 +259,9 @@ int egm_metrics_finalize(const unsigned long long* hist, const unsigned long lon
 /* torch.optim.SGD(momentum, weight_decay) (train.py:115-118) over a device table of {float* p; const float* g; float* buf;
  * long long n;} entries: g' = g*grad_scale + wd*p; v = first_step ? g' : mu*v + g'; p -= lr*v.
  * lr_dev (device scalar) overrides lr when non-NULL. */
-int egm_sgd_multi(const void* table_dev, int ntensors, const float* lr_dev, float lr, float momentum, float weight_decay,
-                  float grad_scale, int first_step, egm_stream_t s);
+int egm_sgd_chunk(void);   /* elements per workgroup; total_chunks = sum over tensors of ceil(n / egm_sgd_chunk()) */
+int egm_sgd_multi(const void* table_dev, int ntensors, long long total_chunks, const float* lr_dev, float lr, float momentum,
+                  float weight_decay, float grad_scale, int first_step, egm_stream_t s);
 /* table of {float* dst; const float* src; long long n;}: gradient bucket gather/scatter for the RCCL all-reduce. */
 int egm_copy_multi(const void* table_dev, int ntensors, egm_stream_t s);
 
