@@ -479,6 +479,43 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, T* __restrict__ wf
     }
 }
 
+
+// all convolution weights of a model in ONE launch: table of descriptors, block -> (conv, chunk) by a scan of the chunk counts
+struct PackEntry { const float* w; void* wf; void* wd; int Cout, Cin, CoutP, CinP, KH, KW, groups, pad; };
+constexpr int kPackChunk = 1024;
+template <typename T>
+__global__ __launch_bounds__(256) void conv_pack_multi_kernel(const PackEntry* __restrict__ tab, int n) {
+    __shared__ int s_t, s_c;
+    if (threadIdx.x == 0) {
+        long long b = blockIdx.x; int t = 0;
+        for (; t < n; ++t) {
+            const long long nch = ((long long)tab[t].KH * tab[t].KW * tab[t].CoutP * tab[t].CinP + kPackChunk - 1) / kPackChunk;
+            if (b < nch) break;
+            b -= nch;
+        }
+        s_t = t; s_c = (int)b;
+    }
+    __syncthreads();
+    if (s_t >= n) return;
+    const PackEntry e = tab[s_t];
+    const long long total = (long long)e.KH * e.KW * e.CoutP * e.CinP;
+    const int cin_g = e.Cin / e.groups, cout_g = e.Cout / e.groups;
+    T* wf = reinterpret_cast<T*>(e.wf); T* wd = reinterpret_cast<T*>(e.wd);
+#pragma unroll
+    for (int k = 0; k < kPackChunk / 256; ++k) {
+        const long long i = (long long)s_c * kPackChunk + k * 256 + threadIdx.x;
+        if (i >= total) break;
+        const int ci = (int)(i % e.CinP), co = (int)((i / e.CinP) % e.CoutP), tap = (int)(i / ((long long)e.CinP * e.CoutP));
+        float v = 0.f;
+        if (co < e.Cout && ci < e.Cin && (co / cout_g) == (ci / cin_g)) {
+            const int r = tap / e.KW, sx = tap % e.KW;
+            v = e.w[(((long long)co * cin_g + (ci % cin_g)) * e.KH + r) * e.KW + sx];
+        }
+        wf[i] = from_f32<T>(v);
+        wd[((long long)(e.KH * e.KW - 1 - tap) * e.CinP + ci) * e.CoutP + co] = from_f32<T>(v);
+    }
+}
+
 template <typename T, int NT>
 int launch_conv(const ConvParams& p, size_t smem, hipStream_t st) {
     static bool attr_done = false;      // >64 KiB dynamic LDS needs an opt-in; done once per instantiation
@@ -552,6 +589,16 @@ extern "C" int egm_conv_pack(int dtype, const void* w, void* wf, void* wd, int C
     EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv_pack_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)s,
                                                  (const float*)w, (T*)wf, (T*)wd, Cout, Cin, CoutP, CinP, KH, KW, groups));
     EGM_CHECK_LAUNCH("conv_pack");
+    return EGM_OK;
+}
+
+extern "C" int egm_conv_pack_chunk(void) { return kPackChunk; }
+/* table: device array of {const float* w; void* wf; void* wd; int Cout, Cin, CoutP, CinP, KH, KW, groups, pad;} (56 bytes) */
+extern "C" int egm_conv_pack_multi(int dtype, const void* table_dev, int n, long long total_chunks, egm_stream_t s) {
+    EGM_REQUIRE(table_dev && n > 0 && total_chunks > 0 && total_chunks < (1LL << 30), "conv_pack_multi: bad args");
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv_pack_multi_kernel<T>), dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)s,
+                                                 (const PackEntry*)table_dev, n));
+    EGM_CHECK_LAUNCH("conv_pack_multi");
     return EGM_OK;
 }
 

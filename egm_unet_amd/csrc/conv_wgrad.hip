@@ -256,6 +256,43 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+
+// deferred reduction of MANY convolutions' slabs in one launch (end of backward): block -> (conv, 64-element chunk)
+struct WredEntry { const float* slab; float* dw; int nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate; };
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WredEntry* __restrict__ tab, int n) {
+    __shared__ float red[256];
+    __shared__ int s_t, s_c;
+    if (threadIdx.x == 0) {
+        long long b = blockIdx.x; int t = 0;
+        for (; t < n; ++t) {
+            const long long nch = ((long long)tab[t].taps * tab[t].CoutP * tab[t].CinP + 63) / 64;
+            if (b < nch) break;
+            b -= nch;
+        }
+        s_t = t; s_c = (int)b;
+    }
+    __syncthreads();
+    if (s_t >= n) return;
+    const WredEntry w = tab[s_t];
+    const long long total = (long long)w.taps * w.CoutP * w.CinP;
+    const int cin_g = w.CinR / w.groups, cout_g = w.CoutR / w.groups;
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long long i = (long long)s_c * 64 + e;
+    float s = 0.f;
+    if (i < total)
+        for (int k = sl; k < w.nslab; k += 4) s += w.slab[(long long)k * total + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+        s = (red[e] + red[64 + e]) + (red[128 + e] + red[192 + e]);
+        const int ci = (int)(i % w.CinP), co = (int)((i / w.CinP) % w.CoutP), tap = (int)(i / ((long long)w.CinP * w.CoutP));
+        if (co < w.CoutR && ci < w.CinR && (co / cout_g) == (ci / cin_g)) {
+            const long long o = ((long long)co * cin_g + (ci % cin_g)) * w.taps + tap;
+            w.dw[o] = w.accumulate ? w.dw[o] + s : s;
+        }
+    }
+}
+
 struct WgradPlan { int A, B, C, ntaps, ngroups, nsplit, nco_tiles, nci_tiles, npt, tiles_y, tiles_x; size_t smem; long long slab_bytes; };
 
 int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, WgradPlan* pl) {
@@ -328,10 +365,24 @@ extern "C" long long egm_conv_wgrad_workspace(int N, int H, int W, int Cin, int 
     return a;
 }
 
+extern "C" int egm_conv_wgrad_slabs(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil) {
+    WgradPlan pl;
+    if (KH == 1 && KW == 1) dil = 1;
+    if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl) != EGM_OK) return -1;
+    return pl.nsplit;
+}
+/* table: device array of {const float* slab; float* dw; int nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate;} (48 bytes) */
+extern "C" int egm_wgrad_reduce_multi(const void* table_dev, int n, long long total_chunks, egm_stream_t s) {
+    EGM_REQUIRE(table_dev && n > 0 && total_chunks > 0 && total_chunks < (1LL << 30), "wgrad_reduce_multi: bad args");
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)s, (const WredEntry*)table_dev, n);
+    EGM_CHECK_LAUNCH("wgrad_reduce_multi");
+    return EGM_OK;
+}
+
 extern "C" int egm_conv_wgrad(int dtype, const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace, int N,
                               int H, int W, int Cin, int Cout, int CinR, int CoutR, int KH, int KW, int dil, int groups,
                               int accumulate, egm_stream_t s) {
-    EGM_REQUIRE(x && dy && dw && workspace, "conv_wgrad: null pointer");
+    EGM_REQUIRE(x && dy && workspace, "conv_wgrad: null pointer");
     EGM_REQUIRE(N > 0 && H > 0 && W > 0, "conv_wgrad: bad shape");
     EGM_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && Cin > 0 && Cout > 0, "conv_wgrad: padded channels must be multiples of 8");
     EGM_REQUIRE(CinR <= Cin && CoutR <= Cout && CinR > 0 && CoutR > 0 && groups > 0 && CinR % groups == 0 && CoutR % groups == 0,
@@ -354,6 +405,7 @@ extern "C" int egm_conv_wgrad(int dtype, const void* x, int ldx, const void* dy,
     else if (dtype == EGM_F32) rc = dispatch_wgrad<float>(p, pl, st);
     else EGM_FAIL(EGM_ERR_ARG, "conv_wgrad: unknown dtype %d", dtype);
     if (rc != EGM_OK) return rc;
+    if (dw == nullptr) return EGM_OK;                  // slabs only: the caller reduces later with egm_wgrad_reduce_multi
     const long long total = (long long)KH * KW * Cout * Cin;
     const int grid = (int)((total + 63) / 64);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)workspace, dw, pl.nsplit,

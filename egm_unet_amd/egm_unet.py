@@ -31,6 +31,7 @@ class MCAGate(nn.Module):
         self.conv = nn.Conv2d(1, 1, kernel_size=(1, k_size), stride=1, padding=(0, (k_size - 1) // 2), bias=False)
         self.sigmoid = nn.Sigmoid()
         self.weight = nn.Parameter(torch.rand(2))
+        self.conv._egm_no_prepack = True
 
 
 class MCALayer(nn.Module):
@@ -110,6 +111,7 @@ class SpatialAttentionModule(nn.Module):
     def __init__(self, kernel_size=7):
         super().__init__()
         self.conv1 = nn.Conv2d(2, 1, kernel_size, padding=kernel_size // 2, bias=False)
+        self.conv1._egm_no_prepack = kernel_size == 7
         self.sigmoid = nn.Sigmoid()
 
     def logits(self, s, c_real):
@@ -132,6 +134,8 @@ class FusionConv(nn.Module):
         self.channel_attention = ChannelAttentionModule(dim)
         self.up = nn.Conv2d(dim, out_channels, kernel_size=1, stride=1)
         self._dim = dim
+        for m in (self.down, self.conv_3x3, self.conv_5x5, self.conv_7x7):
+            m._egm_no_prepack = True                            # consumed through fold2 / merge357
 
     def forward(self, x1, x2=None):
         """x2 is None (or x1 itself) == the reference call fusion_conv(concat, concat): cat([x, x]) is never built, the two
@@ -228,6 +232,7 @@ class RecursiveGatedAttention(nn.Module):
                                 groups=sum(self.split_sizes))
         self.proj_out = nn.Conv2d(self.split_sizes[-1], dim, 1)
         self.scale = nn.Parameter(torch.tensor(1.0))
+        self.dwconv._egm_no_prepack = True
         print(f"[RGA] order={order}, split_sizes={self.split_sizes}")
 
     def _gate(self, i, g):

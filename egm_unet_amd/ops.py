@@ -3,8 +3,10 @@
 Activations are NHWC tensors ``[N, H, W, C]`` (fp32 or bf16, C a multiple of 8, possibly a channel-slice view of a
 wider buffer).  torch is used for memory (torch.empty / views), streams and autograd bookkeeping only.
 """
+import struct
+
 import torch
-from torch.autograd import Function
+from torch.autograd import Function, Variable
 
 from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, dtype_code, lib, ptr, stream  # noqa: F401
 
@@ -86,6 +88,30 @@ def to_nchw(x_nhwc, C):
 
 
 # ----------------------------------------------------------------------------------------------------------
+# descriptor tables for the multi-tensor kernels
+# ----------------------------------------------------------------------------------------------------------
+class DeviceTable:
+    """Packed C structs on the device.  Re-uploaded only when the bytes change; the upload is an async copy from a pinned
+    staging buffer, so it is legal inside hipGraph capture (replays re-copy the same bytes)."""
+
+    def __init__(self):
+        self.key, self.pinned, self.device = None, None, None
+
+    def get(self, blob: bytes, device):
+        if blob == self.key:
+            return self.device
+        n = len(blob)
+        if self.pinned is None or self.pinned.numel() < n:
+            cap = max(n, 4096)
+            self.pinned = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            self.device = torch.empty(cap, dtype=torch.uint8, device=device)
+        self.pinned[:n] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        self.device[:n].copy_(self.pinned[:n], non_blocking=True)
+        self.key = blob
+        return self.device
+
+
+# ----------------------------------------------------------------------------------------------------------
 # convolution
 # ----------------------------------------------------------------------------------------------------------
 _pack_cache = {}
@@ -112,6 +138,67 @@ def _packed_weights(weight, groups, dtype):
     lib().call("egm_conv_pack", dtype_code(dtype), ptr(w), ptr(wf), ptr(wd), Cout, Cin, KH, KW, groups, stream())
     _pack_cache[id(weight)] = (key, wf, wd)
     return wf, wd
+
+
+def prepack_model(model, dtype):
+    """Pack every nn.Conv2d weight of `model` (except holders flagged _egm_no_prepack) in ONE kernel launch."""
+    st = getattr(model, "_egm_prepack", None)
+    if st is None or st["dtype"] != dtype:
+        convs = [m for m in model.modules() if isinstance(m, torch.nn.Conv2d) and not getattr(m, "_egm_no_prepack", False)
+                 and m.weight.dim() == 4 and m.weight.is_cuda]
+        bufs = []
+        for m in convs:
+            Cout, Cin_g, KH, KW = m.weight.shape
+            Cin = Cin_g * m.groups
+            bufs.append((torch.empty((KH * KW, pad8(Cout), pad8(Cin)), dtype=dtype, device=m.weight.device),
+                         torch.empty((KH * KW, pad8(Cin), pad8(Cout)), dtype=dtype, device=m.weight.device)))
+        st = model._egm_prepack = {"dtype": dtype, "convs": convs, "bufs": bufs, "table": DeviceTable(), "stamp": None}
+    convs, bufs = st["convs"], st["bufs"]
+    if not convs:
+        return
+    stamp = (_weight_generation[0], tuple(m.weight._version for m in convs), tuple(m.weight.data_ptr() for m in convs))
+    if stamp == st["stamp"]:
+        return
+    L = lib()
+    chunk = L.cdll.egm_conv_pack_chunk()
+    blob, chunks = bytearray(), 0
+    for m, (wf, wd) in zip(convs, bufs):
+        Cout, Cin_g, KH, KW = m.weight.shape
+        Cin = Cin_g * m.groups
+        blob += struct.pack("<QQQiiiiiiii", m.weight.data_ptr(), wf.data_ptr(), wd.data_ptr(), Cout, Cin, pad8(Cout), pad8(Cin), KH, KW,
+                            m.groups, 0)
+        chunks += (KH * KW * pad8(Cout) * pad8(Cin) + chunk - 1) // chunk
+    dev = convs[0].weight.device
+    table = st["table"].get(bytes(blob), dev)
+    L.call("egm_conv_pack_multi", dtype_code(dtype), ptr(table), len(convs), chunks, stream())
+    for m, (wf, wd) in zip(convs, bufs):
+        w = m.weight
+        key = (w.data_ptr(), w._version, _weight_generation[0], dtype, m.groups, tuple(w.shape))
+        _pack_cache[id(w)] = (key, wf, wd)
+    st["stamp"] = stamp
+
+
+# deferred weight-gradient reductions: the slab kernels run inside backward, ONE multi-conv reduce runs when backward ends
+_pending_wgrad = []
+_wgrad_table = DeviceTable()
+
+
+def _flush_wgrads():
+    if not _pending_wgrad:
+        return
+    blob, chunks = bytearray(), 0
+    for ws, weight, nslab, taps, CoutP, CinP, Cout, Cin, groups in _pending_wgrad:
+        # the gradient tensor returned from backward() was handed over to autograd (no reference kept here, so it is adopted
+        # as weight.grad without a copy); fill it now, in place
+        g = weight.grad
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != weight.shape:
+            raise RuntimeError("egm_unet_amd: deferred weight gradient lost its destination")
+        blob += struct.pack("<QQiiiiiiii", ws.data_ptr(), g.data_ptr(), nslab, taps, CoutP, CinP, Cout, Cin, groups, 0)
+        chunks += (taps * CoutP * CinP + 63) // 64
+    dev = _pending_wgrad[0][1].device
+    table = _wgrad_table.get(bytes(blob), dev)
+    lib().call("egm_wgrad_reduce_multi", ptr(table), len(_pending_wgrad), chunks, stream())
+    _pending_wgrad.clear()
 
 
 def _channel_sum(t):
@@ -173,8 +260,15 @@ class _Conv2d(Function):
             gw = torch.empty_like(weight)
             nbytes = L.query("egm_conv_wgrad_workspace", N, H, W, CinP, CoutP, KH, KW)
             ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=x.device)
-            L.call("egm_conv_wgrad", dt, ptr(x), ldx, ptr(gy), ldg, ptr(gw), ptr(ws), N, H, W, CinP, CoutP, Cin, Cout, KH, KW,
-                   dil, groups, 0, st)
+            # leaf parameter receiving its first gradient of this backward: defer the slab reduction to one multi-conv launch
+            defer = weight.is_leaf and weight.grad is None
+            L.call("egm_conv_wgrad", dt, ptr(x), ldx, ptr(gy), ldg, None if defer else ptr(gw), ptr(ws), N, H, W, CinP, CoutP, Cin, Cout,
+                   KH, KW, dil, groups, 0, st)
+            if defer:
+                nslab = L.query("egm_conv_wgrad_slabs", dt, N, H, W, CinP, CoutP, KH, KW, dil)
+                if not _pending_wgrad:
+                    Variable._execution_engine.queue_callback(_flush_wgrads)
+                _pending_wgrad.append((ws, weight, nslab, KH * KW, CoutP, CinP, Cout, Cin, groups))
         if has_bias and ctx.needs_input_grad[2]:
             gb = _f32(Cout, x.device, zero=True) if ctx.bias_grad_zero else _channel_sum(gy)[0, :Cout]
         return gx, gw, gb, None, None, None, None

@@ -95,6 +95,7 @@ class _SegNetBase(nn.Module):
             raise RuntimeError("egm_unet_amd models run on the GPU only: move the input (and the model) to cuda")
         if x.dim() != 4 or x.shape[1] != self.in_channels:
             raise RuntimeError(f"expected input [N,{self.in_channels},H,W], got {tuple(x.shape)}")
+        ops.prepack_model(self, self.compute_dtype)            # all conv weight packs in one launch
         return ops.to_nhwc(x, self.compute_dtype)
 
     def _exit(self, y) -> Dict[str, torch.Tensor]:

@@ -55,6 +55,11 @@ int egm_nhwc_to_nchw(int dtype, const void* src, int ld, void* dst_f32, int N, i
  *   wd [KH*KW][CinP][CoutP]  (data gradient: taps flipped, in/out swapped).  Either output may be NULL. */
 int egm_conv_pack(int dtype, const void* w_oihw_f32, void* wf, void* wd, int Cout, int Cin, int KH, int KW, int groups,
                   egm_stream_t s);
+/* Every conv weight of a model in one launch.  table_dev: device array of 56-byte entries
+ * {const float* w; void* wf; void* wd; int Cout, Cin, CoutP, CinP, KH, KW, groups, pad;}; total_chunks = sum over entries of
+ * ceil(KH*KW*CoutP*CinP / egm_conv_pack_chunk()). */
+int egm_conv_pack_chunk(void);
+int egm_conv_pack_multi(int dtype, const void* table_dev, int n, long long total_chunks, egm_stream_t s);
 /* y = conv(x, wf) (+bias).  Cin/Cout are the PADDED counts of wf.  bias (fp32, bias_n <= Cout valid entries; the rest count as 0) may be NULL.
  * stats, when non-NULL, receives per-pixel-tile partial sums [ntiles][2][Cout] of y and y*y
  * (consumed by egm_bn_finalize); egm_conv_stats_tiles() gives ntiles for the same dtype/shape/kernel.
@@ -69,6 +74,12 @@ long long egm_conv_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int K
 int egm_conv_wgrad(int dtype, const void* x, int ldx, const void* dy, int lddy, float* dw_oihw_f32, void* workspace,
                    int N, int H, int W, int Cin, int Cout, int CinR, int CoutR, int KH, int KW, int dil, int groups,
                    int accumulate, egm_stream_t s);
+/* Deferred form: egm_conv_wgrad with dw == NULL writes only the partial slabs (egm_conv_wgrad_slabs() of them) into the
+ * workspace; egm_wgrad_reduce_multi() then finishes MANY convolutions in one launch.  table_dev: device array of 48-byte
+ * entries {const float* slab; float* dw; int nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate;};
+ * total_chunks = sum over entries of ceil(taps*CoutP*CinP / 64). */
+int egm_conv_wgrad_slabs(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
+int egm_wgrad_reduce_multi(const void* table_dev, int n, long long total_chunks, egm_stream_t s);
 /* Depthwise 3x3 (RecursiveGatedAttention.dwconv, src/EGM-UNet.py:507-509): y = (dw3x3(x, w) + b) * scale.
  * w fp32 [C][1][3][3], b fp32 [C], scale fp32 [1] (device). */
 int egm_dwconv3_fwd(int dtype, const void* x, int ldx, const float* w, const float* b, const float* scale, void* y, int ldy,
