@@ -188,7 +188,15 @@ def main():
         step = eager_step
     else:
         from egm_unet_amd.graph import GraphedTrainStep
-        step = GraphedTrainStep(model, opt, x, t, lw, num_classes=2, ignore_index=255, reducer=reducer, warmup=2)
+        try:
+            step = GraphedTrainStep(model, opt, x, t, lw, num_classes=2, ignore_index=255, reducer=reducer, warmup=2)
+        except Exception as e:                                  # capture problems must not cost the measurement: go eager
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
+            torch.cuda.synchronize()
+            if reducer is not None:
+                reducer.hooks_enabled = True
+            args.eager = True
+            step = eager_step
 
     def fence():
         if world > 1:

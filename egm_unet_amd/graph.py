@@ -33,6 +33,8 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
+        if self.reducer is not None:
+            self.reducer.hooks_enabled = False       # no collectives inside the captured graph
         with torch.cuda.graph(self.graph):
             loss = criterion(self.model(self.x), self.t, self.lw, num_classes=self.nc, ignore_index=self.ign)
             loss.backward()

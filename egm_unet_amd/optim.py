@@ -16,6 +16,10 @@ class SGD(torch.optim.Optimizer):
         self.grad_source = None        # optional {param: fp32 tensor view} overriding p.grad (DDP buckets)
         self._tables = {}              # (group index, first) -> (key, pinned host table, device table)
 
+    @staticmethod
+    def _alloc_table(cap, dev):
+        return torch.empty((cap, 4), dtype=torch.int64).pin_memory(), torch.empty((cap, 4), dtype=torch.int64, device=dev)
+
     def _device_table(self, slot, rows, dev):
         """Pointer table on the device.  Re-uploaded only when a pointer changed; the upload is an async copy from a
         pinned staging buffer, so it is legal inside hipGraph capture (and replays re-copy the same bytes)."""
@@ -25,9 +29,7 @@ class SGD(torch.optim.Optimizer):
             return hit[2]
         n = len(rows)
         if hit is None or hit[1].shape[0] < n:
-            cap = max(n, 512)
-            pinned = torch.empty((cap, 4), dtype=torch.int64).pin_memory()
-            device = torch.empty((cap, 4), dtype=torch.int64, device=dev)
+            pinned, device = self._alloc_table(max(n, 512), dev)
         else:
             pinned, device = hit[1], hit[2]
         pinned[:n] = torch.tensor(rows, dtype=torch.int64)
@@ -39,6 +41,10 @@ class SGD(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         for gi, group in enumerate(self.param_groups):
+            for first in (True, False):           # staging buffers exist before any hipGraph capture can need them
+                if (gi, first) not in self._tables and group["params"]:
+                    cap = max(512, len(group["params"]))
+                    self._tables[(gi, first)] = (None,) + self._alloc_table(cap, group["params"][0].device)
             rows = {True: [], False: []}          # first-step parameters take v = g (no stale buffer read)
             keep = []
             for p in group["params"]:

@@ -60,10 +60,13 @@ class GradAllReducer:
         self.side = torch.cuda.Stream(device=dev) if (cuda and (use_side_stream is None or use_side_stream)) else None
         self._pending = [len(ps) for ps in self.buckets]
         self._works, self._keep = [], []
+        self.hooks_enabled = True            # switched off while a fwd+bwd hipGraph is being captured
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for _, p in named]
 
     # ---- called by autograd as each parameter's gradient lands
     def _on_grad(self, p):
+        if not self.hooks_enabled:
+            return
         b = self.bucket_of[p]
         self._pending[b] -= 1
         if self._pending[b] == 0:

@@ -160,3 +160,29 @@ def test_egm_train3_trace_fp32():
             rel = float((sd[k[6:]].cpu().double() - ref).norm() / (ref.norm() + 1e-12))
             print(k, "rel-L2 after 3 steps:", rel)
             assert rel < 5e-3, (k, rel)
+
+
+def test_graphed_train_step_matches_reference_trace():
+    """hipGraph replay of the whole step (what bench.py times) reproduces the reference's 3-step loss trace:
+    step 0 runs eagerly as the capture warm-up, steps 1-2 are graph replays with new batches copied into the static buffers."""
+    from egm_unet_amd import GRFBUNet
+    from egm_unet_amd.graph import GraphedTrainStep
+    from egm_unet_amd.optim import SGD
+    fx = load_fixture("train3_egm_b8")
+    m = GRFBUNet(3, 2, base_c=8)
+    load_module_state(m, fx, group="init")
+    m.to(DEV).train()
+    opt = SGD(m.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+    lw = torch.tensor([1.0, 2.0], device=DEV)
+    xs, ts = torch.from_numpy(fx["xs"]).to(DEV), torch.from_numpy(fx["ts"]).to(DEV)
+    step = GraphedTrainStep(m, opt, xs[0], ts[0], lw, num_classes=2, ignore_index=255, warmup=1)
+    for s in (1, 2):
+        loss = float(step(xs[s], ts[s]))
+        assert abs(loss - fx["losses"][s]) <= 5e-4 * abs(fx["losses"][s]), (s, loss, fx["losses"][s])
+    sd = m.state_dict()
+    for k, v in fx.items():
+        if k.startswith("final/"):
+            ref = torch.from_numpy(v).double()
+            rel = float((sd[k[6:]].cpu().double() - ref).norm() / (ref.norm() + 1e-12))
+            assert rel < 5e-3, (k, rel)
+    assert int(sd["in_conv.1.num_batches_tracked"]) == 3

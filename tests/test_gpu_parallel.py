@@ -1,0 +1,69 @@
+"""GPU: the bucketed gradient exchange with the real HIP gather kernel and side stream, 2 ranks sharing cuda:0 over gloo
+(the 1-GPU test box cannot host two RCCL ranks; RCCL itself is exercised by bench.py --gpus N on a multi-GPU node)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q, graphed=False):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from egm_unet_amd import UNet
+    from egm_unet_amd.optim import SGD
+    from egm_unet_amd.parallel import GradAllReducer
+    from egm_unet_amd.train_utils import criterion
+    torch.manual_seed(0)
+    m = UNet(3, 2, base_c=8).to("cuda").train()
+    red = GradAllReducer(m, world_size=world)
+    assert len(red.buckets) == 2
+    opt = SGD(m.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+    opt.grad_scale = 1.0 / world
+    g = torch.Generator().manual_seed(50 + rank)
+    x = torch.randn(2, 3, 32, 32, generator=g).cuda()
+    t = torch.randint(0, 2, (2, 32, 32), generator=g).cuda()
+    lw = torch.tensor([1.0, 2.0], device="cuda")
+    if graphed:
+        from egm_unet_amd.graph import GraphedTrainStep
+        step = GraphedTrainStep(m, opt, x, t, lw, num_classes=2, ignore_index=255, reducer=red, warmup=1)
+        for _ in range(2):
+            step()
+    else:
+        for _ in range(2):
+            loss = criterion(m(x), t, lw, num_classes=2, ignore_index=255)
+            opt.zero_grad()
+            loss.backward()
+            opt.grad_source = red.finish()
+            opt.step()
+    torch.cuda.synchronize()
+    probe = {k: v.detach().float().cpu().numpy().tolist() for k, v in m.state_dict().items() if k in ("in_conv.0.weight", "out_conv.0.bias")}
+    # the averaged gradient of rank-local batches must be identical on both ranks after the all-reduce
+    q.put((rank, probe))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_two_ranks_stay_in_sync(graphed):
+    world, port = 2, 29671 + int(graphed)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, graphed)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for k in res[0]:
+        a, b = torch.tensor(res[0][k]), torch.tensor(res[1][k])
+        assert torch.allclose(a, b, rtol=0, atol=0), k          # bitwise: same reduced gradients, same update
