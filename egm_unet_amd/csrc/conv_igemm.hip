@@ -391,11 +391,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvParams p, i
         }
         const bool last_of_item = !nxt.valid || nxt.pt != cur.pt;
         if (last_of_item) {
-            __syncthreads();                                  // everyone done reading patch/weights: reuse LDS as out tiles
-            unsigned char* ot = smem + wv * 64 * OROW;        // wave-private 64 px x NT*32 couts
+            __syncthreads();                                  // everyone done reading the patch: reuse it as out tiles
+            // The out tiles live strictly inside the PATCH region (4 waves x 32 px x OROW <= patch bytes for every window),
+            // never over the weights: weights that are staged once per workgroup must survive every epilogue.
+            unsigned char* ot = smem + wv * 32 * OROW;        // wave-private 32 px x NT*32 couts, one tile row at a time
+            const int cv = lane % NV, slot = lane / NV;
             // D layout: col (pixel) = lane&31, row (cout) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 2; ++m) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -403,25 +406,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvParams p, i
                         uint2 pk;
                         pk.x = (uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 0]) | ((uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 1]) << 16);
                         pk.y = (uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 2]) | ((uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 3]) << 16);
-                        *reinterpret_cast<uint2*>(ot + (m * 32 + r31) * OROW + (nt * 32 + gq * 8 + h * 4) * 2) = pk;
+                        *reinterpret_cast<uint2*>(ot + r31 * OROW + (nt * 32 + gq * 8 + h * 4) * 2) = pk;
                     }
-            // read back whole channel vectors (same wave: LDS ops of one wave complete in order) and store coalesced
-            const int cv = lane % NV, slot = lane / NV;
+                // read back whole channel vectors (same wave: its LDS ops complete in order) and store coalesced
+                const int oy = cur.oy0 + 2 * wv + m;
 #pragma unroll
-            for (int it = 0; it < NV; ++it) {                 // 64 pixels / (64/NV lanes-slots) = NV iterations
-                const int pl = it * (64 / NV) + slot;         // pixel within the wave's 2x32 rows
-                const int oy = cur.oy0 + 2 * wv + (pl >> 5), ox = cur.ox0 + (pl & 31);
-                const int co = co0 + cv * 8;
-                float v[8];
-                load8(reinterpret_cast<const bf16_t*>(ot + pl * OROW + cv * 16), v);
-                if (oy < p.H && ox < p.W && co < p.Cout) {
-                    if (p.bias != nullptr) {
+                for (int it = 0; it < NV / 2; ++it) {         // 32 pixels / (64/NV pixel slots)
+                    const int pl = it * (64 / NV) + slot;
+                    const int ox = cur.ox0 + pl;
+                    const int co = co0 + cv * 8;
+                    float v[8];
+                    load8(reinterpret_cast<const bf16_t*>(ot + pl * OROW + cv * 16), v);
+                    if (oy < p.H && ox < p.W && co < p.Cout) {
+                        if (p.bias != nullptr) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<bf16_t>(v[j] + bias8[j]));
+                            for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<bf16_t>(v[j] + bias8[j]));
+                        }
+                        store8(yg + ((long long)(cur.n * p.H + oy) * p.W + ox) * p.ldy + co, v);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
                     }
-                    store8(yg + ((long long)(cur.n * p.H + oy) * p.W + ox) * p.ldy + co, v);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
                 }
             }
         }
@@ -561,8 +565,7 @@ int launch_pipe(ConvParams& p, hipStream_t st) {
     }
     p.patch_bytes = (Gm::PH * Gm::PW * 80 + 15) / 16 * 16;
     size_t smem = (size_t)p.patch_bytes + (size_t)Gm::NTAPS * NT * 32 * 80;
-    const size_t otile = (size_t)4 * 64 * (NT * 64 + 16);
-    if (smem < otile) smem = otile;
+    static_assert((size_t)4 * 32 * (NT * 64 + 16) <= (size_t)Gm::PH * Gm::PW * 80, "epilogue out tiles must fit inside the patch region");
     const int G = pipe_groups(p.npt, p.nct);
     const int grid = ((G + 7) / 8) * 8 * p.nct;
     hipLaunchKernelGGL((conv_igemm_pipe_kernel<NT, WH, WW>), dim3(grid), dim3(256), smem, st, p, G);

@@ -69,6 +69,12 @@ CONV_CASES = [
     (2, 18, 18, 64, 3, 3, 1, 1, True),       # target_enhancer
     (2, 10, 10, 2, 1, 7, 1, 1, False),       # spatial attention
     (1, 64, 64, 128, 256, 3, 1, 1, False),   # wide
+    # more pixel tiles than resident workgroups: every workgroup of the persistent kernel walks several tiles
+    (4, 256, 256, 32, 64, 3, 1, 1, False),   # weights staged once (single chunk), 64-cout tiles
+    (3, 256, 256, 64, 64, 3, 1, 1, True),    # two chunks per tile
+    (5, 256, 256, 32, 32, 1, 1, 1, True),    # 1x1
+    (3, 256, 256, 16, 16, 3, 12, 1, False),  # dilated, several tiles per workgroup
+    (3, 256, 256, 16, 16, 7, 1, 1, True),    # 7x7 by kernel rows
 ]
 
 
