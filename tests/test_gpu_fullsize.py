@@ -143,3 +143,45 @@ def test_evaluate_entry_point():
     assert confmat.mat.shape == (2, 2) and int(confmat.mat.sum()) == int(sum((t != 255).sum() for _, t in loader))
     assert 0.0 <= dice <= 1.0
     assert "mean IoU" in str(confmat)
+
+
+def test_fullsize_train_step_fp32_vs_oracle(big_model):
+    """One 512x512 image through EGM-UNet(3,2,32) in train mode: HIP fp32 path vs the CPU oracle.
+    Logits/loss are compared with the fp32 oracle (the reference's own arithmetic).  Gradients of this badly conditioned
+    problem (batch-1 BatchNorm, |loss| ~ 1e2) carry ~5e-3 fp32 rounding noise in the reference itself, so they are judged
+    against the oracle run in float64: the HIP fp32 path must be as close to that truth as the fp32 CPU path is."""
+    import copy
+    from oracle import egm_ref as R, loss_ref as L
+    x, t = synth(1, 512, 512, 5)
+    sd0 = copy.deepcopy(big_model.state_dict())
+    lw = torch.tensor([1.0, 2.0])
+    res = {}
+    for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        work = {k: (v.detach().cpu().clone().to(dt) if v.is_floating_point() else v.detach().cpu().clone()) for k, v in sd0.items()}
+        for k, v in work.items():
+            if v.is_floating_point() and "running_" not in k:
+                v.requires_grad_(True)
+        out_r = R.egm_unet_forward(work, x.to(dt), True)["out"]
+        loss_r = L.criterion({"out": out_r}, t, lw.to(dt), num_classes=2, ignore_index=255)
+        loss_r.backward()
+        res[name] = (out_r.detach(), float(loss_r.detach()), {k: v.grad.double() for k, v in work.items() if v.is_floating_point() and v.grad is not None})
+    ref_out, ref_loss = res["f32"][0], res["f32"][1]
+    out, loss, grads = _train_step_outputs(big_model, x.to(DEV), t.to(DEV), torch.float32)
+    assert_close(out.cpu(), ref_out, rtol=1e-3, atol=2e-4, what="fp32 train logits")
+    # masks: identical except where the reference's own class margin is below the fp32 agreement level (numerical ties)
+    mism = out.argmax(1).cpu() != ref_out.argmax(1)
+    margin = (ref_out[:, 0] - ref_out[:, 1]).abs()
+    assert int(mism.sum()) <= 1e-4 * mism.numel() and (not mism.any() or float(margin[mism].max()) < 2e-4), \
+        (int(mism.sum()), float(margin[mism].max()) if mism.any() else 0.0)
+    assert abs(float(loss) - ref_loss) <= 1e-5 * abs(ref_loss)
+    hip_err, cpu_err = [], []
+    for k, r in res["f64"][2].items():
+        n = float(r.norm())
+        if n > 1e-6:
+            hip_err.append(float((grads[k].cpu().double() - r).norm()) / n)
+            cpu_err.append(float((res["f32"][2][k] - r).norm()) / n)
+    hip_err.sort(); cpu_err.sort()
+    med_h, med_c = hip_err[len(hip_err) // 2], cpu_err[len(cpu_err) // 2]
+    print(f"gradient rel-L2 error vs float64 oracle: HIP fp32 median {med_h:.2e} max {hip_err[-1]:.2e}; CPU fp32 median {med_c:.2e} max {cpu_err[-1]:.2e}")
+    assert med_h <= 2.0 * med_c + 1e-4 and hip_err[-1] <= 2.0 * cpu_err[-1] + 1e-2, (med_h, med_c, hip_err[-1], cpu_err[-1])
+    big_model.load_state_dict(sd0)
