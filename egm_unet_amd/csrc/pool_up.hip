@@ -354,6 +354,30 @@ __global__ void axpby_kernel(const T* __restrict__ a, int lda, float alpha, cons
         store8(out + p * ldo + cv * 8, v);
     }
 }
+// out = a + b + c (+ d): gradient fan-in of a tensor with 3-4 consumers in ONE pass
+template <typename T>
+__global__ void sum4_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b, int ldb, const T* __restrict__ c, int ldc,
+                            const T* __restrict__ d, int ldd, T* __restrict__ out, int ldo, long long npix, int C) {
+    const int ncv = C >> 3;
+    const long long total = npix * ncv;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        float v[8], u[8];
+        load8(a + p * lda + cv * 8, v);
+        load8(b + p * ldb + cv * 8, u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += u[j];
+        load8(c + p * ldc + cv * 8, u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += u[j];
+        if (d != nullptr) {
+            load8(d + p * ldd + cv * 8, u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += u[j];
+        }
+        store8(out + p * ldo + cv * 8, v);
+    }
+}
 __global__ void vec_add_f32_kernel(float* __restrict__ y, const float* __restrict__ x, long long n) {
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] += x[i];
 }
@@ -489,6 +513,16 @@ extern "C" int egm_axpby(int dtype, const void* a, int lda, float alpha, const v
     EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((axpby_kernel<T>), dim3(stream_grid(npix * (C / 8))), dim3(256), 0, (hipStream_t)s,
                                                  (const T*)a, lda, alpha, (const T*)b, ldb, beta, (T*)out, ldo, npix, C));
     EGM_CHECK_LAUNCH("axpby");
+    return EGM_OK;
+}
+extern "C" int egm_sum4(int dtype, const void* a, int lda, const void* b, int ldb, const void* c, int ldc, const void* d, int ldd, void* out,
+                        int ldo, long long npix, int C, egm_stream_t s) {
+    EGM_REQ_VEC("sum4", a, lda, C); EGM_REQ_VEC("sum4", b, ldb, C); EGM_REQ_VEC("sum4", c, ldc, C); EGM_REQ_VEC("sum4", out, ldo, C);
+    if (d) EGM_REQ_VEC("sum4", d, ldd, C);
+    EGM_REQUIRE(npix > 0, "sum4: bad npix");
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sum4_kernel<T>), dim3(stream_grid(npix * (C / 8))), dim3(256), 0, (hipStream_t)s, (const T*)a,
+                                                 lda, (const T*)b, ldb, (const T*)c, ldc, (const T*)d, ldd, (T*)out, ldo, npix, C));
+    EGM_CHECK_LAUNCH("sum4");
     return EGM_OK;
 }
 extern "C" int egm_vec_add_f32(float* y, const float* x, long long n, egm_stream_t s) {

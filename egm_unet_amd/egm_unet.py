@@ -61,8 +61,9 @@ class EdgeAwareFeatureEnhancer(nn.Module):
         self.weight_generator = nn.Sequential(nn.Conv2d(in_channels, in_channels, kernel_size=1), nn.BatchNorm2d(in_channels),
                                               nn.Sigmoid())
 
-    def forward(self, x):
-        xa, xb = ops.fork(x, 2)
+    def forward(self, x, x_alias=None):
+        """x_alias: a second autograd alias of x supplied by the caller (so the caller can sum all of x's gradients in one pass)."""
+        xa, xb = (x, x_alias) if x_alias is not None else ops.fork(x, 2)
         e = ops.highpass3(xa)                                                   # x - avgpool3(x)
         w = ops.conv_bn_act(e, self.weight_generator[0], self.weight_generator[1], ACT_SIGMOID)
         return ops.gate_mul(xb, w)                                              # w*x + x
@@ -188,8 +189,8 @@ class EdgeEnhancedGRFB(nn.Module):
         self.target_enhancer = nn.Sequential(nn.Conv2d(out_channels, 3, 3, padding=1), nn.Sigmoid())
 
     def forward(self, x):
-        x_e, x_cat, x_sc = ops.fork(x, 3)
-        xe = self.edge_enhancer(x_e)
+        x_e, x_e2, x_cat, x_sc = ops.fork(x, 4)
+        xe = self.edge_enhancer(x_e, x_e2)
         xe_d, xe_e, xe_c = ops.fork(xe, 3)
         d = self.branch_dir(xe_d)
         e = self.branch_edge(xe_e)

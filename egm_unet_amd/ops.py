@@ -463,8 +463,19 @@ class _Fork(Function):
         if not gs:
             return None, None
         acc = gs[0]
-        for g in gs[1:]:
-            acc = _axpby(acc, 1.0, g, 1.0)
+        rest = gs[1:]
+        while rest:
+            if len(rest) >= 2:                          # 3-4 gradients summed in one pass
+                take, rest = rest[:3], rest[3:]
+                ts = [_nhwc(t) for t in [acc] + take]
+                out = torch.empty(ts[0][0].shape, dtype=ts[0][0].dtype, device=ts[0][0].device)
+                d = ts[3] if len(ts) > 3 else (None, 0)
+                lib().call("egm_sum4", dtype_code(out.dtype), ptr(ts[0][0]), ts[0][1], ptr(ts[1][0]), ts[1][1], ptr(ts[2][0]), ts[2][1],
+                           ptr(d[0]), d[1], ptr(out), out.shape[3], _npix(out), out.shape[3], stream())
+                acc = out
+            else:
+                acc = _axpby(acc, 1.0, rest[0], 1.0)
+                rest = rest[1:]
         return acc, None
 
 

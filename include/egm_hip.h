@@ -143,6 +143,9 @@ int egm_upcat_bwd_low(int dtype, const void* dout, int ldo, void* dlow, int ldl,
 /* out = alpha*a + beta*b (b may be NULL) */
 int egm_axpby(int dtype, const void* a, int lda, float alpha, const void* b, int ldb, float beta, void* out, int ldo,
               long long npix, int C, egm_stream_t s);
+/* out = a + b + c (+ d when non-NULL): gradient fan-in of a tensor with 3-4 consumers in one pass */
+int egm_sum4(int dtype, const void* a, int lda, const void* b, int ldb, const void* c, int ldc, const void* d, int ldd, void* out,
+             int ldo, long long npix, int C, egm_stream_t s);
 /* fp32 vector add: y[i] += x[i] (parameter-gradient accumulation) */
 int egm_vec_add_f32(float* y, const float* x, long long n, egm_stream_t s);
 int egm_fill_f32(float* y, float v, long long n, egm_stream_t s);
