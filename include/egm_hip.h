@@ -251,6 +251,42 @@ int egm_mca_bwd_dxo(int dtype, const unsigned char* codes, const void* g, int ld
 int egm_mca_bwd_dx(int dtype, const void* dxo, int ldd, const void* x, int ldx, const float* gates, const float* coef, void* dx,
                    int ldo, int N, int H, int W, int C, egm_stream_t s);
 
+/* ---- CLIP ViT / CLIPSeg inference path (clip/model.py:159-206,487-501; models/clipseg.py:79-133,188-256,436-496) --------
+ * Activations are row-major [rows, D] token matrices (batch-first), bf16 or fp32; scores and statistics are fp32. */
+/* Batched GEMM with fused epilogue: C[b] = act(alpha * A[b](M x K) * op(B[b]) + bias) + R[b].
+ * transB != 0: B[b] is [N][K] (nn.Linear weight, K of q k^T); else [K][N] (V of P V, `x @ proj`).  Two batch levels
+ * (nb1 x nb2, e.g. images x heads) with element strides s?1 / s?2.  act: 0 none, 1 ReLU, 2 QuickGELU.
+ * c_is_f32 != 0 stores C as fp32 (attention scores).  bias fp32 [N] or NULL; R (dtype, ldr) or NULL. */
+int egm_gemm(int dtype, const void* A, int lda, const void* B, int ldb, int transB, void* C, int ldc, int c_is_f32,
+             const float* bias, int act, const void* R, int ldr, float alpha, int M, int N, int K, int nb1, int nb2,
+             long long sA1, long long sA2, long long sB1, long long sB2, long long sC1, long long sC2, long long sR1,
+             long long sR2, egm_stream_t s);
+/* P[r][:] (dtype) = softmax(S[r][:L]) (S fp32); causal != 0 keeps columns j <= r % L (text encoder mask,
+ * clip/model.py:462-468); accumulate != 0 adds to P (CSA: softmax(q q^T) + softmax(k k^T), models/clipseg.py:96-102).
+ * Columns L..ldp-1 of P are written as 0. */
+int egm_softmax_rows(int dtype, const float* S, int lds, void* P, int ldp, long long rows, int L, int causal, int accumulate,
+                     egm_stream_t s);
+/* LayerNorm over the last dimension with fp32 statistics (clip/model.py:159-165). */
+int egm_layernorm(int dtype, const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy,
+                  long long rows, int D, egm_stream_t s);
+/* VisionTransformer.conv1 front half: fp32 NCHW image -> patch rows [B*(H/P)*(W/P)][C*P*P] (then egm_gemm with conv1.weight). */
+int egm_patchify(int dtype, const float* img_nchw, void* out, int B, int C, int H, int W, int P, egm_stream_t s);
+/* x[b][0] = class_embedding + pos[0]; x[b][1+t] = tok[b][t] + pos[1+t]  (models/clipseg.py:205-213) */
+int egm_vit_assemble(int dtype, const void* tok, const float* cls, const float* pos, void* x, int B, int Ltok, int D, egm_stream_t s);
+/* x[n][t] = token_embedding[tokens[n][t]] + (t < split ? pos[t] : pos_res[t])  (clip/model.py:428-431,488-490; split = 20) */
+int egm_text_embed(int dtype, const int* tokens, const float* emb, const float* pos, const float* pos_res, int split, void* x,
+                   int n, int L, int D, egm_stream_t s);
+/* FiLM: a[b][t][:] = a[b][t][:] * mul[b][:] + add[b][:]  (models/clipseg.py:467-471) */
+int egm_film(int dtype, void* a, const void* mul, const void* add, int B, int L, int D, egm_stream_t s);
+/* out[n][:] = x[n][idx[n]][:]  (EOT token / class token selection) */
+int egm_gather_rows(int dtype, const void* x, const int* idx, void* out, int n, int L, int D, egm_stream_t s);
+/* ConvTranspose2d(D -> 1, kernel P, stride P) back half: y[b*Ltot + tok_off + ty*g + tx][i*P + j] (+ bias) ->
+ * out fp32 [B][1][g*P][g*P]  (models/clipseg.py:478-484) */
+int egm_pixel_shuffle(int dtype, const void* y, int ldy, int tok_off, int Ltot, const float* bias, float* out, int B, int g,
+                      int P, egm_stream_t s);
+/* fp32 -> dtype copy of a weight matrix */
+int egm_cast_f32(int dtype, const float* src, void* dst, long long n, egm_stream_t s);
+
 /* ---- criterion, metrics, optimizer --------------------------------------------------------------
  * criterion(): train_utils/train_and_eval.py:7-19 + dice_coefficient_loss.py:7-108 (five terms; reference quirks kept:
  * stencils on raw logit channel 0 against the label map of sample 0).  logits/dlogits fp32 NCHW, target int64 [N,H,W].
