@@ -134,6 +134,34 @@ def cpu_baseline(seconds_budget=25.0):
             "sample": f"{len(times)} train steps (fwd+loss+bwd+SGD) of EGM-UNet(3,2,32) at bs 2x3x512x512 fp32 on the CPU oracle; best of steps after the first"}
 
 
+def clipseg_bench(args, dev, rank, world):
+    """BASELINE.json configs[3]: CLIPDensePredT('ViT-B/16', reduce_dim=64) forward on 352x352, synthetic fp16-rounded weights,
+    prompts encoded per call (uncached), bf16.  Replicas only (frozen backbone, no exchange)."""
+    from oracle import clip_ref as C                      # seeded synthetic weights (the reference ships none)
+    from egm_unet_amd.clipseg import CLIPDensePredT
+    m = CLIPDensePredT(version="ViT-B/16", reduce_dim=64)
+    m.clip_model.load_state_dict(C.make_clip_state(seed=0))
+    m.load_state_dict(C.make_decoder_state(seed=0), strict=False)
+    m.to(dev).eval().set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    B = args.batch if args.batch != 8 else 32             # experiments/phrasecut.yaml batch size
+    x = torch.randn(B, 3, 352, 352, generator=torch.Generator().manual_seed(rank)).to(dev)
+    prompts = ["a photo of a tactile paving."] * B
+    for _ in range(args.warmup):
+        m(x, prompts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m(x, prompts)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": "CLIPSeg inference images/sec at 3x352x352", "value": round(B * world * args.steps / el, 2), "unit": "images/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                          "config": {"workload": f"CLIPDensePredT ViT-B/16 rd64 forward, {B}x3x352x352 + {B} prompts (text encoder uncached)",
+                                     "global_batch": B * world, "parallelism": f"replicas x{world}"}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +171,9 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="egm_unet_train", choices=["egm_unet_train", "clipseg_infer"],
+                    help="egm_unet_train = the headline metric (BASELINE.json configs[1]); clipseg_infer = configs[3] (ViT-B/16 image+text "
+                         "encode + decoder on 352x352), reported as a secondary line")
     ap.add_argument("--eager", action="store_true", help="issue every kernel from Python instead of replaying the captured hipGraph")
     args = ap.parse_args()
 
@@ -159,6 +190,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.workload == "clipseg_infer":
+        return clipseg_bench(args, dev, rank, world)
     from egm_unet_amd import GRFBUNet
     from egm_unet_amd._lib import lib, require_gpu
     from egm_unet_amd.optim import SGD
