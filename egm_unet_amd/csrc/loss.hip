@@ -280,6 +280,84 @@ __global__ void metrics_finalize_kernel(const unsigned long long* __restrict__ h
     }
 }
 
+
+// ---- CLIPSeg (+) UNet ensemble tail (predict_CLIPseg.py:501-525, eval_CLIPseg.py:656-723) ------------------------------------
+// fused = bilinear(clip_logits -> HxW, align_corners=False) + alpha * unet_logits ; prediction = argmax_c fused.
+// One lane per output pixel; the alpha grid search evaluates every alpha of the grid in the same pass and accumulates one
+// confusion matrix per alpha (LDS pre-aggregation, integer atomics).
+__device__ __forceinline__ void bilin_src(int dst, int in_size, int out_size, int& i0, int& i1, float& w1) {
+    const float scale = (float)in_size / (float)out_size;
+    float src = ((float)dst + 0.5f) * scale - 0.5f;            // torch area_pixel_compute_source_index, align_corners=False
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src; if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    w1 = src - (float)i0;
+}
+__device__ __forceinline__ float bilin_at(const float* __restrict__ m, int wc, int y0, int y1, float wy, int x0, int x1, float wx) {
+    const float a = m[(long long)y0 * wc + x0], b = m[(long long)y0 * wc + x1], c = m[(long long)y1 * wc + x0], d = m[(long long)y1 * wc + x1];
+    return (1.f - wy) * ((1.f - wx) * a + wx * b) + wy * ((1.f - wx) * c + wx * d);
+}
+// pred[n][y][x] = argmax_c (up(clip)[n][c] + alpha * unet[n][c]); fused (optional) receives the fused logits
+__global__ void ensemble_fuse_kernel(const float* __restrict__ clip, const float* __restrict__ unet, float alpha, int N, int C, int hc, int wc,
+                                     int H, int W, long long* __restrict__ pred, float* __restrict__ fused) {
+    const long long HW = (long long)H * W, total = (long long)N * HW;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)((i / W) % H), n = (int)(i / HW);
+        int y0, y1, x0, x1; float wy, wx;
+        bilin_src(y, hc, H, y0, y1, wy); bilin_src(x, wc, W, x0, x1, wx);
+        int best = 0; float m = -INFINITY;
+        for (int c = 0; c < C; ++c) {
+            const float v = bilin_at(clip + ((long long)n * C + c) * hc * wc, wc, y0, y1, wy, x0, x1, wx) + alpha * unet[((long long)n * C + c) * HW + (i - n * HW)];
+            if (fused) fused[((long long)n * C + c) * HW + (i - n * HW)] = v;
+            if (v > m) { m = v; best = c; }
+        }
+        if (pred) pred[i] = best;
+    }
+}
+// hist[a][t][p] += 1 for every alpha a of the grid (C <= 4, na <= 128)
+__global__ __launch_bounds__(256) void ensemble_alpha_hist_kernel(const float* __restrict__ clip, const float* __restrict__ unet,
+                                                                  const long long* __restrict__ target, const float* __restrict__ alphas, int na,
+                                                                  int N, int C, int hc, int wc, int H, int W,
+                                                                  unsigned long long* __restrict__ hist) {
+    extern __shared__ unsigned int lh[];                         // [na][C][C]
+    for (int i = threadIdx.x; i < na * C * C; i += 256) lh[i] = 0;
+    __syncthreads();
+    const long long HW = (long long)H * W, total = (long long)N * HW;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)((i / W) % H), n = (int)(i / HW);
+        const long long t = target[i];
+        if (t < 0 || t >= C) continue;
+        int y0, y1, x0, x1; float wy, wx;
+        bilin_src(y, hc, H, y0, y1, wy); bilin_src(x, wc, W, x0, x1, wx);
+        float cv[4], uv[4];
+        for (int c = 0; c < C; ++c) {
+            cv[c] = bilin_at(clip + ((long long)n * C + c) * hc * wc, wc, y0, y1, wy, x0, x1, wx);
+            uv[c] = unet[((long long)n * C + c) * HW + (i - n * HW)];
+        }
+        for (int a = 0; a < na; ++a) {
+            const float al = alphas[a];
+            int best = 0; float m = cv[0] + al * uv[0];
+            for (int c = 1; c < C; ++c) { const float v = cv[c] + al * uv[c]; if (v > m) { m = v; best = c; } }
+            atomicAdd(&lh[(a * C + (int)t) * C + best], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < na * C * C; i += 256) if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+}
+// miou[a] = mean_c IoU_c of hist[a]  (ConfusionMatrix.compute, float arithmetic as the reference)
+__global__ void ensemble_miou_kernel(const unsigned long long* __restrict__ hist, int na, int C, float* __restrict__ miou) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= na) return;
+    float acc = 0.f;
+    for (int i = 0; i < C; ++i) {
+        float row = 0.f, col = 0.f;
+        for (int j = 0; j < C; ++j) { row += (float)hist[(a * C + i) * C + j]; col += (float)hist[(a * C + j) * C + i]; }
+        const float dg = (float)hist[(a * C + i) * C + i];
+        acc += dg / (row + col - dg);
+    }
+    miou[a] = acc / (float)C;
+}
+
 // ---- fused multi-tensor SGD -----------------------------------------------------------------------------
 struct SgdEntry { float* p; const float* g; float* buf; long long n; };
 constexpr int kSgdChunk = 2048;                               // elements per block (8 per thread)
@@ -392,5 +470,33 @@ extern "C" int egm_copy_multi(const void* table_dev, int ntensors, egm_stream_t 
     EGM_REQUIRE(table_dev && ntensors > 0, "copy_multi: bad args");
     hipLaunchKernelGGL(copy_multi_kernel, dim3(16, ntensors), dim3(256), 0, (hipStream_t)s, (const CopyEntry*)table_dev);
     EGM_CHECK_LAUNCH("copy_multi");
+    return EGM_OK;
+}
+
+extern "C" int egm_ensemble_fuse(const float* clip_logits, const float* unet_logits, float alpha, int N, int C, int hc, int wc, int H, int W,
+                                 long long* pred, float* fused, egm_stream_t s) {
+    EGM_REQUIRE(clip_logits && unet_logits && (pred || fused) && N > 0 && C > 0 && hc > 0 && wc > 0 && H > 0 && W > 0, "ensemble_fuse: bad args");
+    const long long total = (long long)N * H * W;
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(ensemble_fuse_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, clip_logits, unet_logits, alpha, N, C, hc, wc, H, W, pred, fused);
+    EGM_CHECK_LAUNCH("ensemble_fuse");
+    return EGM_OK;
+}
+/* hist: zeroed [na][C][C] uint64 (accumulates across calls = across images); miou: fp32 [na] */
+extern "C" int egm_ensemble_alpha_hist(const float* clip_logits, const float* unet_logits, const long long* target, const float* alphas, int na,
+                                       int N, int C, int hc, int wc, int H, int W, unsigned long long* hist, egm_stream_t s) {
+    EGM_REQUIRE(clip_logits && unet_logits && target && alphas && hist, "ensemble_alpha_hist: null pointer");
+    EGM_REQUIRE(na > 0 && na <= 128 && C > 0 && C <= 4 && N > 0 && hc > 0 && wc > 0 && H > 0 && W > 0, "ensemble_alpha_hist: bad shape (na<=128, C<=4)");
+    const long long total = (long long)N * H * W;
+    int grid = (int)((total + 255) / 256); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(ensemble_alpha_hist_kernel, dim3(grid), dim3(256), (size_t)na * C * C * sizeof(unsigned int), (hipStream_t)s, clip_logits,
+                       unet_logits, target, alphas, na, N, C, hc, wc, H, W, hist);
+    EGM_CHECK_LAUNCH("ensemble_alpha_hist");
+    return EGM_OK;
+}
+extern "C" int egm_ensemble_miou(const unsigned long long* hist, int na, int C, float* miou, egm_stream_t s) {
+    EGM_REQUIRE(hist && miou && na > 0 && C > 0, "ensemble_miou: bad args");
+    hipLaunchKernelGGL(ensemble_miou_kernel, dim3((na + 63) / 64), dim3(64), 0, (hipStream_t)s, hist, na, C, miou);
+    EGM_CHECK_LAUNCH("ensemble_miou");
     return EGM_OK;
 }

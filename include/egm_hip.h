@@ -306,6 +306,15 @@ int egm_argmax_hist(const float* logits, const long long* target, int N, int C, 
 /* out[2+2C] = {dice (classes 1.., mean over images), acc_global, acc[C], iu[C]} (distributed_utils.py:97-105,147-151) */
 int egm_metrics_finalize(const unsigned long long* hist, const unsigned long long* counts, int N, int C, float* out,
                          egm_stream_t s);
+/* CLIPSeg (+) UNet ensemble tail (predict_CLIPseg.py:501-525): fused = bilinear(clip_logits -> HxW, align_corners=False) +
+ * alpha*unet_logits; pred (int64 [N,H,W], optional) = argmax_c fused; fused (fp32 [N,C,H,W], optional). */
+int egm_ensemble_fuse(const float* clip_logits, const float* unet_logits, float alpha, int N, int C, int hc, int wc, int H, int W,
+                      long long* pred, float* fused, egm_stream_t s);
+/* Alpha grid search (eval_CLIPseg.py:656-723): one pass accumulates a confusion matrix for EVERY alpha of the grid
+ * (hist: zeroed uint64 [na][C][C], accumulates across calls); egm_ensemble_miou gives mean IoU per alpha. na<=128, C<=4. */
+int egm_ensemble_alpha_hist(const float* clip_logits, const float* unet_logits, const long long* target, const float* alphas, int na,
+                            int N, int C, int hc, int wc, int H, int W, unsigned long long* hist, egm_stream_t s);
+int egm_ensemble_miou(const unsigned long long* hist, int na, int C, float* miou, egm_stream_t s);
 /* torch.optim.SGD(momentum, weight_decay) (train.py:115-118) over a device table of {float* p; const float* g; float* buf;
  * long long n;} entries: g' = g*grad_scale + wd*p; v = first_step ? g' : mu*v + g'; p -= lr*v.
  * lr_dev (device scalar) overrides lr when non-NULL. */

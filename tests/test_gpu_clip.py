@@ -128,3 +128,32 @@ def test_clipseg_forward_bf16_tracks_fp32(clipseg):
     ref = torch.from_numpy(fx["out"])
     assert rel(out[:, :, ::4, ::4], ref) < 0.1
     assert float(((out[:, :, ::4, ::4].cpu() > 0) == (ref > 0)).float().mean()) > 0.95
+
+
+def test_ensemble_fuse_and_alpha_search_vs_torch():
+    """fused = bilinear(clip) + alpha*unet, argmax, and the alpha grid search against the same computation in torch."""
+    from egm_unet_amd.ensemble import fuse_predict, search_best_alpha
+    g = torch.Generator().manual_seed(11)
+    clips = [torch.randn(1, 2, 352, 352, generator=g) for _ in range(2)]
+    unets = [torch.randn(1, 2, 200, 260, generator=g) * 0.3 for _ in range(2)]
+    labels = [torch.randint(0, 2, (200, 260), generator=g) for _ in range(2)]
+    for lab in labels:
+        lab[:5] = 255
+    up = [F.interpolate(c, size=(200, 260), mode="bilinear", align_corners=False) for c in clips]
+    pred, fused = fuse_predict(clips[0].to(DEV), unets[0].to(DEV), 3.5, return_fused=True)
+    ref = up[0] + 3.5 * unets[0]
+    assert_close(fused.cpu(), ref, rtol=1e-5, atol=1e-5, what="fused logits")
+    assert float((pred.cpu() == ref.argmax(1)).float().mean()) > 0.9999
+    best, best_miou, mious = search_best_alpha([c.to(DEV) for c in clips], [u.to(DEV) for u in unets], [l.numpy() for l in labels],
+                                               search_scale=(0.1, 10.0), search_step=100)
+    alphas = np.linspace(0.1, 10.0, 100)
+    ref_m = []
+    for a in alphas:
+        mat = torch.zeros(2, 2)
+        for u_, c_, l_ in zip(unets, up, labels):
+            p = (c_ + float(np.float32(a)) * u_).argmax(1).flatten(); t = l_.flatten(); k = (t >= 0) & (t < 2)
+            mat += torch.bincount(2 * t[k] + p[k], minlength=4).reshape(2, 2).float()
+        iu = torch.diag(mat) / (mat.sum(1) + mat.sum(0) - torch.diag(mat))
+        ref_m.append(float(iu.mean()))
+    assert np.allclose(mious, np.array(ref_m), atol=2e-4), float(np.abs(mious - np.array(ref_m)).max())
+    assert abs(best_miou - max(ref_m)) < 2e-4
