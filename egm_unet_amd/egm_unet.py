@@ -259,30 +259,29 @@ class RecursiveGatedAttention(nn.Module):
 class DoubleConv1(nn.Sequential):
     """conv-BN-ReLU -> MCALayer -> conv-BN-ReLU -> EdgeEnhancedGRFB (src/EGM-UNet.py:888-904)"""
 
-    def __init__(self, in_channels, out_channels, mid_channels=None):
+    def __init__(self, in_channels, out_channels, mid_channels=None, use_mca=True):
         if mid_channels is None:
             mid_channels = out_channels
-        super().__init__(
-            nn.Conv2d(in_channels, mid_channels, kernel_size=3, padding=1, bias=False),
-            nn.BatchNorm2d(mid_channels),
-            nn.ReLU(inplace=True),
-            MCALayer(mid_channels),
-            nn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=1, bias=False),
-            nn.BatchNorm2d(out_channels),
-            nn.ReLU(inplace=True),
-            EdgeEnhancedGRFB(mid_channels, out_channels, stride=1, scale=0.1, visual=12),
-        )
+        layers = [nn.Conv2d(in_channels, mid_channels, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(mid_channels), nn.ReLU(inplace=True)]
+        if use_mca:                       # use_mca=False == the ablation twin src/yuanGRFBUNet.py:859-875 (indices shift by one)
+            layers.append(MCALayer(mid_channels))
+        layers += [nn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(out_channels),
+                   nn.ReLU(inplace=True), EdgeEnhancedGRFB(mid_channels, out_channels, stride=1, scale=0.1, visual=12)]
+        super().__init__(*layers)
+        self._mca = use_mca
 
     def forward(self, x):
+        o = 1 if self._mca else 0
         x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU)
-        x = self[3](x)
-        x = ops.conv_bn_act(x, self[4], self[5], ACT_RELU)
-        return self[7](x)
+        if self._mca:
+            x = self[3](x)
+        x = ops.conv_bn_act(x, self[3 + o], self[4 + o], ACT_RELU)
+        return self[6 + o](x)
 
 
 class Down(nn.Sequential):
-    def __init__(self, in_channels, out_channels):
-        super().__init__(nn.MaxPool2d(2, stride=2), DoubleConv1(in_channels, out_channels))
+    def __init__(self, in_channels, out_channels, use_mca=True):
+        super().__init__(nn.MaxPool2d(2, stride=2), DoubleConv1(in_channels, out_channels, use_mca=use_mca))
 
     def forward(self, x):
         return self[1](ops.maxpool2(x))
@@ -290,17 +289,18 @@ class Down(nn.Sequential):
 
 class GRFBUNet(_SegNetBase):
     def __init__(self, in_channels: int = 1, num_classes: int = 2, bilinear: bool = True, base_c: int = 64,
-                 use_attention: bool = False):
+                 use_attention: bool = False, use_mca: bool = True):
+        """use_mca=False builds the ablation twin src/yuanGRFBUNet.py (same network without the MCALayer)."""
         super().__init__()
         self.in_channels = in_channels
         self.num_classes = num_classes
         self.bilinear = bilinear
         self.in_conv = DoubleConv(in_channels, base_c)
-        self.down1 = Down(base_c, base_c * 2)
-        self.down2 = Down(base_c * 2, base_c * 4)
-        self.down3 = Down(base_c * 4, base_c * 8)
+        self.down1 = Down(base_c, base_c * 2, use_mca)
+        self.down2 = Down(base_c * 2, base_c * 4, use_mca)
+        self.down3 = Down(base_c * 4, base_c * 8, use_mca)
         factor = 2 if bilinear else 1
-        self.down4 = Down(base_c * 8, base_c * 16 // factor)
+        self.down4 = Down(base_c * 8, base_c * 16 // factor, use_mca)
         self.attn1 = RecursiveGatedAttention(base_c * 16 // factor)
         self.up1 = Up(base_c * 16, base_c * 8 // factor, bilinear)
         self.up2 = Up(base_c * 8, base_c * 4 // factor, bilinear)

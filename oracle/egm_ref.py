@@ -185,20 +185,22 @@ def rga(state: State, p: str, x, order: int = 2):
 # EGM-UNet ("GRFBUNet", src/EGM-UNet.py:1503-1541); Down = pool + DoubleConv1 (:888-912)
 # --------------------------------------------------------------------------- #
 def egm_down(state: State, p: str, x, train: bool, use_mca: bool = True, fft_exact: bool = False):
+    """use_mca=False is the ablation twin src/yuanGRFBUNet.py:859-875 (no MCALayer; Sequential indices shift by one)."""
+    c2, b2, gr = (".1.4", ".1.5", ".1.7") if use_mca else (".1.3", ".1.4", ".1.6")
     x = F.max_pool2d(x, 2, 2)
     x = F.relu(_bn(state, p + ".1.1", _conv(state, p + ".1.0", x, padding=1), train))
     if use_mca:
         x = mca_layer(state, p + ".1.3", x, fft_exact)
-    x = F.relu(_bn(state, p + ".1.5", _conv(state, p + ".1.4", x, padding=1), train))
-    return edge_grfb(state, p + ".1.7", x, train)
+    x = F.relu(_bn(state, p + b2, _conv(state, p + c2, x, padding=1), train))
+    return edge_grfb(state, p + gr, x, train)
 
 
-def egm_unet_forward(state: State, x, train: bool = True, fft_exact: bool = False):
+def egm_unet_forward(state: State, x, train: bool = True, fft_exact: bool = False, use_mca: bool = True):
     x1 = double_conv(state, "in_conv", x, train)
-    x2 = egm_down(state, "down1", x1, train, fft_exact=fft_exact)
-    x3 = egm_down(state, "down2", x2, train, fft_exact=fft_exact)
-    x4 = egm_down(state, "down3", x3, train, fft_exact=fft_exact)
-    x5 = egm_down(state, "down4", x4, train, fft_exact=fft_exact)
+    x2 = egm_down(state, "down1", x1, train, use_mca, fft_exact)
+    x3 = egm_down(state, "down2", x2, train, use_mca, fft_exact)
+    x4 = egm_down(state, "down3", x3, train, use_mca, fft_exact)
+    x5 = egm_down(state, "down4", x4, train, use_mca, fft_exact)
     y = rga(state, "attn1", x5)
     y = up_block(state, "up1", y, x4, train)
     y = up_block(state, "up2", y, x3, train)

@@ -186,3 +186,24 @@ def test_graphed_train_step_matches_reference_trace():
             rel = float((sd[k[6:]].cpu().double() - ref).norm() / (ref.norm() + 1e-12))
             assert rel < 5e-3, (k, rel)
     assert int(sd["in_conv.1.num_batches_tracked"]) == 3
+
+
+def test_yuan_twin_fixture_fp32():
+    """GRFBUNet(use_mca=False) == src/yuanGRFBUNet.py: state_dict keys, logits and gradients against its fixture."""
+    from egm_unet_amd import GRFBUNet
+    fx = load_fixture("yuan_unet_b8")
+    m = GRFBUNet(3, 2, base_c=8, use_mca=False)
+    load_module_state(m, fx)                                   # strict=True: identical keys to the twin's state_dict
+    m.to(DEV).train()
+    out = m(torch.from_numpy(fx["in0"]).to(DEV))["out"]
+    assert_close(out.detach().cpu(), fx["out"], what="logits", **F32)
+    out.backward(torch.from_numpy(fx["gout"]).to(DEV))
+    params = dict(m.named_parameters())
+    rels = []
+    for k, v in fx.items():
+        if k.startswith("grad/"):
+            ref = torch.from_numpy(v).double()
+            if float(ref.norm()) > 1e-5:
+                rels.append(float((params[k[5:]].grad.cpu().double() - ref).norm() / ref.norm()))
+    rels.sort()
+    assert rels[len(rels) // 2] < 2e-3 and rels[-1] < 3e-2, (rels[len(rels) // 2], rels[-1])

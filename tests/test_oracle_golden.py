@@ -177,3 +177,16 @@ def test_manifest_shapes_match_oracle_state_builders():
         for k, shp in keys.items():
             assert list(st[k].shape) == shp, (tag, k)
         assert len(st) == man[tag]["n_entries"]
+
+
+def test_yuan_twin_without_mca():
+    """Ablation twin src/yuanGRFBUNet.py (no MCALayer): same oracle with use_mca=False and shifted Sequential indices."""
+    fx = load_fixture("yuan_unet_b8")
+    st = fixture_state(fx, prefix="")
+    x = torch.from_numpy(fx["in0"]).requires_grad_(True)
+    out = R.egm_unet_forward(st, x, True, use_mca=False)["out"]
+    assert_close(out.detach(), fx["out"], what="yuan out", **TOL)
+    (out * torch.from_numpy(fx["gout"])).sum().backward()
+    for k, v in fx.items():
+        if k.startswith("grad/"):
+            assert_close(st[k[5:]].grad, v, rtol=5e-3, atol=5e-4, what=k)

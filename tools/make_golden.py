@@ -151,6 +151,10 @@ def main():
     block_fixture("unet_b8", m, [torch.randn(2, 3, 64, 64, generator=g)])
     m = egm.GRFBUNet(3, 2, base_c=8); randomize_bn(m, g)
     block_fixture("egm_unet_b8", m, [torch.randn(2, 3, 64, 64, generator=g)])
+    # ablation twin without MCALayer (src/yuanGRFBUNet.py)
+    yuan = _load("ref_yuan_unet", f"{REF}/src/yuanGRFBUNet.py")
+    my = yuan.GRFBUNet(3, 2, base_c=8); randomize_bn(my, g)
+    block_fixture("yuan_unet_b8", my, [torch.randn(2, 3, 64, 64, generator=g)])
     # eval-mode forward of the same EGM-UNet after one train-mode forward (running stats in use)
     m.eval()
     with torch.no_grad():
