@@ -14,6 +14,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libegm_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("EGM_HIPCC_EXTRA", "").split()        # e.g. -DEGM_CONV_TIMING for tools/diag_conv_phases.py
 
 
 def _sources():

@@ -26,6 +26,7 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
 
 namespace {
 
@@ -232,16 +233,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 //     pixel-group instead of one per tile.
 //   * staged window WH x WW: 3x3 (whole kernel), 1x1 (1x1 convs and each tap of a dilated conv), 1x7 (one kernel row of
 //     a 7x7 conv per stage: the 49-tap weight slab would not fit LDS).
-template <int WH, int WW> struct PipeGeom {
-    static constexpr int PH = TH + WH - 1, PW = TW + WW - 1, NTAPS = WH * WW;
+//   * R = tile rows per wave (workgroup tile = 4R x 32 pixels).  Within a k-step every patch-row fragment is read from LDS
+//     ONCE and fed to all (output row, kernel row) pairs that use it, and the weight fragments of one kernel column are
+//     held in registers across the patch rows: LDS reads per MFMA = (WH*NT + R+WH-1) / (R*WH*NT) per kernel column, i.e.
+//     0.5 (R=4, NT=2, 3x3) instead of 1.0 for the naive "two loads per MFMA pair" order -- LDS bandwidth (128 B/clk/CU)
+//     is what bounds a 32x32x16 MFMA loop fed from LDS.
+template <int WH, int WW, int R> struct PipeGeom {
+    static constexpr int THR = 4 * R;
+    static constexpr int PH = THR + WH - 1, PW = TW + WW - 1, NTAPS = WH * WW;
     static constexpr int PVEC = (PH * PW * 4 + 255) / 256;                 // patch 16-byte vectors per thread
 };
 
-template <int NT, int WH, int WW>
-__global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvParams p, int G) {
+template <int NT, int WH, int WW, int R>
+__global__ __launch_bounds__(256, (R * NT >= 8) ? 1 : 2) void conv_igemm_pipe_kernel(ConvParams p, int G) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using Gm = PipeGeom<WH, WW>;
+    using Gm = PipeGeom<WH, WW, R>;
     using M = Mma<bf16_t>;
+    constexpr int THR = Gm::THR;
     constexpr int PS = 80;                                                   // LDS row: 32 ch bf16 + 16 B pad
     constexpr int PH = Gm::PH, PW = Gm::PW, NTAPS = Gm::NTAPS, PVEC = Gm::PVEC;
     constexpr int WROWS = NTAPS * NT * 32;
@@ -267,76 +275,130 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvParams p, i
     const int nchunks = (p.Cin + KC - 1) / KC;
     const bool w_static = (ngroups == 1 && nchunks == 1);
 
-    // ---- per-thread staging slots (fixed for the whole kernel)
-    int pv_off[PVEC], pv_py[PVEC], pv_px[PVEC];
+    // ---- per-thread staging slots (fixed for the whole kernel): slot k of a thread is 16-byte vector i = tid + 256 k of the
+    // patch (pixel i/4, channel vector i%4) resp. of the weight slab (row i/4), so LDS offsets and weight offsets are affine
+    // in k and only the patch's global offsets need a register each.  Slots past the end of the patch / slab are written to
+    // a per-lane dump area behind the weights, so the hot path has no per-slot predicates.
+    unsigned char* dump = wts + WROWS * PS + lane * 16;
+    const int lds_off0 = (tid >> 2) * PS + (tid & 3) * 16;                 // + k * 64 * PS
+    constexpr bool kPatchTail = (PH * PW * 4) % 256 != 0, kWtsTail = (WROWS * 4) % 256 != 0;
+    const bool p_tail_ok = tid + (PVEC - 1) * 256 < PH * PW * 4, w_tail_ok = tid + (WVEC - 1) * 256 < WROWS * 4;
+    int pv_rel[PVEC];                                                       // elements from the halo origin of a tile
+    bool pv_ok[PVEC];                                                       // slot's pixel inside the image (edge tiles; per tile)
 #pragma unroll
     for (int k = 0; k < PVEC; ++k) {
-        const int i = tid + k * 256;
-        const int pix = i >> 2;
-        pv_off[k] = (i < PH * PW * 4) ? pix * PS + (i & 3) * 16 : -1;
-        pv_py[k] = pix / PW; pv_px[k] = pix - (pix / PW) * PW;
+        const int pix = (tid >> 2) + 64 * k, py = pix / PW, px = pix - py * PW;
+        const bool in = !kPatchTail || k < PVEC - 1 || p_tail_ok;
+        pv_rel[k] = in ? (py * p.W + px) * p.ldx + (tid & 3) * 8 : 0;
+        pv_ok[k] = in;
     }
+    // weight slab row (tid>>2) + 64 k = tap t, cout j with 64 / (NT*32) taps per k step
+    constexpr int TAPS_PER_K = 64 / (NT * 32);
+    const int w_rel0 = (((tid >> 2) / (NT * 32)) * p.Cout + ((tid >> 2) % (NT * 32))) * p.Cin + (tid & 3) * 8;
+    const int w_step = TAPS_PER_K * p.Cout * p.Cin;
+    const bool w_rows_full = co0 + NT * 32 <= p.Cout;                      // uniform: every weight row of this cout tile exists
     uint4 pre_p[PVEC], pre_w[WVEC];
 
     // ---- stage iterator: (pixel tile, tap group, chunk) with wholly-out-of-image dilated groups skipped
-    struct Stage { int pt, g, c0, n, oy0, ox0, offy, offx, tap0; bool valid; };
+    struct Stage { int pt, g, c0, n, oy0, ox0, offy, offx, tap0; bool valid, interior; };
     auto locate = [&](Stage& st) {
         // normalise (pt, g, c0): advance until a contributing group is found or the tile list ends
         while (true) {
             if (st.pt >= p.npt) { st.valid = false; return; }
             st.n = st.pt / tpi; const int trem = st.pt - st.n * tpi;
-            st.oy0 = (trem / p.tiles_x) * TH; st.ox0 = (trem % p.tiles_x) * TW;
+            st.oy0 = (trem / p.tiles_x) * THR; st.ox0 = (trem % p.tiles_x) * TW;
             if (p.dil == 1) {
                 st.offy = row_mode ? st.g - p.KH / 2 : -(p.KH / 2); st.offx = -(p.KW / 2); st.tap0 = row_mode ? st.g * p.KW : 0;
-                st.valid = true; return;
+            } else {
+                st.offy = (st.g / p.KW - p.KH / 2) * p.dil; st.offx = (st.g % p.KW - p.KW / 2) * p.dil; st.tap0 = st.g;
+                const bool out = st.oy0 + st.offy >= p.H || st.oy0 + st.offy + THR <= 0 || st.ox0 + st.offx >= p.W || st.ox0 + st.offx + TW <= 0;
+                // the centre tap (offset 0) always contributes, so every tile keeps at least one group
+                if (out) {
+                    st.c0 = 0; st.g += 1;
+                    if (st.g >= ngroups) { st.g = 0; st.pt += G; }
+                    continue;
+                }
             }
-            st.offy = (st.g / p.KW - p.KH / 2) * p.dil; st.offx = (st.g % p.KW - p.KW / 2) * p.dil; st.tap0 = st.g;
-            const bool out = st.oy0 + st.offy >= p.H || st.oy0 + st.offy + TH <= 0 || st.ox0 + st.offx >= p.W || st.ox0 + st.offx + TW <= 0;
-            // the centre tap (offset 0) always contributes, so every tile keeps at least one group
-            if (!out) { st.valid = true; return; }
-            st.c0 = 0; st.g += 1;
-            if (st.g >= ngroups) { st.g = 0; st.pt += G; }
+            // the part of the staged window that lies inside the image (never empty: see above / dil == 1 tiles always overlap)
+            const int y0 = st.oy0 + st.offy, x0 = st.ox0 + st.offx;
+            const int ylo = max(0, -y0), yhi = min(PH, p.H - y0), xlo = max(0, -x0), xhi = min(PW, p.W - x0);
+            st.interior = ylo == 0 && yhi == PH && xlo == 0 && xhi == PW;   // whole window inside: loads need no bounds tests
+            if (!st.interior) {
+                // per-slot "pixel inside the image" flags, once per tile (they hold for every channel chunk of the tile)
+#pragma unroll
+                for (int k = 0; k < PVEC; ++k) {
+                    const int pix = (tid >> 2) + 64 * k, py = pix / PW, px = pix - py * PW;
+                    pv_ok[k] = py >= ylo && py < yhi && px >= xlo && px < xhi && (!kPatchTail || k < PVEC - 1 || p_tail_ok);
+                }
+            }
+            st.valid = true; return;
         }
     };
     auto advance = [&](Stage st) {
         st.c0 += KC;
-        if (st.c0 >= p.Cin) { st.c0 = 0; st.g += 1; if (st.g >= ngroups) { st.g = 0; st.pt += G; } }
+        if (st.c0 < p.Cin) return st;                        // next chunk of the same window: coordinates unchanged
+        st.c0 = 0; st.g += 1;
+        if (st.g >= ngroups) { st.g = 0; st.pt += G; }
         locate(st);
         return st;
     };
     auto issue_loads = [&](const Stage& st, bool with_weights) {
+        const bool full_chunk = st.c0 + KC <= p.Cin;
+        // uniform base + fixed per-thread offsets: one load instruction per slot (the base may lie outside the tensor for
+        // edge tiles; it is only dereferenced by slots whose pixel is inside the image)
+        const bf16_t* base = xg + ((long long)(st.n * p.H + st.oy0 + st.offy) * p.W + st.ox0 + st.offx) * p.ldx + st.c0;
+        if (st.interior && full_chunk) {
 #pragma unroll
-        for (int k = 0; k < PVEC; ++k) {
-            const int iy = st.oy0 + st.offy + pv_py[k], ix = st.ox0 + st.offx + pv_px[k];
-            const int c = st.c0 + ((tid + k * 256) & 3) * 8;
-            const bool ok = pv_off[k] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.Cin;
-            pre_p[k] = make_uint4(0, 0, 0, 0);
-            if (ok) pre_p[k] = *reinterpret_cast<const uint4*>(xg + ((long long)(st.n * p.H + iy) * p.W + ix) * p.ldx + c);
+            for (int k = 0; k < PVEC; ++k) pre_p[k] = *reinterpret_cast<const uint4*>(base + pv_rel[k]);
+        } else if (full_chunk) {
+            // edge tile: the per-slot flags of this tile gate the loads
+#pragma unroll
+            for (int k = 0; k < PVEC; ++k) {
+                pre_p[k] = make_uint4(0, 0, 0, 0);
+                if (pv_ok[k]) pre_p[k] = *reinterpret_cast<const uint4*>(base + pv_rel[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PVEC; ++k) {
+                const int pix = (tid >> 2) + 64 * k, py = pix / PW, px = pix - py * PW;      // ragged last chunk only: recomputed
+                const int iy = st.oy0 + st.offy + py, ix = st.ox0 + st.offx + px;
+                const int c = st.c0 + (tid & 3) * 8;
+                const bool ok = (!kPatchTail || k < PVEC - 1 || p_tail_ok) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.Cin;
+                pre_p[k] = make_uint4(0, 0, 0, 0);
+                if (ok) pre_p[k] = *reinterpret_cast<const uint4*>(xg + ((long long)(st.n * p.H + iy) * p.W + ix) * p.ldx + c);
+            }
         }
         if (with_weights) {
+            if (w_rows_full && full_chunk) {
+                const bf16_t* wbase = wg + ((long long)st.tap0 * p.Cout + co0) * p.Cin + st.c0;
 #pragma unroll
-            for (int k = 0; k < WVEC; ++k) {
-                const int i = tid + k * 256, row = i >> 2, t = row / (NT * 32), j = row - t * (NT * 32);
-                const int co = co0 + j, c = st.c0 + (i & 3) * 8;
-                const bool ok = i < WROWS * 4 && co < p.Cout && c < p.Cin;
-                pre_w[k] = make_uint4(0, 0, 0, 0);
-                if (ok) pre_w[k] = *reinterpret_cast<const uint4*>(wg + ((long long)(st.tap0 + t) * p.Cout + co) * p.Cin + c);
+                for (int k = 0; k < WVEC; ++k)
+                    pre_w[k] = *reinterpret_cast<const uint4*>(wbase + ((!kWtsTail || k < WVEC - 1 || w_tail_ok) ? w_rel0 + k * w_step : 0));
+            } else {
+#pragma unroll
+                for (int k = 0; k < WVEC; ++k) {
+                    const int i = tid + k * 256, row = i >> 2, t = row / (NT * 32), j = row - t * (NT * 32);
+                    const int co = co0 + j, c = st.c0 + (i & 3) * 8;
+                    const bool ok = i < WROWS * 4 && co < p.Cout && c < p.Cin;
+                    pre_w[k] = make_uint4(0, 0, 0, 0);
+                    if (ok) pre_w[k] = *reinterpret_cast<const uint4*>(wg + ((long long)(st.tap0 + t) * p.Cout + co) * p.Cin + c);
+                }
             }
         }
     };
     auto write_lds = [&](bool with_weights) {
 #pragma unroll
-        for (int k = 0; k < PVEC; ++k) if (pv_off[k] >= 0) *reinterpret_cast<uint4*>(patch + pv_off[k]) = pre_p[k];
+        for (int k = 0; k < PVEC; ++k)
+            *reinterpret_cast<uint4*>((!kPatchTail || k < PVEC - 1 || p_tail_ok) ? patch + lds_off0 + k * 64 * PS : dump) = pre_p[k];
         if (with_weights) {
 #pragma unroll
             for (int k = 0; k < WVEC; ++k) {
-                const int i = tid + k * 256;
-                if (i < WROWS * 4) *reinterpret_cast<uint4*>(wts + (i >> 2) * PS + (i & 3) * 16) = pre_w[k];
+                *reinterpret_cast<uint4*>((!kWtsTail || k < WVEC - 1 || w_tail_ok) ? wts + lds_off0 + k * 64 * PS : dump) = pre_w[k];
             }
         }
     };
 
-    f32x16_t acc[2][NT];
+    f32x16_t acc[R][NT];
     float ssum[8], ssq[8];
     zero8(ssum); zero8(ssq);
     float bias8[8];
@@ -346,49 +408,73 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvParams p, i
         for (int j = 0; j < 8; ++j) { const int co = co0 + cv * 8 + j; bias8[j] = (p.bias != nullptr && co < p.bias_n) ? p.bias[co] : 0.f; }
     }
 
+#ifdef EGM_CONV_TIMING
+    long long tph[6] = {0, 0, 0, 0, 0, 0}; int nstages = 0;
+    long long tmark = __builtin_amdgcn_s_memtime();
+#define EGM_TICK(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); tph[i] += t_ - tmark; tmark = t_; } while (0)
+#else
+#define EGM_TICK(i) do { } while (0)
+#endif
     Stage cur; cur.pt = grp; cur.g = 0; cur.c0 = 0;
     locate(cur);
     if (!cur.valid) return;
     issue_loads(cur, true);
+    EGM_TICK(2);
     bool first_of_item = true;
     bool need_w = true;
 
     while (true) {
         if (first_of_item) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < R; ++m)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.f;
         }
         __syncthreads();                                      // LDS free: previous compute / epilogue finished everywhere
+        EGM_TICK(0);
         write_lds(need_w);
+        EGM_TICK(1);
         __syncthreads();
+        EGM_TICK(0);
         const Stage nxt = advance(cur);
         const bool nxt_w = nxt.valid && !w_static;
         if (nxt.valid) issue_loads(nxt, nxt_w);              // in flight during the MFMAs below
+        EGM_TICK(2);
         // ---- MFMA: A = weights (rows = couts), B = patch (cols = pixels)
         {
-            const int kc = min(KC, p.Cin - cur.c0);
-            const int nks = (kc + 15) >> 4;
+            const unsigned char* brow = patch + ((R * wv) * PW + r31) * PS;
+            const unsigned char* arow = wts + r31 * PS;
+            auto kstep = [&](int ks) {
 #pragma unroll
-            for (int t = 0; t < NTAPS; ++t) {
-                const int wr = t / WW, ws = t - wr * WW;
-                const unsigned char* b0 = patch + ((2 * wv + 0 + wr) * PW + r31 + ws) * PS;
-                const unsigned char* b1 = patch + ((2 * wv + 1 + wr) * PW + r31 + ws) * PS;
-                const unsigned char* a0 = wts + (t * NT * 32 + r31) * PS;
-                for (int ks = 0; ks < nks; ++ks) {
-                    const M::Frag fb0 = M::load(b0, ks, h), fb1 = M::load(b1, ks, h);
+                for (int ws = 0; ws < WW; ++ws) {
+                    M::Frag fa[WH][NT];                         // one kernel column of weights, held across the patch rows
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const M::Frag fa = M::load(a0 + nt * 32 * PS, ks, h);
-                        acc[0][nt] = M::mma(fa, fb0, acc[0][nt]);
-                        acc[1][nt] = M::mma(fa, fb1, acc[1][nt]);
+                    for (int wr = 0; wr < WH; ++wr)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) fa[wr][nt] = M::load(arow + ((wr * WW + ws) * NT + nt) * 32 * PS, ks, h);
+#pragma unroll
+                    for (int rho = 0; rho < R + WH - 1; ++rho) {
+                        const M::Frag fb = M::load(brow + (rho * PW + ws) * PS, ks, h);
+#pragma unroll
+                        for (int m = 0; m < R; ++m) {
+                            const int wr = rho - m;
+                            if (wr >= 0 && wr < WH) {
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = M::mma(fa[wr][nt], fb, acc[m][nt]);
+                            }
+                        }
                     }
                 }
-            }
+            };
+            kstep(0);
+            if (p.Cin - cur.c0 > 16) kstep(1);
         }
+        EGM_TICK(3);
+#ifdef EGM_CONV_TIMING
+        ++nstages;
+#endif
         const bool last_of_item = !nxt.valid || nxt.pt != cur.pt;
         if (last_of_item) {
             __syncthreads();                                  // everyone done reading the patch: reuse it as out tiles
@@ -398,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvParams p, i
             const int cv = lane % NV, slot = lane / NV;
             // D layout: col (pixel) = lane&31, row (cout) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+            for (int m = 0; m < R; ++m) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -409,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvParams p, i
                         *reinterpret_cast<uint2*>(ot + r31 * OROW + (nt * 32 + gq * 8 + h * 4) * 2) = pk;
                     }
                 // read back whole channel vectors (same wave: its LDS ops complete in order) and store coalesced
-                const int oy = cur.oy0 + 2 * wv + m;
+                const int oy = cur.oy0 + R * wv + m;
 #pragma unroll
                 for (int it = 0; it < NV / 2; ++it) {         // 32 pixels / (64/NV pixel slots)
                     const int pl = it * (64 / NV) + slot;
@@ -429,11 +515,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_pipe_kernel(ConvParams p, i
                 }
             }
         }
+        EGM_TICK(4);
         if (!nxt.valid) break;
         first_of_item = last_of_item;
         need_w = nxt_w;
         cur = nxt;
     }
+#ifdef EGM_CONV_TIMING
+    if (p.stats != nullptr) {       // debug build: the stats rows carry per-phase shader-clock totals of wave 0 instead
+        __syncthreads();
+        if (tid == 0 && ct == 0) {
+            for (int i = 0; i < 5; ++i) p.stats[(long long)grp * 2 * p.Cout + i] = (float)tph[i];
+            p.stats[(long long)grp * 2 * p.Cout + 5] = (float)nstages;
+        }
+        return;
+    }
+#endif
 
     if (p.stats != nullptr) {
         // lanes with equal cv (cv, cv+NV, ...) hold partial sums of the same 8 channels
@@ -553,32 +650,59 @@ bool pipe_eligible(int dtype, int KH, int KW, int dil) {
     return dtype == EGM_BF16 && KH == KW && ((KH == 3 && dil == 1) || KH == 1 || (KH == 3 && dil > 1) || (KH == 7 && dil == 1));
 }
 
-template <int NT, int WH, int WW>
-int launch_pipe(ConvParams& p, hipStream_t st) {
-    using Gm = PipeGeom<WH, WW>;
+template <int NT, int WH, int WW, int R>
+int launch_pipe(ConvParams& p, int G, hipStream_t st) {
+    using Gm = PipeGeom<WH, WW, R>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_pipe_kernel<NT, WH, WW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_pipe_kernel<NT, WH, WW, R>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_igemm_pipe: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     p.patch_bytes = (Gm::PH * Gm::PW * 80 + 15) / 16 * 16;
-    size_t smem = (size_t)p.patch_bytes + (size_t)Gm::NTAPS * NT * 32 * 80;
+    size_t smem = (size_t)p.patch_bytes + (size_t)Gm::NTAPS * NT * 32 * 80 + 64 * 16;      // + per-lane dump slots
     static_assert((size_t)4 * 32 * (NT * 64 + 16) <= (size_t)Gm::PH * Gm::PW * 80, "epilogue out tiles must fit inside the patch region");
-    const int G = pipe_groups(p.npt, p.nct);
+    static_assert((size_t)Gm::PH * Gm::PW * 80 + 16 + (size_t)Gm::NTAPS * NT * 32 * 80 + 1024 <= 160 * 1024, "LDS budget");
     const int grid = ((G + 7) / 8) * 8 * p.nct;
-    hipLaunchKernelGGL((conv_igemm_pipe_kernel<NT, WH, WW>), dim3(grid), dim3(256), smem, st, p, G);
+    hipLaunchKernelGGL((conv_igemm_pipe_kernel<NT, WH, WW, R>), dim3(grid), dim3(256), smem, st, p, G);
     EGM_CHECK_LAUNCH("conv_igemm_pipe");
     return EGM_OK;
+}
+
+// One place decides tile shape and grouping, so the stats-tile count the caller allocates always matches the launch.
+struct ConvPlan { bool pipe; int R, NT, tiles_y, tiles_x, npt, nct, G; };
+ConvPlan conv_plan(int dtype, int N, int H, int W, int Cout, int KH, int KW, int dil) {
+    ConvPlan c;
+    if (KH == 1 && KW == 1) dil = 1;
+    c.pipe = pipe_eligible(dtype, KH, KW, dil);
+    c.R = 2;
+    if (c.pipe && KH == 3 && dil == 1 && Cout <= 32) {
+        // tall tiles (16 x 32 pixels, 4 rows per wave) for the narrow layers when they still fill the chip: 0.75 instead of
+        // 1.5 LDS fragment reads per MFMA and half the weight re-staging.  (Measured: with 64-cout tiles the taller tile
+        // needs one workgroup per CU and is no faster than two 8-row workgroups, so those keep R = 2.)
+        const long long npt4 = (long long)N * egm_cdiv(H, 16) * egm_cdiv(W, TW);
+        if (npt4 >= 256) c.R = 4;
+    }
+    c.tiles_y = egm_cdiv(H, 4 * c.R); c.tiles_x = egm_cdiv(W, TW); c.npt = N * c.tiles_y * c.tiles_x;
+    c.NT = (c.R == 4) ? (Cout <= 32 ? 1 : 2) : conv_nt(c.npt, Cout);
+    c.nct = egm_cdiv(Cout, 32 * c.NT);
+    if (!c.pipe) { c.G = c.npt; return c; }
+    if (c.R == 4) {
+        const int per_cu = (c.NT == 2) ? 1 : 2;                 // resident workgroups per CU (LDS / register budget)
+        int g = (256 * per_cu / c.nct) / 8 * 8;
+        if (g < 8) g = 8;
+        if (g > c.npt) g = c.npt;
+        c.G = g;
+    } else {
+        c.G = pipe_groups(c.npt, c.nct);
+    }
+    return c;
 }
 }  // namespace
 
 extern "C" int egm_conv_stats_tiles(int dtype, int N, int H, int W, int Cout, int KH, int KW, int dil) {
-    const int npt = N * egm_cdiv(H, TH) * egm_cdiv(W, TW);
-    if (KH == 1 && KW == 1) dil = 1;
-    if (pipe_eligible(dtype, KH, KW, dil)) return pipe_groups(npt, egm_cdiv(Cout, 32 * conv_nt(npt, Cout)));
-    return npt;
+    return conv_plan(dtype, N, H, W, Cout, KH, KW, dil).G;
 }
 
 extern "C" int egm_conv_pack(int dtype, const void* w, void* wf, void* wd, int Cout, int Cin, int KH, int KW, int groups,
@@ -620,14 +744,17 @@ extern "C" int egm_conv_fwd(int dtype, const void* x, int ldx, const void* wf, c
     ConvParams p;
     p.x = x; p.w = wf; p.bias = (const float*)bias; p.y = y; p.stats = stats;
     p.ldx = ldx; p.ldy = ldy; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.dil = dil; p.bias_n = bias ? bias_n : 0;
-    p.tiles_y = egm_cdiv(H, TH); p.tiles_x = egm_cdiv(W, TW); p.npt = N * p.tiles_y * p.tiles_x;
-    const int NT = conv_nt(p.npt, Cout);
-    p.nct = egm_cdiv(Cout, NT * 32);
-    if (pipe_eligible(dtype, KH, KW, dil)) {
+    const ConvPlan c = conv_plan(dtype, N, H, W, Cout, KH, KW, dil);
+    p.tiles_y = c.tiles_y; p.tiles_x = c.tiles_x; p.npt = c.npt; p.nct = c.nct;
+    const int NT = c.NT;
+    if (c.pipe) {
         hipStream_t st = (hipStream_t)s;
-        if (KH == 3 && dil == 1) return NT == 2 ? launch_pipe<2, 3, 3>(p, st) : launch_pipe<1, 3, 3>(p, st);
-        if (KH == 7) return NT == 2 ? launch_pipe<2, 1, 7>(p, st) : launch_pipe<1, 1, 7>(p, st);
-        return NT == 2 ? launch_pipe<2, 1, 1>(p, st) : launch_pipe<1, 1, 1>(p, st);
+        if (KH == 3 && dil == 1) {
+            if (c.R == 4) return NT == 2 ? launch_pipe<2, 3, 3, 4>(p, c.G, st) : launch_pipe<1, 3, 3, 4>(p, c.G, st);
+            return NT == 2 ? launch_pipe<2, 3, 3, 2>(p, c.G, st) : launch_pipe<1, 3, 3, 2>(p, c.G, st);
+        }
+        if (KH == 7) return NT == 2 ? launch_pipe<2, 1, 7, 2>(p, c.G, st) : launch_pipe<1, 1, 7, 2>(p, c.G, st);
+        return NT == 2 ? launch_pipe<2, 1, 1, 2>(p, c.G, st) : launch_pipe<1, 1, 1, 2>(p, c.G, st);
     }
     const int ps = (dtype == EGM_BF16) ? Mma<bf16_t>::kPixStride : Mma<float>::kPixStride;
     const bool halo = (dil == 1);

@@ -4,6 +4,7 @@ Activations are NHWC tensors ``[N, H, W, C]`` (fp32 or bf16, C a multiple of 8, 
 wider buffer).  torch is used for memory (torch.empty / views), streams and autograd bookkeeping only.
 """
 import struct
+import weakref
 
 import torch
 from torch.autograd import Function, Variable
@@ -127,7 +128,7 @@ def _packed_weights(weight, groups, dtype):
     """fp32 OIHW parameter -> (wf, wd) operand packs; cached on (storage, version) so eval loops don't repack."""
     key = (weight.data_ptr(), weight._version, _weight_generation[0], dtype, groups, tuple(weight.shape))
     hit = _pack_cache.get(id(weight))
-    if hit is not None and hit[0] == key:
+    if hit is not None and hit[0] == key and hit[3]() is weight:    # the weakref guards against id()/address reuse by a new tensor
         return hit[1], hit[2]
     Cout, Cin_g, KH, KW = weight.shape
     Cin = Cin_g * groups
@@ -136,7 +137,7 @@ def _packed_weights(weight, groups, dtype):
     w = weight.detach()
     w = w if w.is_contiguous() else w.contiguous()
     lib().call("egm_conv_pack", dtype_code(dtype), ptr(w), ptr(wf), ptr(wd), Cout, Cin, KH, KW, groups, stream())
-    _pack_cache[id(weight)] = (key, wf, wd)
+    _pack_cache[id(weight)] = (key, wf, wd, weakref.ref(weight))
     return wf, wd
 
 
@@ -174,7 +175,7 @@ def prepack_model(model, dtype):
     for m, (wf, wd) in zip(convs, bufs):
         w = m.weight
         key = (w.data_ptr(), w._version, _weight_generation[0], dtype, m.groups, tuple(w.shape))
-        _pack_cache[id(w)] = (key, wf, wd)
+        _pack_cache[id(w)] = (key, wf, wd, weakref.ref(w))
     st["stamp"] = stamp
 
 
@@ -237,6 +238,7 @@ class _Conv2d(Function):
         ctx.save_for_backward(x, weight, wd)
         ctx.meta = (dil, groups, bias is not None, Cin, Cout)
         ctx.bias_grad_zero = bias_grad_zero
+        ctx.set_materialize_grads(False)                # no zero-filled "gradient" for the non-differentiable stats output
         if want_stats:
             ctx.mark_non_differentiable(stats)
             return y, stats
@@ -244,6 +246,8 @@ class _Conv2d(Function):
 
     @staticmethod
     def backward(ctx, gy, *_):
+        if gy is None:
+            return (None,) * 7
         x, weight, wd = ctx.saved_tensors
         dil, groups, has_bias, Cin, Cout = ctx.meta
         gy, ldg = _nhwc(gy)

@@ -75,6 +75,10 @@ CONV_CASES = [
     (5, 256, 256, 32, 32, 1, 1, 1, True),    # 1x1
     (3, 256, 256, 16, 16, 3, 12, 1, False),  # dilated, several tiles per workgroup
     (3, 256, 256, 16, 16, 7, 1, 1, True),    # 7x7 by kernel rows
+    # tall-tile (16x32, four rows per wave) variants of the 3x3 kernel: ragged edges, 1 and 2 cout blocks, 2 chunks
+    (3, 250, 500, 40, 24, 3, 1, 1, True),
+    (2, 250, 270, 32, 72, 3, 1, 1, True),
+    (1, 512, 512, 8, 32, 3, 1, 1, False),
 ]
 
 
@@ -154,16 +158,17 @@ def rel_l2(a, b):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_conv_bn_stats_fused(dtype):
+@pytest.mark.parametrize("shape", [(2, 19, 37), (4, 120, 250)], ids=["small", "tall_tiles"])
+def test_conv_bn_stats_fused(dtype, shape):
     """conv -> BN(train, statistics from the conv epilogue) -> ReLU, forward and backward."""
     ops = _ops()
     from egm_unet_amd._lib import ACT_RELU
     import copy
     g = torch.Generator().manual_seed(9)
-    x = torch.randn(2, 16, 19, 37, generator=g)
+    x = torch.randn(shape[0], 16, shape[1], shape[2], generator=g)
     conv = torch.nn.Conv2d(16, 24, 3, padding=1, bias=False)
     bn = torch.nn.BatchNorm2d(24)
-    gz = torch.randn(2, 24, 19, 37, generator=g)
+    gz = torch.randn(shape[0], 24, shape[1], shape[2], generator=g)
     if dtype == torch.bfloat16:
         x, gz = x.bfloat16().float(), gz.bfloat16().float()
         with torch.no_grad():
