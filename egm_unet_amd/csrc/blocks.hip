@@ -322,17 +322,24 @@ __global__ __launch_bounds__(256) void global_pool_partial_kernel(const T* __res
 }
 // out rows [0,N) = average, rows [N,2N) = max, dtype T, [2N][C]; argidx [N][C] = first position of the max
 template <typename T>
-__global__ void global_pool_final_kernel(const float* __restrict__ part, const int* __restrict__ part_idx, int nblk, int N, long long HW,
-                                         int C, T* __restrict__ out, int* __restrict__ argidx) {
-    const int n = blockIdx.y;
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        double ss = 0.0; float mm = -INFINITY; int ii = 0x7fffffff;
-        for (int b = 0; b < nblk; ++b) {
-            const long long o = ((long long)n * nblk + b) * 2 * C;
-            ss += (double)part[o + c];
-            const float m = part[o + C + c]; const int k = part_idx[((long long)n * nblk + b) * C + c];
-            if (m > mm || (m == mm && k < ii)) { mm = m; ii = k; }
-        }
+__global__ __launch_bounds__(64) void global_pool_final_kernel(const float* __restrict__ part, const int* __restrict__ part_idx, int nblk, int N,
+                                                               long long HW, int C, T* __restrict__ out, int* __restrict__ argidx) {
+    // one wave per (channel, image): lanes stride over the partial blocks, then a butterfly that keeps (max, first index)
+    const int n = blockIdx.y, c = blockIdx.x, lane = threadIdx.x;
+    double ss = 0.0; float mm = -INFINITY; int ii = 0x7fffffff;
+    for (int b = lane; b < nblk; b += 64) {
+        const long long o = ((long long)n * nblk + b) * 2 * C;
+        ss += (double)part[o + c];
+        const float m = part[o + C + c]; const int k = part_idx[((long long)n * nblk + b) * C + c];
+        if (m > mm || (m == mm && k < ii)) { mm = m; ii = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ss += __shfl_xor(ss, o, 64);
+        const float m2 = __shfl_xor(mm, o, 64); const int i2 = __shfl_xor(ii, o, 64);
+        if (m2 > mm || (m2 == mm && i2 < ii)) { mm = m2; ii = i2; }
+    }
+    if (lane == 0) {
         out[(long long)n * C + c] = from_f32<T>((float)(ss / (double)HW));
         out[(long long)(N + n) * C + c] = from_f32<T>(mm);
         argidx[(long long)n * C + c] = ii;
@@ -552,12 +559,16 @@ __global__ __launch_bounds__(256) void sa_conv7_bwd_w_kernel(const T* __restrict
     __syncthreads();
     if (threadIdx.x < 98) part[(long long)blockIdx.x * 98 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
-__global__ void sa_conv7_bwd_w_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dw) {
-    const int k = threadIdx.x;
-    if (k >= 98) return;
+// one block per weight element: 256 lanes stride over the per-block partials, fixed-order tree in LDS
+__global__ __launch_bounds__(256) void sa_conv7_bwd_w_final_kernel(const float* __restrict__ part, int nblk, float* __restrict__ dw) {
+    __shared__ double red[256];
+    const int k = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[(long long)b * 98 + k];
-    dw[k] = (float)s;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += (double)part[(long long)b * 98 + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) dw[k] = (float)red[0];
 }
 
 inline int group_for(int ncv) { int g = 1; while (g < ncv) g <<= 1; return g; }
@@ -711,7 +722,7 @@ extern "C" int egm_global_avgmax_fwd(int dtype, const void* x, int ldx, void* ou
     int* pidx = (int*)(part + (long long)N * nb * 2 * C);
     EGM_DISPATCH_DTYPE(dtype, {
         hipLaunchKernelGGL((global_pool_partial_kernel<T>), dim3(nb, N), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, HW, C, part, pidx);
-        hipLaunchKernelGGL((global_pool_final_kernel<T>), dim3((C + 255) / 256, N), dim3(256), 0, (hipStream_t)s, part, pidx, nb, N, HW, C,
+        hipLaunchKernelGGL((global_pool_final_kernel<T>), dim3(C, N), dim3(64), 0, (hipStream_t)s, part, pidx, nb, N, HW, C,
                            (T*)out, argidx);
     });
     EGM_CHECK_LAUNCH("global_avgmax_fwd");
@@ -811,7 +822,7 @@ extern "C" int egm_sa_conv7_bwd(int dtype, const void* x, int ldx, const void* d
         hipLaunchKernelGGL((sa_conv7_bwd_w_kernel<T>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, (const T*)dy, lddy,
                            (float*)workspace, N, H, W);
     });
-    hipLaunchKernelGGL(sa_conv7_bwd_w_final_kernel, dim3(1), dim3(128), 0, (hipStream_t)s, (const float*)workspace, nb, dw);
+    hipLaunchKernelGGL(sa_conv7_bwd_w_final_kernel, dim3(98), dim3(256), 0, (hipStream_t)s, (const float*)workspace, nb, dw);
     EGM_CHECK_LAUNCH("sa_conv7_bwd");
     return EGM_OK;
 }

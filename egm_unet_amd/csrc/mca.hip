@@ -73,18 +73,27 @@ __global__ __launch_bounds__(256) void mca_reduce_row_kernel(const T* __restrict
     tq = block_sum(tq, red);
     if (tid == 0) { sums[((long long)n * L + h) * 2 + 0] = ts; sums[((long long)n * L + h) * 2 + 1] = tq; }
 }
-// pass 2: sum the per-row partials over h in fixed order -> sums[n][H + w] and sums[n][H + W + c]
-__global__ void mca_reduce_h_kernel(const float* __restrict__ colp, const float* __restrict__ chp, float* __restrict__ sums, int N, int H,
-                                    int W, int C) {
-    const int L = H + W + C;
-    const long long total = (long long)N * (W + C) * 2;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int k = (int)(i & 1); const long long e = i >> 1;
-        const int n = (int)(e / (W + C)), r = (int)(e - (long long)n * (W + C));
-        double s = 0.0;
-        if (r < W) for (int h = 0; h < H; ++h) s += (double)colp[(((long long)n * H + h) * W + r) * 2 + k];
-        else for (int h = 0; h < H; ++h) s += (double)chp[(((long long)n * H + h) * C + (r - W)) * 2 + k];
-        sums[((long long)n * L + H + r) * 2 + k] = (float)s;
+// pass 2: sum the per-row partials over h in fixed order -> sums[n][H + w] and sums[n][H + W + c].
+// block = 16 consecutive output floats x 16 h-lanes (coalesced 64-byte rows); the h-lanes are combined in fixed order.
+__global__ __launch_bounds__(256) void mca_reduce_h_kernel(const float* __restrict__ colp, const float* __restrict__ chp, float* __restrict__ sums,
+                                                           int N, int H, int W, int C) {
+    __shared__ double red[256];
+    const int L = H + W + C, per_img = (W + C) * 2;
+    const int n = blockIdx.y, col = threadIdx.x & 15, hl = threadIdx.x >> 4;
+    const int f = blockIdx.x * 16 + col;                       // float index inside [W cols | C chans] x 2 of image n
+    double s = 0.0;
+    if (f < per_img) {
+        const bool is_col = f < W * 2;
+        const float* src = is_col ? colp + (long long)n * H * W * 2 + f : chp + (long long)n * H * C * 2 + (f - W * 2);
+        const int pitch = is_col ? W * 2 : C * 2;
+        for (int h = hl; h < H; h += 16) s += (double)src[(long long)h * pitch];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (hl == 0 && f < per_img) {
+        double t = 0.0;
+        for (int j = 0; j < 16; ++j) t += red[j * 16 + col];
+        sums[((long long)n * L + H) * 2 + f] = (float)t;
     }
 }
 
@@ -129,11 +138,14 @@ __global__ void mca_gates_fwd_kernel(const float* __restrict__ sums, GateParams 
 __global__ void mca_gates_bwd_kernel(const float* __restrict__ dG, const float* __restrict__ stats, const float* __restrict__ o,
                                      const float* __restrict__ gates, GateParams gp, float* __restrict__ dz, float* __restrict__ coef,
                                      float* __restrict__ dwts, float* __restrict__ dks, int N, int H, int W, int C) {
-    __shared__ float red[16];
     const int L = H + W + C, total = N * L;
     for (int e = threadIdx.x; e < total; e += blockDim.x) dz[e] = dG[e * 2] * (1.f / 3.f) * gates[e] * (1.f - gates[e]);
     __syncthreads();
-    float da[3] = {0.f, 0.f, 0.f}, db[3] = {0.f, 0.f, 0.f};     // d(alpha), d(beta) per axis
+    // per-thread partials of everything that is summed over the entries: d(alpha), d(beta) per axis and the <= 7 kernel taps
+    // per axis (dk[a][t] = sum_e dz[e] * o[e + t - pad]); one LDS reduction at the end instead of one per scalar
+    float acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) acc[i] = 0.f;
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         int ax, idx, len; axis_of(e, H, W, C, ax, idx, len);
         const int ks = gp.ks[ax], pad = (ks - 1) / 2;
@@ -145,29 +157,33 @@ __global__ void mca_gates_bwd_kernel(const float* __restrict__ dG, const float* 
         const float dmean = alpha * d_o, dsd = beta * d_o;
         const float B = sd > 0.f ? dsd / ((cnt - 1.f) * sd) : 0.f;
         coef[e * 2] = dmean / cnt - B * mean; coef[e * 2 + 1] = B;
+        const float dze = dz[e];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) if (a == ax) { da[a] += d_o * mean; db[a] += d_o * sd; }
-    }
+        for (int a = 0; a < 3; ++a)
+            if (a == ax) {
+                acc[a * 2] += d_o * mean; acc[a * 2 + 1] += d_o * sd;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float sa = block_sum(da[a], red), sb = block_sum(db[a], red);
-        if (threadIdx.x == 0) {
-            const float s0 = sigm(gp.w[a][0]), s1 = sigm(gp.w[a][1]);
-            dwts[a * 2 + 0] = sa * s0 * (1.f - s0); dwts[a * 2 + 1] = sb * s1 * (1.f - s1);
-        }
-    }
-    for (int a = 0; a < 3; ++a) {                                   // dk[a][t] = sum_e dz[e] * o[e + t - pad]
-        const int pad = (gp.ks[a] - 1) / 2;
-        for (int t = 0; t < gp.ks[a]; ++t) {
-            float acc = 0.f;
-            for (int e = threadIdx.x; e < total; e += blockDim.x) {
-                int ax, idx, len; axis_of(e, H, W, C, ax, idx, len);
-                if (ax != a) continue;
-                const int j = idx + t - pad;
-                if (j >= 0 && j < len) acc += dz[e] * o[e - idx + j];
+                for (int t = 0; t < 7; ++t) {
+                    const int j = idx + t - pad;
+                    if (t < ks && j >= 0 && j < len) acc[6 + a * 7 + t] += dze * o[e - idx + j];
+                }
             }
-            acc = block_sum(acc, red);
-            if (threadIdx.x == 0) dks[a * 8 + t] = acc;
+    }
+    __shared__ float part[16][27];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < 27; ++i) { const float v = wave_sum(acc[i]); if (lane == 0) part[wv][i] = v; }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        float v = 0.f;
+        for (int w = 0; w < nw; ++w) v += part[w][threadIdx.x];
+        const int i = threadIdx.x;
+        if (i < 6) {
+            const float sg = sigm(gp.w[i >> 1][i & 1]);
+            dwts[i] = v * sg * (1.f - sg);
+        } else {
+            const int a = (i - 6) / 7, t = (i - 6) % 7;
+            if (t < gp.ks[a]) dks[a * 8 + t] = v;
         }
     }
 }
@@ -386,7 +402,7 @@ extern "C" int egm_mca_reduce(int dtype, int mode, const void* a, int lda, const
         else hipLaunchKernelGGL((mca_reduce_row_kernel<T, 1>), dim3(H, N), dim3(256), 0, st, (const T*)a, lda, (const T*)b, ldb, sums, colp,
                                 chp, H, W, C);
     });
-    hipLaunchKernelGGL(mca_reduce_h_kernel, dim3(stream_grid((long long)N * (W + C) * 2)), dim3(256), 0, st, colp, chp, sums, N, H, W, C);
+    hipLaunchKernelGGL(mca_reduce_h_kernel, dim3(((W + C) * 2 + 15) / 16, N), dim3(256), 0, st, colp, chp, sums, N, H, W, C);
     EGM_CHECK_LAUNCH("mca_reduce");
     return EGM_OK;
 }
