@@ -114,13 +114,18 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__
 __global__ void loss_finalize_kernel(float* partials, int nblk, int N, int C, long long HW, int dice,
                                      float* __restrict__ loss, float* __restrict__ stats) {
     const int K = 5 + 3 * C;
-    // one thread per (n, k): fixed-order double sum over blocks
-    for (int i = threadIdx.x; i < N * K; i += blockDim.x) {
+    // one wave per (n, k) item: lanes stride over the blocks, fixed-order butterfly in double
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int i = wv; i < N * K; i += nw) {
         const int n = i / K, k = i - n * K;
         double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += (double)partials[((long long)n * nblk + b) * K + k];
-        if (k >= 5) stats[(long long)n * 3 * C + (k - 5)] = (float)s;
-        else partials[(long long)n * nblk * K + k] = (float)s;   // stash per-image scalar in block 0's slot (same thread wrote/read it)
+        for (int b = lane; b < nblk; b += 64) s += (double)partials[((long long)n * nblk + b) * K + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) {
+            if (k >= 5) stats[(long long)n * 3 * C + (k - 5)] = (float)s;
+            else partials[(long long)n * nblk * K + k] = (float)s;   // stash per-image scalar in block 0's slot
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -420,7 +425,7 @@ extern "C" int egm_loss_fwd(const float* logits, const long long* target, const 
     float* stats = workspace + (long long)N * kLossBlocksPerImage * K;
     hipLaunchKernelGGL(loss_fwd_kernel, dim3(kLossBlocksPerImage, N), dim3(256), 0, (hipStream_t)s, logits, target, class_weight, C, H, W,
                        ignore_index, dice, partials, signs);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, partials, kLossBlocksPerImage, N, C, (long long)H * W,
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, partials, kLossBlocksPerImage, N, C, (long long)H * W,
                        dice, loss6, stats);
     EGM_CHECK_LAUNCH("loss_fwd");
     return EGM_OK;

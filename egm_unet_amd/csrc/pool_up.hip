@@ -314,13 +314,19 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_param_kernel(const T* __restr
     }
 }
 // out[blk][11][C] -> dw[C][9], db[C], per-channel dscale terms tmp[C]; one thread per (k, c), fixed-order sum over blocks
-__global__ void dwconv3_bwd_finish_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ dw, float* __restrict__ db,
-                                          float* __restrict__ tmp) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 11 * C) return;
+// block = 64 consecutive outputs x 4 block-lanes (each sums a quarter of the partial blocks), combined in fixed order
+__global__ __launch_bounds__(256) void dwconv3_bwd_finish_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ dw,
+                                                                 float* __restrict__ db, float* __restrict__ tmp) {
+    __shared__ double red[256];
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), bl = threadIdx.x >> 6;
     const int k = i / C, c = i - k * C;
     double v = 0.0;
-    for (int bk = 0; bk < nblk; ++bk) v += (double)part[((long long)bk * 11 + k) * C + c];
+    if (i < 11 * C)
+        for (int bk = bl; bk < nblk; bk += 4) v += (double)part[((long long)bk * 11 + k) * C + c];
+    red[threadIdx.x] = v;
+    __syncthreads();
+    if (bl != 0 || i >= 11 * C) return;
+    v = red[threadIdx.x] + red[64 + threadIdx.x] + red[128 + threadIdx.x] + red[192 + threadIdx.x];
     if (k < 9) dw[c * 9 + k] = (float)v;
     else if (k == 9) { if (db) db[c] = (float)v; }
     else tmp[c] = (float)v;
@@ -474,7 +480,7 @@ extern "C" int egm_dwconv3_fwd(int dtype, const void* x, int ldx, const float* w
 static int dw_blocks(long long npix, int C) {
     const int rows = 256 / (C >> 3);
     long long b = (npix + rows - 1) / rows;
-    if (b > 64) b = 64;
+    if (b > 256) b = 256;
     return (int)(b < 1 ? 1 : b);
 }
 extern "C" long long egm_dwconv3_bwd_workspace(int N, int H, int W, int C) {
@@ -497,7 +503,7 @@ extern "C" int egm_dwconv3_bwd(int dtype, const void* x, int ldx, const void* dy
                            (const T*)dy, lddy, w, b, scale, (float*)workspace, N, H, W, C);
     });
     float* tmp = (float*)workspace + (long long)nb * 11 * C;
-    hipLaunchKernelGGL(dwconv3_bwd_finish_kernel, dim3((11 * C + 255) / 256), dim3(256), 0, (hipStream_t)s, (const float*)workspace, nb, C, dw,
+    hipLaunchKernelGGL(dwconv3_bwd_finish_kernel, dim3((11 * C + 63) / 64), dim3(256), 0, (hipStream_t)s, (const float*)workspace, nb, C, dw,
                        db, tmp);
     hipLaunchKernelGGL(dwconv3_bwd_scale_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, tmp, C, dscale);
     EGM_CHECK_LAUNCH("dwconv3_bwd");
