@@ -99,10 +99,13 @@ class KernelTimer:
                 KH, KW = args[14:16]
                 flops = 2.0 * N * H * W * Cin * Cout * KH * KW
                 key = f"egm_conv_wgrad[{KH}x{KW}]"
-            a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
+            a = agg.setdefault(key, [0, 0.0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += flops
             if flops:
-                a[3] += 2.0 * (N * H * W * (Cin + Cout) + KH * KW * Cin * Cout)      # bf16 in + out + weights, once each
+                byts = 2.0 * (N * H * W * (Cin + Cout) + KH * KW * Cin * Cout)        # bf16 in + out + weights, once each
+                a[3] += byts
+                # per-launch roofline time: the layer is bound by whichever of MFMA peak and HBM peak takes longer
+                a[4] += 1e3 * max(flops / (MFMA_BF16_PEAK_TFLOPS * 1e12), byts / (HBM_PEAK_GBS * 1e9))
         return agg
 
 
@@ -272,7 +275,10 @@ def main():
                     "unit": "TFLOP/s", "frac": round(achieved / (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3), 4),
                     "traffic": traffic, "kernel": dom_key, "algorithmic_bytes_per_launch": round(dom[3] / dom[0]), "launches_per_step": dom[0],
                     "avg_launch_ms": round(dom[1] / dom[0], 4), "algorithmic_gflop_per_launch": round(dom[2] / dom[0] / 1e9, 3),
-                    "share_of_step_kernel_time": round(dom[1] / total_ms, 3)}
+                    "share_of_step_kernel_time": round(dom[1] / total_ms, 3),
+                    # sum over the launches of min(MFMA, HBM)-roofline time / measured time: the high-resolution layers of this
+                    # U-Net are HBM-bound (AI 144-192 FLOP/B < ridge ~310), so "frac" vs the MFMA peak understates them
+                    "frac_of_per_layer_roofline": round(dom[4] / dom[1], 4) if args.dtype == "bf16" else None}
         top = sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]
         print(f"[bench] host enqueue {1e3 * t_enqueue / args.steps:.2f} ms/step vs wall {1e3 * elapsed / args.steps:.2f} ms/step", file=sys.stderr)
         print("[bench] kernel time by C-ABI entry (instrumented step, ms): " +

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch from two rocprofv3 counter-collection runs of the same command (one --pmc FETCH_SIZE, one --pmc
+WRITE_SIZE; never combined with tracing flags).  FETCH_SIZE is doubled (gfx950: 128-B requests tallied at 64 B for 16-B/lane
+streaming reads, /opt/skills/guides/MI355X_MICROARCH.md, HBM section); WRITE_SIZE is used as reported.  Both are in KB.
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+import collections
+import csv
+import json
+import re
+import sys
+
+FAMILIES = [
+    ("conv_fwd[3x3] (conv_igemm_pipe_kernel<*,3,3,*>)", re.compile(r"conv_igemm_pipe_kernel<\d+, 3, 3, \d+>")),
+    ("conv_fwd[1x1] (conv_igemm_pipe_kernel<*,1,1,*>)", re.compile(r"conv_igemm_pipe_kernel<\d+, 1, 1, \d+>")),
+    ("conv_wgrad[3x3] (conv_wgrad_kernel<bf16,9>)", re.compile(r"conv_wgrad_kernel<.*bf16_t, 9>")),
+    ("conv_wgrad[1x1] (conv_wgrad_kernel<bf16,1>)", re.compile(r"conv_wgrad_kernel<.*bf16_t, 1>")),
+    ("bn_act_bwd_apply", re.compile(r"bn_act_bwd_apply_kernel")),
+    ("bn_act_bwd_reduce (channel_partials_kernel<bf16,1>)", re.compile(r"channel_partials_kernel<.*bf16_t, 1>")),
+    ("bn_act_fwd", re.compile(r"bn_act_fwd_kernel")),
+    ("wgrad_reduce_multi", re.compile(r"wgrad_reduce_multi_kernel")),
+]
+
+
+def collect(path, counter):
+    tot, cnt = collections.Counter(), collections.Counter()
+    for r in csv.DictReader(open(path)):
+        if r.get("Counter_Name") != counter:
+            continue
+        for fam, rx in FAMILIES:
+            if rx.search(r["Kernel_Name"]):
+                tot[fam] += float(r["Counter_Value"]); cnt[fam] += 1
+                break
+    return tot, cnt
+
+
+def main():
+    f_tot, f_cnt = collect(sys.argv[1], "FETCH_SIZE")
+    w_tot, w_cnt = collect(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for fam, _ in FAMILIES:
+        if not f_cnt[fam] or not w_cnt[fam]:
+            continue
+        fetch_kb, write_kb = f_tot[fam] / f_cnt[fam], w_tot[fam] / w_cnt[fam]
+        out[fam] = {"launches_in_trace": f_cnt[fam], "fetch_kb_raw": round(fetch_kb, 1), "write_kb": round(write_kb, 1),
+                    "hbm_bytes_per_launch_corrected": int(round((2.0 * fetch_kb + write_kb) * 1024))}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
