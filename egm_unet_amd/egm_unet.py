@@ -203,6 +203,43 @@ class EdgeEnhancedGRFB(nn.Module):
         return ops.gate3(o_b, t)                                                # out*(1 + mean_c sigmoid(t))
 
 
+class GRFB(nn.Module):
+    """The plain receptive-field block the edge-enhanced one grew out of (src/EGM-UNet.py:977-1023): three dilated branches on
+    the raw input, 1x1 `ConvLinear` over cat(x, branches), relu(out*scale + shortcut).  Kept as the block-level ablation twin."""
+
+    def __init__(self, in_channels, out_channels, stride=1, scale=0.1, visual=12):
+        super().__init__()
+        self.scale = scale
+        self.out_channels = out_channels
+        i = in_channels // 8
+        self.branch0 = nn.Sequential(
+            BasicConv(in_channels, 2 * i, 1, stride),
+            BasicConv(2 * i, 2 * i, 3, 1, padding=visual, dilation=visual, relu=False),
+            BasicConv(2 * i, 2 * i, 1, stride))
+        self.branch1 = nn.Sequential(
+            BasicConv(in_channels, i, 1, 1),
+            BasicConv(i, 2 * i, (3, 3), stride, padding=(1, 1), groups=i),
+            BasicConv(2 * i, 2 * i, 1, stride),
+            BasicConv(2 * i, 2 * i, 3, 1, padding=2 * visual, dilation=2 * visual, relu=False),
+            BasicConv(2 * i, 2 * i, 1, 1))
+        self.branch2 = nn.Sequential(
+            BasicConv(in_channels, i, 1, 1),
+            BasicConv(i, 2 * i, 3, 1, padding=1, groups=i),
+            BasicConv(2 * i, 2 * i, 1, stride),
+            BasicConv(2 * i, 2 * i, 3, stride, padding=1, groups=2 * i),
+            BasicConv(2 * i, 2 * i, 1, stride),
+            BasicConv(2 * i, 2 * i, 3, 1, padding=3 * visual, dilation=3 * visual, relu=False),
+            BasicConv(2 * i, 2 * i, 1, stride))
+        self.ConvLinear = BasicConv(14 * i, out_channels, 1, 1, relu=False)
+        self.shortcut = BasicConv(in_channels, out_channels, 1, stride, relu=False)
+        self.relu = nn.ReLU(inplace=False)
+
+    def forward(self, x):
+        x_cat, x0, x1, x2, x_sc = ops.fork(x, 5)
+        cat = ops.cat_channels([x_cat, self.branch0(x0), self.branch1(x1), self.branch2(x2)])
+        return ops.scale_add_relu(self.ConvLinear(cat), self.scale, self.shortcut(x_sc))     # relu(out*scale + short)
+
+
 # --------------------------------------------------------------------------------------------------------------
 # RecursiveGatedAttention (src/EGM-UNet.py:458-547)
 # --------------------------------------------------------------------------------------------------------------

@@ -158,6 +158,28 @@ def edge_grfb(state: State, p: str, x, train: bool, scale: float = 0.1, visual: 
     return out * (1 + t.mean(dim=1, keepdim=True))
 
 
+def plain_grfb(state: State, p: str, x, train: bool, scale: float = 0.1, visual: int = 12):
+    """GRFB without the edge machinery (src/EGM-UNet.py:977-1023), the block-level ablation twin."""
+    i = x.shape[1] // 8
+    b0 = basic_conv(state, p + ".branch0.0", x, train)
+    b0 = basic_conv(state, p + ".branch0.1", b0, train, padding=visual, dilation=visual, relu=False)
+    b0 = basic_conv(state, p + ".branch0.2", b0, train)
+    b1 = basic_conv(state, p + ".branch1.0", x, train)
+    b1 = basic_conv(state, p + ".branch1.1", b1, train, padding=1, groups=i)
+    b1 = basic_conv(state, p + ".branch1.2", b1, train)
+    b1 = basic_conv(state, p + ".branch1.3", b1, train, padding=2 * visual, dilation=2 * visual, relu=False)
+    b1 = basic_conv(state, p + ".branch1.4", b1, train)
+    b2 = basic_conv(state, p + ".branch2.0", x, train)
+    b2 = basic_conv(state, p + ".branch2.1", b2, train, padding=1, groups=i)
+    b2 = basic_conv(state, p + ".branch2.2", b2, train)
+    b2 = basic_conv(state, p + ".branch2.3", b2, train, padding=1, groups=2 * i)
+    b2 = basic_conv(state, p + ".branch2.4", b2, train)
+    b2 = basic_conv(state, p + ".branch2.5", b2, train, padding=3 * visual, dilation=3 * visual, relu=False)
+    b2 = basic_conv(state, p + ".branch2.6", b2, train)
+    out = basic_conv(state, p + ".ConvLinear", torch.cat([x, b0, b1, b2], dim=1), train, relu=False)
+    return F.relu(out * scale + basic_conv(state, p + ".shortcut", x, train, relu=False))
+
+
 # --------------------------------------------------------------------------- #
 # RecursiveGatedAttention, order 2 (src/EGM-UNet.py:458-547)
 # --------------------------------------------------------------------------- #

@@ -49,6 +49,15 @@ def test_edge_grfb_fixture(name, c):
     run_block(m, fx, 1, grad_tol=dict(rtol=5e-3, atol=5e-4))
 
 
+def test_plain_grfb_fixture():
+    """Block-level ablation twin src/EGM-UNet.py:977-1023 (incl. the depthwise groups=2i conv) against its own fixture."""
+    from egm_unet_amd.egm_unet import GRFB
+    fx = load_fixture("plain_grfb_c64")
+    m = GRFB(64, 64, stride=1, scale=0.1, visual=12)
+    load_module_state(m, fx)
+    run_block(m, fx, 1, grad_tol=dict(rtol=5e-3, atol=5e-4))
+
+
 def test_rga_fixture():
     from egm_unet_amd.egm_unet import RecursiveGatedAttention
     fx = load_fixture("rga_d64")

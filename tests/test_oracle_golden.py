@@ -190,3 +190,14 @@ def test_yuan_twin_without_mca():
     for k, v in fx.items():
         if k.startswith("grad/"):
             assert_close(st[k[5:]].grad, v, rtol=5e-3, atol=5e-4, what=k)
+
+
+def test_plain_grfb_block():
+    """Block-level ablation twin (src/EGM-UNet.py:977-1023)."""
+    fx = load_fixture("plain_grfb_c64")
+    st = fixture_state(fx, prefix="m")
+    x = torch.from_numpy(fx["in0"]).requires_grad_(True)
+    out = R.plain_grfb(st, "m", x, True)
+    assert_close(out.detach(), fx["out"], what="plain grfb out", **TOL)
+    (out * torch.from_numpy(fx["gout"])).sum().backward()
+    assert_close(x.grad, fx["gin0"], rtol=5e-3, atol=5e-4, what="gin")

@@ -236,6 +236,12 @@ def main():
         lrs.append(sched_opt.param_groups[0]["lr"]); sched_opt.step(); sch.step()
     np.savez_compressed(os.path.join(OUT, "lr_schedule.npz"), lrs=np.array(lrs))
 
+    # ---- block-level ablation twin: the plain GRFB (own generator, so the fixtures above keep their values) ----
+    g2 = torch.Generator().manual_seed(77)
+    torch.manual_seed(77)
+    m = egm.GRFB(64, 64, stride=1, scale=0.1, visual=12); randomize_bn(m, g2)
+    block_fixture("plain_grfb_c64", m, [torch.relu(torch.randn(2, 64, 40, 44, generator=g2))])
+
 
 if __name__ == "__main__":
     main()
