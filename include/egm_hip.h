@@ -324,6 +324,23 @@ int egm_sgd_multi(const void* table_dev, int ntensors, long long total_chunks, c
 /* table of {float* dst; const float* src; long long n;}: gradient bucket gather/scatter for the RCCL all-reduce. */
 int egm_copy_multi(const void* table_dev, int ntensors, egm_stream_t s);
 
+/* ---- device-side data path (transforms.py, my_dataset.py:118-132) ----------------------------------------------
+ * Decoded uint8 images [H][W][C] already in device memory.
+ * egm_resample_u8: one separable pass of Pillow's antialiased resize (F.resize -> Image.resize(BILINEAR), transforms.py:39):
+ *   axis 1: dst [H][out_size][C], axis 0: dst [out_size][W][C];  out = clip8((2^21 + sum_j src[b0+j] * coefs[o][j]) >> 22)
+ *   with bounds [out_size][2] = (b0, n) and coefs [out_size][ksize] int32 (22-bit fixed point) computed by the caller.
+ * egm_gather_u8: dst[y][x][c] = src[yidx[y]][xidx[x]][c]  (NEAREST resize of the mask, transforms.py:40).
+ * egm_augment_u8: hflip/vflip -> pad_if_smaller with zeros -> crop(top, left, crop_h, crop_w) -> to_tensor (/255) ->
+ *   normalize(mean, std) (transforms.py:46-107), written into an [out_h][out_w] collate slot: outside the crop the image is
+ *   0.0 and the target 255 (collate_fn).  out_img_chw fp32 [3][out_h][out_w], out_target int64 [out_h][out_w] (may be NULL with
+ *   mask_hw NULL).  mean3/std3 are HOST pointers (3 floats each). */
+int egm_resample_u8(const void* src, int H, int W, int C, void* dst, int axis, int out_size, const int* bounds, const int* coefs,
+                    int ksize, egm_stream_t s);
+int egm_gather_u8(const void* src, int H, int W, int C, void* dst, int Ho, int Wo, const int* yidx, const int* xidx, egm_stream_t s);
+int egm_augment_u8(const void* img_hwc3, const void* mask_hw, int H, int W, int hflip, int vflip, int top, int left, int crop_h,
+                   int crop_w, const float* mean3_host, const float* std3_host, float* out_img_chw, long long* out_target,
+                   int out_h, int out_w, egm_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif
