@@ -1,0 +1,220 @@
+// 1x1 and dilated convolutions without an activation tile in LDS.
+//
+// nn.Conv2d(k=1) (BasicConv / FusionConv / RGA / OutConv, src/EGM-UNet.py:171-187,223-234,952-956) and the dilated 3x3
+// BasicConvs of the receptive-field branches (dilation 12/24/36, :172,178,183) have no halo to share between neighbouring
+// pixels, so staging a pixel tile through LDS only adds two barriers per 32-channel chunk to a loop with 4-8 MFMAs in it.
+// Here every lane loads its pixel's 16-byte channel vectors from global memory straight into the MFMA B-operand layout
+// (lane (n, h) of v_mfma_f32_32x32x16_bf16 holds k = 8h..8h+7 of column n = one pixel's 8 consecutive channels), the weights
+// of the workgroup's cout tile sit in LDS for the whole launch (A operand), and a wave owns its 32-pixel block from the first
+// load to the store: the main loop has NO barrier.  Dilated taps are shifted pixel addresses with out-of-image lanes zeroed
+// (rows outside the image skip the tap for the whole block).  Epilogue as in conv_igemm.hip: +bias, bf16, wave-private LDS
+// transpose, 16-byte coalesced stores, per-group BatchNorm partial sums.
+//
+// HBM-bound for the narrow layers (C <= 64), MFMA-bound for 256 -> 256; algorithmic work as for conv_igemm.hip.
+#include "common.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+namespace {
+
+struct DirectParams {
+    const void* x; const void* w; const float* bias; void* y; float* stats;
+    int ldx, ldy, N, H, W, Cin, Cout, KH, KW, dil, bias_n;
+    int nblk, nct, G, wrow;      // 32-pixel blocks, cout tiles, pixel groups (workgroups per cout tile), LDS weight row bytes
+};
+
+__device__ __forceinline__ bf16x8_t as_frag(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_direct_kernel(DirectParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int OROW = NT * 64 + 16, NV = NT * 4;
+    const int b = blockIdx.x, q = b >> 3;
+    const int ct = q % p.nct;
+    const int grp = (q / p.nct) * 8 + (b & 7);                              // b % 8 == grp % 8: cout tiles of a group share an XCD
+    if (grp >= p.G) return;
+    const int co0 = ct * NT * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r31 = lane & 31, h = lane >> 5;
+    const bf16_t* __restrict__ xg = reinterpret_cast<const bf16_t*>(p.x);
+    const bf16_t* __restrict__ wg = reinterpret_cast<const bf16_t*>(p.w);
+    bf16_t* __restrict__ yg = reinterpret_cast<bf16_t*>(p.y);
+    const int ntaps = p.KH * p.KW, nks = (p.Cin + 15) >> 4, cvecs = p.Cin >> 3;
+    unsigned char* wts = smem;                                               // [ntaps][NT*32][wrow]
+    unsigned char* ot = smem + (size_t)ntaps * NT * 32 * p.wrow + wv * 32 * OROW;   // wave-private out tile
+
+    // ---- weights of this cout tile: staged once, zero rows past Cout, zero tail past Cin (the k-loop runs in steps of 16)
+    {
+        const int vec_per_row = nks * 2, total = ntaps * NT * 32 * vec_per_row;
+        for (int i = tid; i < total; i += 256) {
+            const int row = i / vec_per_row, cv = i - row * vec_per_row;
+            const int t = row / (NT * 32), j = row - t * (NT * 32), co = co0 + j;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (co < p.Cout && cv < cvecs) v = *reinterpret_cast<const uint4*>(wg + ((long long)t * p.Cout + co) * p.Cin + cv * 8);
+            *reinterpret_cast<uint4*>(wts + (size_t)row * p.wrow + cv * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    float ssum[8], ssq[8], bias8[8];
+    zero8(ssum); zero8(ssq);
+    const int cvo = lane % NV, slot = lane / NV;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int co = co0 + cvo * 8 + j; bias8[j] = (p.bias != nullptr && co < p.bias_n) ? p.bias[co] : 0.f; }
+    const long long npix = (long long)p.N * p.H * p.W;
+    const bool row_blocks = (p.W & 31) == 0;                                 // a 32-pixel block never straddles an image row
+    const unsigned char* arow = wts + (size_t)r31 * p.wrow + h * 16;
+
+    for (int blk = grp * 4 + wv; blk < p.nblk; blk += p.G * 4) {
+        const long long pix = (long long)blk * 32 + r31;
+        const bool pvalid = pix < npix;
+        int n, y, x;
+        {
+            const long long pp = pvalid ? pix : npix - 1;
+            const int hw = p.H * p.W;
+            n = (int)(pp / hw); const int rem = (int)(pp - (long long)n * hw);
+            y = rem / p.W; x = rem - y * p.W;
+        }
+        f32x16_t acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+
+        for (int t = 0; t < ntaps; ++t) {
+            const int sy = (t / p.KW - p.KH / 2) * p.dil, sx = (t % p.KW - p.KW / 2) * p.dil;
+            const int ys = y + sy, xs = x + sx;
+            if (row_blocks && (ys < 0 || ys >= p.H)) continue;               // uniform: the whole block's source row is outside
+            const bool ok = pvalid && ys >= 0 && ys < p.H && xs >= 0 && xs < p.W;
+            const bf16_t* src = xg + ((long long)(n * p.H + ys) * p.W + xs) * p.ldx + h * 8;
+            const unsigned char* at = arow + (size_t)t * NT * 32 * p.wrow;
+            for (int k0 = 0; k0 < nks; k0 += 8) {                            // up to 8 k-steps (128 channels) of loads in flight
+                uint4 fb[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    fb[k] = make_uint4(0, 0, 0, 0);
+                    if (ok && k0 + k < nks && (k0 + k) * 16 + h * 8 < p.Cin) fb[k] = *reinterpret_cast<const uint4*>(src + (k0 + k) * 16);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (k0 + k < nks) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(at + (size_t)nt * 32 * p.wrow + (k0 + k) * 32);
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, as_frag(fb[k]), acc[nt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue.  D layout: col (pixel) = lane&31, row (cout) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(acc[nt][gq * 4 + 0]) | ((uint32_t)f32_to_bf16(acc[nt][gq * 4 + 1]) << 16);
+                pk.y = (uint32_t)f32_to_bf16(acc[nt][gq * 4 + 2]) | ((uint32_t)f32_to_bf16(acc[nt][gq * 4 + 3]) << 16);
+                *reinterpret_cast<uint2*>(ot + r31 * OROW + (nt * 32 + gq * 8 + h * 4) * 2) = pk;
+            }
+        // read back whole channel vectors (same wave: LDS operations complete in order) and store coalesced
+#pragma unroll
+        for (int it = 0; it < NV / 2; ++it) {
+            const int pl = it * (64 / NV) + slot;
+            const long long po = (long long)blk * 32 + pl;
+            const int co = co0 + cvo * 8;
+            float v[8];
+            load8(reinterpret_cast<const bf16_t*>(ot + pl * OROW + cvo * 16), v);
+            if (po < npix && co < p.Cout) {
+                if (p.bias != nullptr) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<bf16_t>(v[j] + bias8[j]));
+                }
+                store8(yg + po * p.ldy + co, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
+            }
+        }
+    }
+
+    if (p.stats != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            for (int o = NV; o < 64; o <<= 1) { ssum[j] += __shfl_xor(ssum[j], o, 64); ssq[j] += __shfl_xor(ssq[j], o, 64); }
+        __syncthreads();                                        // every wave is done with the weights: reuse the front of LDS
+        float* red = reinterpret_cast<float*>(smem);            // [4 waves][2][NT*32]
+        if (lane < NV) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { red[(wv * 2 + 0) * NT * 32 + lane * 8 + j] = ssum[j]; red[(wv * 2 + 1) * NT * 32 + lane * 8 + j] = ssq[j]; }
+        }
+        __syncthreads();
+        if (tid < 2 * NT * 32) {
+            const int which = tid / (NT * 32), j = tid - which * NT * 32;
+            const int co = co0 + j;
+            if (co < p.Cout) {
+                float v = 0.f;
+                for (int w4 = 0; w4 < 4; ++w4) v += red[(w4 * 2 + which) * NT * 32 + j];
+                p.stats[((long long)grp * 2 + which) * p.Cout + co] = v;
+            }
+        }
+    }
+}
+
+template <int NT>
+int launch_direct(const DirectParams& p, size_t smem, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_direct: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    const int grid = ((p.G + 7) / 8) * 8 * p.nct;
+    hipLaunchKernelGGL((conv_direct_kernel<NT>), dim3(grid), dim3(256), smem, st, p);
+    EGM_CHECK_LAUNCH("conv_direct");
+    return EGM_OK;
+}
+
+}  // namespace
+
+// Planning shared with conv_igemm.hip's conv_plan(): returns 0 when this kernel does not take the shape.
+// On success *NT_out, *nct_out, *G_out describe the launch (G = stats tiles).
+int egm_conv_direct_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int* NT_out, int* nct_out, int* G_out,
+                         size_t* smem_out) {
+    if (dtype != EGM_BF16 || KH != KW) return 0;
+    if (!((KH == 1) || (KH == 3 && dil > 1))) return 0;
+    static const int mode = getenv("EGM_CONV_DIRECT") ? atoi(getenv("EGM_CONV_DIRECT")) : 3;   // debug knob: bit0 = 1x1, bit1 = dilated
+    if (!(mode & (KH == 1 ? 1 : 2))) return 0;
+    // Measured per shape against the LDS-tiled kernel (tools/conv_shapes_bench.py under rocprofv3): this kernel wins for the
+    // dilated convs (no tap shares a tile anyway) and for wide-in / narrow-out 1x1 (64->16, 112->16); square 1x1 layers
+    // (64->64 ... 256->256) stay with the tiled kernel, whose 64-byte-per-4-lanes loads coalesce better.
+    if (KH == 1 && !(Cout <= 16 && Cin >= 64)) return 0;
+    const long long npix = (long long)N * H * W;
+    const int nblk = (int)((npix + 31) / 32);
+    int NT = Cout <= 32 ? 1 : 2;
+    const int nks = (Cin + 15) / 16, wrow = nks * 32 + 16;
+    size_t smem = (size_t)KH * KW * NT * 32 * wrow + 4 * 32 * (NT * 64 + 16);
+    if (smem > 150 * 1024 && NT == 2) { NT = 1; smem = (size_t)KH * KW * NT * 32 * wrow + 4 * 32 * (NT * 64 + 16); }
+    if (smem > 150 * 1024) return 0;
+    const int nct = egm_cdiv(Cout, NT * 32);
+    // workgroups: enough waves to hide the global-load latency (no LDS staging to overlap with), at most one block per wave
+    const int per_cu = smem > 76 * 1024 ? 1 : (smem > 50 * 1024 ? 2 : (smem > 36 * 1024 ? 3 : 4));
+    int g = (256 * per_cu / nct) / 8 * 8;
+    if (g < 8) g = 8;
+    const int max_g = (nblk + 3) / 4;
+    if (g > max_g) g = max_g;
+    *NT_out = NT; *nct_out = nct; *G_out = g; *smem_out = smem;
+    return 1;
+}
+
+int egm_conv_direct_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, float* stats, int N, int H,
+                           int W, int Cin, int Cout, int KH, int KW, int dil, int NT, int nct, int G, size_t smem, egm_stream_t s) {
+    DirectParams p;
+    p.x = x; p.w = wf; p.bias = bias; p.y = y; p.stats = stats;
+    p.ldx = ldx; p.ldy = ldy; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.dil = (KH == 1) ? 1 : dil;
+    p.bias_n = bias ? bias_n : 0;
+    p.nblk = (int)(((long long)N * H * W + 31) / 32); p.nct = nct; p.G = G; p.wrow = ((Cin + 15) / 16) * 32 + 16;
+    return NT == 2 ? launch_direct<2>(p, smem, (hipStream_t)s) : launch_direct<1>(p, smem, (hipStream_t)s);
+}

@@ -28,6 +28,12 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
 
+// conv_direct.hip: 1x1 / dilated convolutions without an LDS activation tile
+int egm_conv_direct_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int* NT_out, int* nct_out, int* G_out,
+                         size_t* smem_out);
+int egm_conv_direct_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, float* stats, int N, int H,
+                           int W, int Cin, int Cout, int KH, int KW, int dil, int NT, int nct, int G, size_t smem, egm_stream_t s);
+
 namespace {
 
 constexpr int TH = 8, TW = 32, KC = 32;
@@ -670,11 +676,13 @@ int launch_pipe(ConvParams& p, int G, hipStream_t st) {
     return EGM_OK;
 }
 
-// One place decides tile shape and grouping, so the stats-tile count the caller allocates always matches the launch.
-struct ConvPlan { bool pipe; int R, NT, tiles_y, tiles_x, npt, nct, G; };
-ConvPlan conv_plan(int dtype, int N, int H, int W, int Cout, int KH, int KW, int dil) {
+// One place decides kernel, tile shape and grouping, so the stats-tile count the caller allocates always matches the launch.
+struct ConvPlan { bool pipe, direct; int R, NT, tiles_y, tiles_x, npt, nct, G; size_t smem; };
+ConvPlan conv_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil) {
     ConvPlan c;
     if (KH == 1 && KW == 1) dil = 1;
+    c.direct = Cin > 0 && egm_conv_direct_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.NT, &c.nct, &c.G, &c.smem) != 0;
+    if (c.direct) { c.pipe = false; c.R = 0; c.tiles_y = c.tiles_x = c.npt = 0; return c; }
     c.pipe = pipe_eligible(dtype, KH, KW, dil);
     c.R = 2;
     if (c.pipe && KH == 3 && dil == 1 && Cout <= 32) {
@@ -701,8 +709,8 @@ ConvPlan conv_plan(int dtype, int N, int H, int W, int Cout, int KH, int KW, int
 }
 }  // namespace
 
-extern "C" int egm_conv_stats_tiles(int dtype, int N, int H, int W, int Cout, int KH, int KW, int dil) {
-    return conv_plan(dtype, N, H, W, Cout, KH, KW, dil).G;
+extern "C" int egm_conv_stats_tiles(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil) {
+    return conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil).G;
 }
 
 extern "C" int egm_conv_pack(int dtype, const void* w, void* wf, void* wd, int Cout, int Cin, int KH, int KW, int groups,
@@ -744,7 +752,10 @@ extern "C" int egm_conv_fwd(int dtype, const void* x, int ldx, const void* wf, c
     ConvParams p;
     p.x = x; p.w = wf; p.bias = (const float*)bias; p.y = y; p.stats = stats;
     p.ldx = ldx; p.ldy = ldy; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.dil = dil; p.bias_n = bias ? bias_n : 0;
-    const ConvPlan c = conv_plan(dtype, N, H, W, Cout, KH, KW, dil);
+    const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil);
+    if (c.direct)
+        return egm_conv_direct_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, KH, KW, dil, c.NT, c.nct, c.G,
+                                      c.smem, s);
     p.tiles_y = c.tiles_y; p.tiles_x = c.tiles_x; p.npt = c.npt; p.nct = c.nct;
     const int NT = c.NT;
     if (c.pipe) {

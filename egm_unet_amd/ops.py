@@ -230,7 +230,7 @@ class _Conv2d(Function):
         y = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=x.device)
         stats = None
         if want_stats:
-            ntiles = lib().query("egm_conv_stats_tiles", dtype_code(x.dtype), N, H, W, CoutP, KH, KW, dil)
+            ntiles = lib().query("egm_conv_stats_tiles", dtype_code(x.dtype), N, H, W, CinP, CoutP, KH, KW, dil)
             stats = _f32((ntiles, 2, CoutP), x.device)
         b = bias.detach() if bias is not None else None
         lib().call("egm_conv_fwd", dtype_code(x.dtype), ptr(x), ldx, ptr(wf), ptr(b), Cout if b is not None else 0, ptr(y),

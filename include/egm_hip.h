@@ -66,7 +66,7 @@ int egm_conv_pack_multi(int dtype, const void* table_dev, int n, long long total
  * The data gradient is the same call on dy with wd (Cin/Cout swapped). */
 int egm_conv_fwd(int dtype, const void* x, int ldx, const void* wf, const void* bias_f32, int bias_n, void* y, int ldy,
                  float* stats, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, egm_stream_t s);
-int egm_conv_stats_tiles(int dtype, int N, int H, int W, int Cout, int KH, int KW, int dil);
+int egm_conv_stats_tiles(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
 /* Weight gradient: dw_oihw_f32 [CoutR][CinR/groups][KH][KW] (+)= sum_pixels dy (x) x.
  * Cin/Cout are padded counts of the activation buffers, CinR/CoutR the real (unpadded) ones.
  * workspace: egm_conv_wgrad_workspace() bytes.  accumulate != 0 adds to dw. */

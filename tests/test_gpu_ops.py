@@ -79,6 +79,11 @@ CONV_CASES = [
     (3, 250, 500, 40, 24, 3, 1, 1, True),
     (2, 250, 270, 32, 72, 3, 1, 1, True),
     (1, 512, 512, 8, 32, 3, 1, 1, False),
+    # LDS-free activation path (conv_direct.hip): wide-in / narrow-out 1x1, ragged and 32-aligned rows; dilated on aligned rows
+    (2, 40, 44, 112, 16, 1, 1, 1, True),
+    (2, 64, 64, 64, 10, 1, 1, 1, True),
+    (2, 64, 64, 64, 64, 3, 12, 1, False),
+    (1, 32, 32, 24, 40, 3, 24, 1, True),
 ]
 
 
