@@ -137,31 +137,62 @@ def cpu_baseline(seconds_budget=25.0):
             "sample": f"{len(times)} train steps (fwd+loss+bwd+SGD) of EGM-UNet(3,2,32) at bs 2x3x512x512 fp32 on the CPU oracle; best of steps after the first"}
 
 
-def clipseg_bench(args, dev, rank, world):
-    """BASELINE.json configs[3]: CLIPDensePredT('ViT-B/16', reduce_dim=64) forward on 352x352, synthetic fp16-rounded weights,
-    prompts encoded per call (uncached), bf16.  Replicas only (frozen backbone, no exchange)."""
-    from oracle import clip_ref as C                      # seeded synthetic weights (the reference ships none)
+def _seeded_clipseg(dev, dtype, seed=0):
+    """CLIPDensePredT('ViT-B/16', reduce_dim=64) with seeded random weights of the reference's architecture (it ships none)."""
     from egm_unet_amd.clipseg import CLIPDensePredT
     m = CLIPDensePredT(version="ViT-B/16", reduce_dim=64)
-    m.clip_model.load_state_dict(C.make_clip_state(seed=0))
-    m.load_state_dict(C.make_decoder_state(seed=0), strict=False)
-    m.to(dev).eval().set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
-    B = args.batch if args.batch != 8 else 32             # experiments/phrasecut.yaml batch size
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith(("ln_1.weight", "ln_2.weight", "ln_pre.weight", "ln_post.weight", "ln_final.weight", "norm1.weight", "norm2.weight")):
+                p.fill_(1.0)
+            elif p.dim() >= 2 or "embedding" in name:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            else:
+                p.zero_()
+    return m.to(dev).set_compute_dtype(torch.bfloat16 if dtype == "bf16" else torch.float32)
+
+
+def clipseg_bench(args, dev, rank, world):
+    """BASELINE.json configs[3]: CLIPDensePredT('ViT-B/16', reduce_dim=64) on 352x352, seeded synthetic weights, bf16.
+    clipseg_infer: forward with prompts encoded per call (uncached).  clipseg_train: frozen-backbone forward + decoder forward,
+    BCE-with-logits, decoder backward, AdamW (experiments/phrasecut.yaml, batch 64).  Replicas only (no exchange)."""
+    train = args.workload == "clipseg_train"
+    m = _seeded_clipseg(dev, args.dtype)
+    B = args.batch if args.batch != 8 else (64 if train else 32)      # experiments/phrasecut.yaml batch sizes
     x = torch.randn(B, 3, 352, 352, generator=torch.Generator().manual_seed(rank)).to(dev)
     prompts = ["a photo of a tactile paving."] * B
+    if train:
+        from egm_unet_amd.clip import train_ops as T
+        m.train()
+        opt = T.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+        target = (torch.rand(B, 1, 352, 352, generator=torch.Generator().manual_seed(100 + rank)) < 0.3).float().to(dev)
+        cond = m.compute_conditional(prompts)                         # prompts are constant across iterations: encoded once
+
+        def step():
+            loss = T.bce_with_logits(m(x, cond)[0], target)
+            opt.zero_grad(); loss.backward(); opt.step()
+    else:
+        m.eval()
+
+        def step():
+            m(x, prompts)
     for _ in range(args.warmup):
-        m(x, prompts)
+        step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        m(x, prompts)
+        step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if rank == 0:
-        print(json.dumps({"metric": "CLIPSeg inference images/sec at 3x352x352", "value": round(B * world * args.steps / el, 2), "unit": "images/s",
+        what = ("decoder training step (frozen ViT-B/16 forward + decoder fwd/bwd + BCE + AdamW)" if train
+                else "forward (text encoder uncached)")
+        print(json.dumps({"metric": f"CLIPSeg {'decoder training' if train else 'inference'} images/sec at 3x352x352",
+                          "value": round(B * world * args.steps / el, 2), "unit": "images/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-                          "config": {"workload": f"CLIPDensePredT ViT-B/16 rd64 forward, {B}x3x352x352 + {B} prompts (text encoder uncached)",
+                          "config": {"workload": f"CLIPDensePredT ViT-B/16 rd64 {what}, {B}x3x352x352 + {B} prompts",
                                      "global_batch": B * world, "parallelism": f"replicas x{world}"}}))
 
 
@@ -174,7 +205,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="egm_unet_train", choices=["egm_unet_train", "clipseg_infer"],
+    ap.add_argument("--workload", default="egm_unet_train", choices=["egm_unet_train", "clipseg_infer", "clipseg_train"],
                     help="egm_unet_train = the headline metric (BASELINE.json configs[1]); clipseg_infer = configs[3] (ViT-B/16 image+text "
                          "encode + decoder on 352x352), reported as a secondary line")
     ap.add_argument("--eager", action="store_true", help="issue every kernel from Python instead of replaying the captured hipGraph")
@@ -193,7 +224,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    if args.workload == "clipseg_infer":
+    if args.workload in ("clipseg_infer", "clipseg_train"):
         return clipseg_bench(args, dev, rank, world)
     from egm_unet_amd import GRFBUNet
     from egm_unet_amd._lib import lib, require_gpu

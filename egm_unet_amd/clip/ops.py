@@ -5,13 +5,19 @@ import torch
 from .._lib import dtype_code, lib, ptr, stream
 
 _cast_cache = {}
+_cast_generation = [0]
+
+
+def bump_cast_generation():
+    """Called by optimizers that update parameters through raw pointers (no torch version bump)."""
+    _cast_generation[0] += 1
 
 
 def cast_weight(w: torch.Tensor, dtype):
     """fp32 parameter -> contiguous matrix in the activation dtype (cached on storage + version)."""
     if dtype == torch.float32:
         return w.detach().contiguous()
-    key = (w.data_ptr(), w._version, dtype, tuple(w.shape))
+    key = (w.data_ptr(), w._version, _cast_generation[0], dtype, tuple(w.shape))
     hit = _cast_cache.get(id(w))
     if hit is not None and hit[0] == key:
         return hit[1]

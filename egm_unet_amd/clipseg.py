@@ -116,13 +116,52 @@ class CLIPDensePredT(nn.Module):
         h = O.linear(a, blk.linear1.weight, blk.linear1.bias, act=1)
         return O.layernorm(O.linear(h, blk.linear2.weight, blk.linear2.bias, residual=a), blk.norm2)
 
-    @torch.no_grad()
     def forward(self, inp_image, conditional=None, return_features=False, mask=None):
+        """models/clipseg.py:436-496.  eval(): inference path, no autograd.  train(): the decoder (reduces, FiLM, blocks, trans_conv)
+        is differentiable through the HIP autograd operators of clip/train_ops.py; the CLIP backbone stays frozen (:155-156).
+        nn.TransformerEncoderLayer's dropout (p=0.1 in the reference's train mode) is not applied."""
         assert type(return_features) == bool
         if mask is not None:
             raise ValueError("mask not supported")
-        if self.training:
-            raise NotImplementedError("egm_unet_amd: CLIPDensePredT runs the inference path only (call .eval())")
+        if self.training and torch.is_grad_enabled():
+            return self._forward_train(inp_image, conditional, return_features)
+        with torch.no_grad():
+            return self._forward_eval(inp_image, conditional, return_features)
+
+    def _encoder_layer_train(self, blk, a):
+        from .clip import train_ops as T
+        qkv = T.linear(a, blk.self_attn.in_proj_weight, blk.self_attn.in_proj_bias)
+        att = T.attention(qkv, self.n_heads)
+        a = T.layernorm(T.linear(att, blk.self_attn.out_proj.weight, blk.self_attn.out_proj.bias, residual=a), blk.norm1)
+        h = T.linear(a, blk.linear1.weight, blk.linear1.bias, act=1)
+        return T.layernorm(T.linear(h, blk.linear2.weight, blk.linear2.bias, residual=a), blk.norm2)
+
+    def _forward_train(self, inp_image, conditional, return_features):
+        from .clip import train_ops as T
+        dev = self.model.positional_embedding.device
+        x_inp = inp_image.to(dev)
+        bs = x_inp.shape[0]
+        with torch.no_grad():
+            cond = self.get_cond_vec(conditional, bs)
+            visual_q, activations, _ = self.visual_forward(x_inp, extract_layers=[0] + list(self.extract_layers))
+        dt, code = self.compute_dtype, dtype_code(self.compute_dtype)
+        acts = self._acts_bf[1:]
+        acts = acts[::-1] if not self.rev_activations else acts
+        condT = torch.empty(cond.shape, dtype=dt, device=dev)
+        lib().call("egm_cast_f32", code, ptr(cond.float().contiguous()), ptr(condT), cond.numel(), stream())
+        a = None
+        for i, (act, blk, red) in enumerate(zip(acts, self.blocks, self.reduces)):
+            a = T.linear(act.detach(), red.weight, red.bias, residual=a)
+            if i == self.cond_layer:
+                a = T.FilmFn.apply(a, T.linear(condT, self.film_mul.weight, self.film_mul.bias),
+                                   T.linear(condT, self.film_add.weight, self.film_add.bias))
+            a = self._encoder_layer_train(blk, a)
+        out = T.TransConvFn.apply(a, self.trans_conv.weight, self.trans_conv.bias)
+        if return_features:
+            return out, visual_q, cond, activations
+        return out,
+
+    def _forward_eval(self, inp_image, conditional=None, return_features=False):
         dev = self.model.positional_embedding.device
         x_inp = inp_image.to(dev)
         bs = x_inp.shape[0]

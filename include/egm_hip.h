@@ -341,6 +341,32 @@ int egm_augment_u8(const void* img_hwc3, const void* mask_hw, int H, int W, int 
                    int crop_w, const float* mean3_host, const float* std3_host, float* out_img_chw, long long* out_target,
                    int out_h, int out_w, egm_stream_t s);
 
+/* ---- CLIPSeg decoder training (models/clipseg.py:380-420,452-496; experiments/phrasecut.yaml:1-47) ------------------
+ * The backward matrix products run on egm_gemm over transposed copies (egm_transpose: dst[b][c][r] = src[b][r][c]).
+ * egm_relu_bwd: dst = g where out > 0.  egm_softmax_bwd_rows: dS = P*(dP - sum_j dP_j P_j)*alpha per row (P storage type,
+ * dP fp32).  egm_layernorm_bwd: dx and per-block partials [egm_layernorm_bwd_blocks(rows)][2][D] of (dbeta, dgamma) for
+ * egm_reduce_tiles.  egm_film_fwd/bwd: out = mul[b,:]*a + add[b,:] and its gradients.  egm_pixel_unshuffle: gradient of
+ * egm_pixel_shuffle (rows of the tok_off leading tokens are zero).  egm_bce_logits_*: nn.BCEWithLogitsLoss(mean).
+ * egm_adamw_multi: torch.optim.AdamW step over a device table of 40-byte {p, g, m, v, n} entries. */
+int egm_transpose(int dtype, const void* src, int rows, int cols, int ld_src, long long batch_stride_src, void* dst, int ld_dst,
+                  long long batch_stride_dst, int batch, egm_stream_t s);
+int egm_relu_bwd(int dtype, const void* g, const void* out, void* dst, long long n, egm_stream_t s);
+int egm_softmax_bwd_rows(int dtype, const void* P, int ldp, const float* dP, int lddp, void* dS, int ldds, long long rows, int L,
+                         float alpha, egm_stream_t s);
+int egm_layernorm_bwd_blocks(long long rows);
+int egm_layernorm_bwd(int dtype, const void* x, int ldx, const void* g, int ldg, const float* gamma, float eps, void* dx, int lddx,
+                      float* partials, long long rows, int D, egm_stream_t s);
+int egm_film_fwd(int dtype, const void* a, const void* mul, const void* add, void* out, int B, int L, int D, egm_stream_t s);
+int egm_film_bwd(int dtype, const void* g, const void* a, const void* mul, void* da, void* dmul, void* dadd, int B, int L, int D,
+                 egm_stream_t s);
+int egm_pixel_unshuffle(int dtype, const float* dout, void* dy, int B, int g, int P, int tok_off, int Ltot, egm_stream_t s);
+int egm_sum_f32(const float* x, long long n, float scale, float* partials, float* out, egm_stream_t s);
+int egm_bce_logits_fwd(const float* x, const float* t, long long n, float* partials, float* loss, egm_stream_t s);
+int egm_bce_logits_bwd(const float* x, const float* t, const float* grad_out, long long n, float* dx, egm_stream_t s);
+int egm_adamw_chunk(void);
+int egm_adamw_multi(const void* table_dev, int ntensors, long long total_chunks, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int step, egm_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -196,12 +196,12 @@ def _encoder_layer(s, p, x, n_heads):
     return _ln(s, p + ".norm2", x + h)
 
 
-def clipseg_forward(clip_s, dec_s, img, cond, extract_layers=(3, 6, 9), cond_layer=0, n_heads=4):
-    """CLIPDensePredT.forward with a [B, 512] conditional -> ([B, 1, H, W], visual_q, activations)."""
-    B = img.shape[0]
-    q, acts = visual_forward(clip_s, img, extract_layers=[0] + list(extract_layers))
+def clipseg_decoder(dec_s, acts, cond, cond_layer=0, n_heads=4):
+    """The trainable part of CLIPDensePredT.forward (models/clipseg.py:452-496): acts = extracted layer activations [B, L, 768]
+    in extraction order (shallow first, the forward walks them deepest first), cond [B, 512] -> [B, 1, H, W]."""
+    B = acts[0].shape[0]
     a = None
-    for i, act in enumerate(acts[1:][::-1]):
+    for i, act in enumerate(acts[::-1]):
         r = F.linear(act, dec_s[f"reduces.{i}.weight"], dec_s[f"reduces.{i}.bias"])
         a = r if a is None else r + a
         if i == cond_layer:
@@ -213,4 +213,10 @@ def clipseg_forward(clip_s, dec_s, img, cond, extract_layers=(3, 6, 9), cond_lay
     size = int(math.isqrt(a.shape[2]))
     a = a.reshape(B, a.shape[1], size, size)
     k = dec_s["trans_conv.weight"].shape[-1]
-    return F.conv_transpose2d(a, dec_s["trans_conv.weight"], dec_s["trans_conv.bias"], stride=k), q, acts
+    return F.conv_transpose2d(a, dec_s["trans_conv.weight"], dec_s["trans_conv.bias"], stride=k)
+
+
+def clipseg_forward(clip_s, dec_s, img, cond, extract_layers=(3, 6, 9), cond_layer=0, n_heads=4):
+    """CLIPDensePredT.forward with a [B, 512] conditional -> ([B, 1, H, W], visual_q, activations)."""
+    q, acts = visual_forward(clip_s, img, extract_layers=[0] + list(extract_layers))
+    return clipseg_decoder(dec_s, acts[1:], cond, cond_layer, n_heads), q, acts

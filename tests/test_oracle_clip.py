@@ -39,6 +39,29 @@ def test_clipseg_forward(states):
     assert_close(o224[:, :, 64:128, 64:128], fx["out224_crop"], rtol=1e-3, atol=1e-3, what="224 crop (no pos-emb resize)")
 
 
+def test_decoder_training_gradients_vs_reference(states):
+    """BCE-with-logits loss and decoder parameter gradients of the reference (eval mode, autograd on; clipseg_train.npz)."""
+    fx, tr = load_fixture("clipseg_fwd"), load_fixture("clipseg_train")
+    img = torch.from_numpy(fx["img"].astype(np.float32))
+    with torch.no_grad():
+        _, acts = C.visual_forward(states[0], img, extract_layers=[0, 3, 6, 9])
+    dec = {k: v.clone().requires_grad_(True) for k, v in states[1].items()}
+    out = C.clipseg_decoder(dec, acts[1:], torch.from_numpy(fx["cond"]))
+    target = (torch.rand(2, 1, 352, 352, generator=torch.Generator().manual_seed(int(tr["target_seed"]))) < 0.3).float()
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out, target)
+    loss.backward()
+    assert abs(float(loss) - float(tr["loss"])) < 2e-5
+    n = 0
+    for k in tr:
+        if k.startswith("norm/"):
+            name = k[5:]
+            g = dec[name].grad.flatten()
+            assert abs(float(g.norm()) - float(tr[k])) <= 2e-3 * float(tr[k]) + 1e-7, name
+            assert_close(g[:: max(1, g.numel() // 257)][:257], tr["probe/" + name], rtol=5e-3, atol=1e-6 + 5e-3 * float(tr[k]) / g.numel() ** 0.5, what=name)
+            n += 1
+    assert n == 48
+
+
 def test_decoder_state_keys_in_manifest(states):
     man = json.load(open(os.path.join(GOLDEN, "clipseg_manifest.json")))
     for k, v in states[1].items():

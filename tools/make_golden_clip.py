@@ -110,6 +110,25 @@ def main():
         d[f"act{i}_tok"] = a[:, 1:9].numpy()                # first 8 patch tokens
         d[f"act{i}_norm"] = a.norm().numpy()
     np.savez_compressed(os.path.join(OUT, "clipseg_fwd.npz"), **d)
+
+    # ---- decoder training step of the reference (eval mode = no dropout, autograd on): BCE-with-logits loss and parameter
+    # gradients (experiments/phrasecut.yaml: loss binary_cross_entropy_with_logits); probes + norms keep the fixture small
+    gt = torch.Generator().manual_seed(11)
+    target = (torch.rand(2, 1, 352, 352, generator=gt) < 0.3).float()
+    for p_ in m.parameters():
+        p_.grad = None
+    out_t = m(img, cond)[0]
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(out_t, target)
+    loss.backward()
+    tr = {"loss": loss.detach().numpy(), "target_seed": np.array(11)}
+    for name, p_ in m.named_parameters():
+        if p_.grad is None:
+            continue
+        gflat = p_.grad.flatten()
+        tr["norm/" + name] = gflat.norm().numpy()
+        tr["probe/" + name] = gflat[:: max(1, gflat.numel() // 257)][:257].numpy()
+    np.savez_compressed(os.path.join(OUT, "clipseg_train.npz"), **tr)
+    print("train fixture: loss", float(loss), "params with grad", sum(1 for k in tr if k.startswith("norm/")))
     print("clipseg out", tuple(out.shape), float(out.mean()), float(out.std()), "visual_q", float(visual_q.norm()))
 
 
