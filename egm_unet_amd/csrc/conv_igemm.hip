@@ -474,8 +474,10 @@ __global__ __launch_bounds__(256, (R * NT >= 8) ? 1 : 2) void conv_igemm_pipe_ke
                     }
                 }
             };
+            __builtin_amdgcn_s_setprio(1);                    // MFMA phase wins issue arbitration over a partner wave that is staging
             kstep(0);
             if (p.Cin - cur.c0 > 16) kstep(1);
+            __builtin_amdgcn_s_setprio(0);
         }
         EGM_TICK(3);
 #ifdef EGM_CONV_TIMING
