@@ -151,6 +151,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradParams p) {
         return pt;
     };
 
+#ifdef EGM_CONV_TIMING
+    long long tph[4] = {0, 0, 0, 0}; int nstages = 0;
+    long long tmark = __builtin_amdgcn_s_memtime();
+#define EGM_WTICK(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); tph[i] += t_ - tmark; tmark = t_; } while (0)
+#else
+#define EGM_WTICK(i) do { } while (0)
+#endif
     int n = 0, oy0 = 0, ox0 = 0;
     int pt = next_tile(split, n, oy0, ox0);
     if (PIPE && pt < p.npt) {
@@ -161,6 +168,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradParams p) {
     }
     while (pt < p.npt) {
         __syncthreads();                                              // previous tile's MFMAs done: LDS free
+        EGM_WTICK(0);
         if (PIPE) {
 #pragma unroll
             for (int k = 0; k < DYVEC; ++k) if (tid + k * 256 < ndy) *reinterpret_cast<uint4*>(dy_lds(tid + k * 256)) = pre_dy[k];
@@ -170,7 +178,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradParams p) {
             for (int i = tid; i < ndy; i += 256) *reinterpret_cast<uint4*>(dy_lds(i)) = load_dy(i, n, oy0, ox0);
             for (int i = tid; i < nx; i += 256) *reinterpret_cast<uint4*>(x_lds(i)) = load_x(i, n, oy0, ox0);
         }
+        EGM_WTICK(1);
         __syncthreads();
+        EGM_WTICK(0);
         int n2 = 0, oy2 = 0, ox2 = 0;
         const int pt2 = next_tile(pt + p.nsplit, n2, oy2, ox2);
         if (PIPE && pt2 < p.npt) {                                    // in flight during the MFMAs below
@@ -179,24 +189,47 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int k = 0; k < XVEC; ++k) pre_x[k] = load_x(tid + k * 256, n2, oy2, ox2);
         }
+        EGM_WTICK(2);
         // ---- MFMA: rows wc, wc+C, ... of the tile; k runs along the row
         const unsigned char* ablk = dyl + wa * (TH * TW) * RB;
         const unsigned char* bblk = xl + wb * (PH * PW) * RB;
-        for (int ry = wc; ry < TH; ry += p.C) {
-#pragma unroll 2
-            for (int k0 = 0; k0 < TW; k0 += M::kStep) {
-                const typename M::Frag fa = M::load(ablk, ry * TW + k0, lane);
+        // two fragment sets in flight: the LDS reads of k-step s+1 are issued before the MFMAs of k-step s (left alone the
+        // compiler funnels every tap's fragment through one register quad and waits lgkmcnt(0) before each MFMA)
+        static_assert(TW == 2 * M::kStep || sizeof(T) == 4, "two k-steps per tile row");
+        auto load_step = [&](int ry, int k0, typename M::Frag& fa, typename M::Frag (&fb)[NTAPS]) {
+            fa = M::load(ablk, ry * TW + k0, lane);
 #pragma unroll
-                for (int t = 0; t < NTAPS; ++t) {
-                    const int wr = t / WW, ws = t % WW;
-                    const typename M::Frag fb = M::load(bblk, (ry + wr) * PW + k0 + ws, lane);
-                    acc[t] = M::mma(fa, fb, acc[t]);
+            for (int t = 0; t < NTAPS; ++t) fb[t] = M::load(bblk, (ry + t / WW) * PW + k0 + t % WW, lane);
+        };
+        auto mma_step = [&](const typename M::Frag& fa, const typename M::Frag (&fb)[NTAPS]) {
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) acc[t] = M::mma(fa, fb[t], acc[t]);
+        };
+        if (sizeof(T) == 2) {
+            typename M::Frag fa0, fa1, fb0[NTAPS], fb1[NTAPS];
+            if (wc < TH) load_step(wc, 0, fa0, fb0);
+            for (int ry = wc; ry < TH; ry += p.C) {
+                load_step(ry, M::kStep, fa1, fb1);
+                mma_step(fa0, fb0);
+                if (ry + p.C < TH) load_step(ry + p.C, 0, fa0, fb0);
+                mma_step(fa1, fb1);
+            }
+        } else {
+            for (int ry = wc; ry < TH; ry += p.C) {
+#pragma unroll 2
+                for (int k0 = 0; k0 < TW; k0 += M::kStep) {
+                    typename M::Frag fa, fb[NTAPS];
+                    load_step(ry, k0, fa, fb);
+                    mma_step(fa, fb);
                 }
             }
         }
+        EGM_WTICK(3);
+#ifdef EGM_CONV_TIMING
+        ++nstages;
+#endif
         pt = pt2; n = n2; oy0 = oy2; ox0 = ox2;
     }
-
     // ---- reduce the C pixel-row waves of each (wa, wb) pair through LDS (fixed order), then one slab per workgroup
     for (int r = 1; r < p.C; ++r) {
         __syncthreads();
@@ -230,6 +263,13 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradParams p) {
             }
         }
     }
+#ifdef EGM_CONV_TIMING
+    __syncthreads();
+    if (tid == 0 && blockIdx.y == 0 && blockIdx.z == 0) {       // debug build: phase totals of wave 0 overwrite the first slab floats
+        for (int i = 0; i < 4; ++i) p.slab[(long long)split * 8 + i] = (float)tph[i];
+        p.slab[(long long)split * 8 + 4] = (float)nstages;
+    }
+#endif
 }
 
 // sum slabs in fixed order and scatter to fp32 OIHW (real, possibly grouped, shape).
