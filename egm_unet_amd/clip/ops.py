@@ -81,6 +81,12 @@ def attention(qkv, n_heads, mode):
     dh = D // n_heads
     Lp = (L + 7) // 8 * 8
     dt, dev = qkv.dtype, qkv.device
+    if dt == torch.bfloat16 and dh == 64 and qkv.is_contiguous():
+        # fused path: scores and probabilities stay on chip (csrc/vit.hip attention_fused_kernel)
+        out = torch.empty((B, L, D), dtype=dt, device=dev)
+        lib().call("egm_attention_fused", dtype_code(dt), ptr(qkv), D3, B, L, n_heads, dh, {"full": 0, "causal": 1, "csa": 2}[mode], ptr(out), D,
+                   stream())
+        return out
     S = torch.empty((B * n_heads, L, Lp), dtype=torch.float32, device=dev)
     P = torch.empty((B * n_heads, L, Lp), dtype=dt, device=dev)
     scale = dh ** -0.5

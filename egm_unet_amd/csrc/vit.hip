@@ -146,6 +146,239 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
 }
 
+// ---- bf16 C = act(alpha * A * B^T + bias) + R for the large products (every nn.Linear of the encoders / decoder, q k^T) ---------
+// Workgroup tile 128 x 128, K chunks of 64; waves 2 x 2, each owning 64 x 64 = 2 x 2 MFMA tiles (64 accumulator registers).
+// Global -> register prefetch of chunk c+1 is issued before the MFMAs of chunk c and written to LDS after them; inside a chunk
+// the fragments of k-step s+1 are read from LDS before the MFMAs of k-step s (two fragment sets).  LDS rows are 128 B of k + 16 B
+// pad (conflict-free ds_read_b128, see conv_igemm.hip).  16 MFMAs per wave between barriers instead of 4 in gemm_kernel.
+__global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BK = 64, ROW = BK * 2 + 16, NV = BK / 8;             // 8 vectors of 8 bf16 per row
+    unsigned char* As = smem;                                          // [128][ROW]
+    unsigned char* Bs = smem + 128 * ROW;                              // [128][ROW]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r31 = lane & 31, h = lane >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int b1 = blockIdx.z / p.nb2, b2 = blockIdx.z - b1 * p.nb2;
+    const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A) + b1 * p.sA1 + b2 * p.sA2;
+    const bf16_t* __restrict__ B = reinterpret_cast<const bf16_t*>(p.B) + b1 * p.sB1 + b2 * p.sB2;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // staging slots: vector i = tid + 256 s -> row i / 8, k-vector i % 8 (4 slots for A, 4 for B)
+    const int srow = tid >> 3, sv = tid & 7;
+    uint4 pa[4], pb[4];
+    auto issue = [&](int k0) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int row = srow + 32 * s2, k = k0 + sv * 8;
+            pa[s2] = make_uint4(0, 0, 0, 0); pb[s2] = make_uint4(0, 0, 0, 0);
+            if (m0 + row < p.M && k < p.K) pa[s2] = *reinterpret_cast<const uint4*>(A + (long long)(m0 + row) * p.lda + k);
+            if (n0 + row < p.N && k < p.K) pb[s2] = *reinterpret_cast<const uint4*>(B + (long long)(n0 + row) * p.ldb + k);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            *reinterpret_cast<uint4*>(As + (srow + 32 * s2) * ROW + sv * 16) = pa[s2];
+            *reinterpret_cast<uint4*>(Bs + (srow + 32 * s2) * ROW + sv * 16) = pb[s2];
+        }
+    };
+    const unsigned char* arow = As + (wm * 64 + r31) * ROW + h * 16;
+    const unsigned char* brow = Bs + (wn * 64 + r31) * ROW + h * 16;
+    auto frags = [&](int ks, bf16x8_t (&fa)[2], bf16x8_t (&fb)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa[i] = *reinterpret_cast<const bf16x8_t*>(arow + i * 32 * ROW + ks * 32);
+            fb[i] = *reinterpret_cast<const bf16x8_t*>(brow + i * 32 * ROW + ks * 32);
+        }
+    };
+    auto mmas = [&](const bf16x8_t (&fa)[2], const bf16x8_t (&fb)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+
+    issue(0);
+    for (int k0 = 0; k0 < p.K; k0 += BK) {
+        __syncthreads();                                               // previous chunk's fragment reads are done
+        commit();
+        __syncthreads();
+        if (k0 + BK < p.K) issue(k0 + BK);                             // in flight during the MFMAs below
+        bf16x8_t fa0[2], fb0[2], fa1[2], fb1[2];
+        frags(0, fa0, fb0);
+        __builtin_amdgcn_s_setprio(1);
+        frags(1, fa1, fb1); mmas(fa0, fb0);
+        frags(2, fa0, fb0); mmas(fa1, fb1);
+        frags(3, fa1, fb1); mmas(fa0, fb0);
+        mmas(fa1, fb1);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    // epilogue: col (n) = lane&31, row (m) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const long long coff = b1 * p.sC1 + b2 * p.sC2, roff = b1 * p.sR1 + b2 * p.sR2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + r31;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m >= p.M) continue;
+                float v = gemm_act(p.alpha * acc[i][j][e] + bv, p.act);
+                if (p.R) v += to_f32(reinterpret_cast<const bf16_t*>(p.R)[roff + (long long)m * p.ldr + n]);
+                if (p.c_f32) reinterpret_cast<float*>(p.C)[coff + (long long)m * p.ldc + n] = v;
+                else reinterpret_cast<bf16_t*>(p.C)[coff + (long long)m * p.ldc + n] = from_f32<bf16_t>(v);
+            }
+    }
+}
+
+// ---- fused multi-head attention (bf16, head dim 64): scores never leave the chip --------------------------------------------
+//   MODE 0: softmax(q k^T s) v      (nn.MultiheadAttention, clip/model.py:173-206)
+//   MODE 1: causal                   (text encoder, clip/model.py:462-468)
+//   MODE 2: CSA  (softmax(q q^T s) + softmax(k k^T s)) v      (models/clipseg.py:96-102, all 12 visual layers)
+// One workgroup = 128 queries of one (batch, head): wave w owns 32 queries, ONE query per lane column.  Keys stream through LDS in
+// blocks of 64 (X = the key-side matrix row-major, V transposed).  The score tile is computed TRANSPOSED (A = keys, B = queries),
+// so a lane holds 16 keys of its own query: the online-softmax row statistics are in-lane reductions plus one exchange between
+// the two half-waves, and the probabilities already sit in the B-operand layout of the P V product -- the k-slots of that MFMA are
+// simply numbered in the order the score tile delivers them (key = 4h + (j&3) + 8(j>>2) inside a 16-key step), and V^T fragments
+// are read from LDS with the same numbering (two 8-byte reads).  No score / probability tensor in HBM, no LDS transpose of P.
+template <int MODE>
+__global__ __launch_bounds__(256) void attention_fused_kernel(const bf16_t* __restrict__ qkv, int ld, int L, int H, int D, bf16_t* __restrict__ out,
+                                                              int ldo, float scale_log2e) {
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[64 * 144];       // [key][64 d] + pad
+    __shared__ __attribute__((aligned(16))) unsigned char Vt[64 * 144];       // [d][64 keys] + pad
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r31 = lane & 31, hq = lane >> 5;
+    const int b = blockIdx.y / H, hh = blockIdx.y - b * H;
+    const int qblk0 = blockIdx.x * 128, query = qblk0 + wv * 32 + r31;
+    const bf16_t* base = qkv + (long long)b * L * ld + hh * 64;
+    const int nterms = MODE == 2 ? 2 : 1;
+    const int Lk = MODE == 1 ? min(L, qblk0 + 128) : L;                        // causal: no key beyond the block's last query
+    f32x16_t otot[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) otot[t][e] = 0.f;
+
+    for (int term = 0; term < nterms; ++term) {
+        const int qoff = (MODE == 2 && term == 1) ? D : 0;
+        const int koff = MODE == 2 ? (term == 0 ? 0 : D) : D;
+        bf16x8_t fq[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (query < L) v = *reinterpret_cast<const uint4*>(base + (long long)query * ld + qoff + ks * 16 + hq * 8);
+            fq[ks] = __builtin_bit_cast(bf16x8_t, v);
+        }
+        float m = -INFINITY, l = 0.f;
+        f32x16_t acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+        for (int key0 = 0; key0 < Lk; key0 += 64) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {                                      // 64 keys x 8 vectors of X and of V
+                const int i = tid + 256 * j, key = i >> 3, v = i & 7;
+                uint4 xv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+                if (key0 + key < L) {
+                    const bf16_t* row = base + (long long)(key0 + key) * ld;
+                    xv = *reinterpret_cast<const uint4*>(row + koff + v * 8);
+                    vv = *reinterpret_cast<const uint4*>(row + 2 * D + v * 8);
+                }
+                *reinterpret_cast<uint4*>(Xs + key * 144 + v * 16) = xv;
+                const unsigned short* ve = reinterpret_cast<const unsigned short*>(&vv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) *reinterpret_cast<unsigned short*>(Vt + (v * 8 + e) * 144 + key * 2) = ve[e];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile) {
+                if (key0 + tile * 32 >= Lk) break;
+                f32x16_t st;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(Xs + (tile * 32 + r31) * 144 + ks * 32 + hq * 16);
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fq[ks], st, 0, 0, 0);
+                }
+                // st[e]: key = key0 + tile*32 + 4 hq + (e&3) + 8 (e>>2), query = this lane's column
+                float sv[16], tmax = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = key0 + tile * 32 + 4 * hq + (e & 3) + 8 * (e >> 2);
+                    const bool dead = key >= L || (MODE == 1 && key > query);
+                    sv[e] = dead ? -INFINITY : st[e] * scale_log2e;
+                    tmax = fmaxf(tmax, sv[e]);
+                }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m, tmax);
+                const float m_use = m_new == -INFINITY ? 0.f : m_new;           // fully masked so far: keep everything at zero
+                const float corr = exp2f(m - m_use);
+                float psum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { sv[e] = exp2f(sv[e] - m_use); psum += sv[e]; }
+                l = l * corr + psum;
+                m = m_new;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[t][e] *= corr;
+                bf16x8_t pk[2];
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    uint4 u;
+                    u.x = (uint32_t)f32_to_bf16(sv[k2 * 8 + 0]) | ((uint32_t)f32_to_bf16(sv[k2 * 8 + 1]) << 16);
+                    u.y = (uint32_t)f32_to_bf16(sv[k2 * 8 + 2]) | ((uint32_t)f32_to_bf16(sv[k2 * 8 + 3]) << 16);
+                    u.z = (uint32_t)f32_to_bf16(sv[k2 * 8 + 4]) | ((uint32_t)f32_to_bf16(sv[k2 * 8 + 5]) << 16);
+                    u.w = (uint32_t)f32_to_bf16(sv[k2 * 8 + 6]) | ((uint32_t)f32_to_bf16(sv[k2 * 8 + 7]) << 16);
+                    pk[k2] = __builtin_bit_cast(bf16x8_t, u);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        const unsigned char* vrow = Vt + (dt * 32 + r31) * 144 + (tile * 32 + k2 * 16 + 4 * hq) * 2;
+                        uint4 a;
+                        const uint2 lo = *reinterpret_cast<const uint2*>(vrow), hi = *reinterpret_cast<const uint2*>(vrow + 16);
+                        a.x = lo.x; a.y = lo.y; a.z = hi.x; a.w = hi.y;
+                        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), pk[k2], acc[dt], 0, 0, 0);
+                    }
+            }
+        }
+        const float ltot = l + __shfl_xor(l, 32, 64);
+        const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) otot[t][e] += acc[t][e] * inv;
+    }
+    // out^T layout: column = query (this lane), rows d = dt*32 + (e&3) + 8 (e>>2) + 4 hq  -> 4 consecutive d per register quad
+    if (query < L) {
+        bf16_t* orow = out + ((long long)b * L + query) * ldo + hh * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(otot[dt][gq * 4 + 0]) | ((uint32_t)f32_to_bf16(otot[dt][gq * 4 + 1]) << 16);
+                pk.y = (uint32_t)f32_to_bf16(otot[dt][gq * 4 + 2]) | ((uint32_t)f32_to_bf16(otot[dt][gq * 4 + 3]) << 16);
+                *reinterpret_cast<uint2*>(orow + dt * 32 + gq * 8 + hq * 4) = pk;
+            }
+    }
+}
+
 // ---- row softmax: scores fp32 [rows][ld] -> probabilities T [rows][ldp]; one wave per row ---------------------------
 // causal: row r (position r % L) keeps columns j <= r % L.  accumulate: P += softmax (CSA sums two attention maps).
 template <typename T>
@@ -266,6 +499,12 @@ inline int sgrid(long long total) { long long b = (total + 255) / 256; if (b > 4
 template <typename T>
 int launch_gemm(const GemmParams& p, int transB, int batch, hipStream_t st) {
     using M_ = GMma<T>;
+    if (sizeof(T) == 2 && transB && p.M >= 128 && p.N >= 96 && p.K % 8 == 0) {          // the large A * B^T products
+        dim3 grid2((p.N + 127) / 128, (p.M + 127) / 128, batch);
+        hipLaunchKernelGGL(gemm_nt128_kernel, grid2, dim3(256), (size_t)2 * 128 * (64 * 2 + 16), st, p);
+        EGM_CHECK_LAUNCH("gemm_nt128");
+        return EGM_OK;
+    }
     const size_t smem = (size_t)128 * M_::kRow + (transB ? (size_t)64 * M_::kRow : (size_t)2 * 32 * M_::kRowT);
     dim3 grid((p.N + 63) / 64, (p.M + 127) / 128, batch);
     if (transB) hipLaunchKernelGGL((gemm_kernel<T, true>), grid, dim3(256), smem, st, p);
@@ -292,6 +531,21 @@ extern "C" int egm_gemm(int dtype, const void* A, int lda, const void* B, int ld
     if (dtype == EGM_BF16) return launch_gemm<bf16_t>(p, transB, nb1 * nb2, (hipStream_t)s);
     if (dtype == EGM_F32) return launch_gemm<float>(p, transB, nb1 * nb2, (hipStream_t)s);
     EGM_FAIL(EGM_ERR_ARG, "gemm: unknown dtype %d", dtype);
+}
+
+extern "C" int egm_attention_fused(int dtype, const void* qkv, int ld, int B, int L, int H, int head_dim, int mode, void* out, int ldo,
+                                   egm_stream_t s) {
+    EGM_REQUIRE(dtype == EGM_BF16 && head_dim == 64, "attention_fused: bf16 with head dimension 64 only (dtype=%d head_dim=%d)", dtype, head_dim);
+    EGM_REQUIRE(qkv && out && B > 0 && L > 0 && H > 0 && mode >= 0 && mode <= 2 && ld >= 3 * H * 64 && ldo >= H * 64 && ld % 8 == 0 && ldo % 4 == 0 &&
+                egm_aligned16(qkv) && (long long)B * H < 65536, "attention_fused: bad args");
+    const float sl2e = 0.125f * 1.4426950408889634f;                // 64^-1/2 * log2(e): exp(x) = exp2(x * log2 e)
+    dim3 grid((L + 127) / 128, B * H);
+    const int D = H * 64;
+    if (mode == 0) hipLaunchKernelGGL((attention_fused_kernel<0>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv, ld, L, H, D, (bf16_t*)out, ldo, sl2e);
+    else if (mode == 1) hipLaunchKernelGGL((attention_fused_kernel<1>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv, ld, L, H, D, (bf16_t*)out, ldo, sl2e);
+    else hipLaunchKernelGGL((attention_fused_kernel<2>), grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)qkv, ld, L, H, D, (bf16_t*)out, ldo, sl2e);
+    EGM_CHECK_LAUNCH("attention_fused");
+    return EGM_OK;
 }
 
 extern "C" int egm_softmax_rows(int dtype, const float* S, int lds_, void* P, int ldp, long long rows, int L, int causal, int accumulate,

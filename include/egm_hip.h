@@ -264,6 +264,11 @@ int egm_gemm(int dtype, const void* A, int lda, const void* B, int ldb, int tran
 /* P[r][:] (dtype) = softmax(S[r][:L]) (S fp32); causal != 0 keeps columns j <= r % L (text encoder mask,
  * clip/model.py:462-468); accumulate != 0 adds to P (CSA: softmax(q q^T) + softmax(k k^T), models/clipseg.py:96-102).
  * Columns L..ldp-1 of P are written as 0. */
+/* Fused multi-head self attention on packed qkv [B][L][3*H*64] (bf16, head dimension 64): out [B][L][H*64].
+ * mode 0: softmax(q k^T / 8) v; 1: causal (clip/model.py:462-468); 2: CSA (softmax(q q^T / 8) + softmax(k k^T / 8)) v
+ * (models/clipseg.py:96-102).  Online softmax, fp32 statistics; scores and probabilities never reach HBM. */
+int egm_attention_fused(int dtype, const void* qkv, int ld, int B, int L, int H, int head_dim, int mode, void* out, int ldo,
+                        egm_stream_t s);
 int egm_softmax_rows(int dtype, const float* S, int lds, void* P, int ldp, long long rows, int L, int causal, int accumulate,
                      egm_stream_t s);
 /* LayerNorm over the last dimension with fp32 statistics (clip/model.py:159-165). */

@@ -62,6 +62,27 @@ def test_attention_modes_vs_torch(dtype):
         assert rel(out.float(), ref.transpose(1, 2).reshape(B, L, D)) < (2e-5 if dtype == torch.float32 else 1e-2), mode
 
 
+@pytest.mark.parametrize("L", [485, 248, 101, 33])
+def test_fused_attention_head64_vs_torch(L):
+    """bf16, head dimension 64 (ViT-B/16 and the text encoder): the fused kernel (scores on chip) against fp32 torch."""
+    from egm_unet_amd.clip import ops as O
+    g = torch.Generator().manual_seed(L)
+    B, H, dh = 2, 3, 64
+    D = H * dh
+    qkv = (torch.randn(B, L, 3 * D, generator=g) * 1.5).bfloat16().float()
+    q, k, v = [t.view(B, L, H, dh).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
+    s = dh ** -0.5
+    refs = {
+        "full": torch.softmax(q @ k.transpose(-1, -2) * s, -1) @ v,
+        "causal": torch.softmax(q @ k.transpose(-1, -2) * s + torch.full((L, L), float("-inf")).triu(1), -1) @ v,
+        "csa": (torch.softmax(q @ q.transpose(-1, -2) * s, -1) + torch.softmax(k @ k.transpose(-1, -2) * s, -1)) @ v,
+    }
+    for mode, ref in refs.items():
+        out = O.attention(qkv.to(DEV).bfloat16(), H, mode)
+        assert out.shape == (B, L, D)
+        assert rel(out.float(), ref.transpose(1, 2).reshape(B, L, D)) < 1e-2, (mode, L)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_layernorm_vs_torch(dtype):
     from egm_unet_amd.clip import ops as O
