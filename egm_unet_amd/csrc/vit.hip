@@ -151,58 +151,65 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 // Global -> register prefetch of chunk c+1 is issued before the MFMAs of chunk c and written to LDS after them; inside a chunk
 // the fragments of k-step s+1 are read from LDS before the MFMAs of k-step s (two fragment sets).  LDS rows are 128 B of k + 16 B
 // pad (conflict-free ds_read_b128, see conv_igemm.hip).  16 MFMAs per wave between barriers instead of 4 in gemm_kernel.
-__global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmParams p) {
+template <int NJ, int WMW>                                            // wave tile 64 x 32*NJ; WMW x 2 waves; workgroup tile 64*WMW x 64*NJ
+__global__ __launch_bounds__(128 * WMW, 2) void gemm_nt128_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int BK = 64, ROW = BK * 2 + 16, NV = BK / 8;             // 8 vectors of 8 bf16 per row
-    unsigned char* As = smem;                                          // [128][ROW]
-    unsigned char* Bs = smem + 128 * ROW;                              // [128][ROW]
+    constexpr int BK = 64, ROW = BK * 2 + 16, BM = 64 * WMW, BN = 64 * NJ, NT_ = 128 * WMW, RPS = NT_ / 8;   // rows staged per slot
+    constexpr int NSA = BM / RPS, NSB = BN / RPS;                     // staging slots per thread (8 vectors of 8 bf16 per row)
+    unsigned char* As = smem;                                          // [BM][ROW]
+    unsigned char* Bs = smem + BM * ROW;                               // [BN][ROW]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r31 = lane & 31, h = lane >> 5;
     const int wm = wv >> 1, wn = wv & 1;
     const int b1 = blockIdx.z / p.nb2, b2 = blockIdx.z - b1 * p.nb2;
     const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A) + b1 * p.sA1 + b2 * p.sA2;
     const bf16_t* __restrict__ B = reinterpret_cast<const bf16_t*>(p.B) + b1 * p.sB1 + b2 * p.sB2;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
-    f32x16_t acc[2][2];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    f32x16_t acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // staging slots: vector i = tid + 256 s -> row i / 8, k-vector i % 8 (4 slots for A, 4 for B)
     const int srow = tid >> 3, sv = tid & 7;
-    uint4 pa[4], pb[4];
+    uint4 pa[NSA], pb[NSB];
     auto issue = [&](int k0) {
+        const int k = k0 + sv * 8;
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-            const int row = srow + 32 * s2, k = k0 + sv * 8;
-            pa[s2] = make_uint4(0, 0, 0, 0); pb[s2] = make_uint4(0, 0, 0, 0);
+        for (int s2 = 0; s2 < NSA; ++s2) {
+            const int row = srow + RPS * s2;
+            pa[s2] = make_uint4(0, 0, 0, 0);
             if (m0 + row < p.M && k < p.K) pa[s2] = *reinterpret_cast<const uint4*>(A + (long long)(m0 + row) * p.lda + k);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < NSB; ++s2) {
+            const int row = srow + RPS * s2;
+            pb[s2] = make_uint4(0, 0, 0, 0);
             if (n0 + row < p.N && k < p.K) pb[s2] = *reinterpret_cast<const uint4*>(B + (long long)(n0 + row) * p.ldb + k);
         }
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-            *reinterpret_cast<uint4*>(As + (srow + 32 * s2) * ROW + sv * 16) = pa[s2];
-            *reinterpret_cast<uint4*>(Bs + (srow + 32 * s2) * ROW + sv * 16) = pb[s2];
-        }
+        for (int s2 = 0; s2 < NSA; ++s2) *reinterpret_cast<uint4*>(As + (srow + RPS * s2) * ROW + sv * 16) = pa[s2];
+#pragma unroll
+        for (int s2 = 0; s2 < NSB; ++s2) *reinterpret_cast<uint4*>(Bs + (srow + RPS * s2) * ROW + sv * 16) = pb[s2];
     };
     const unsigned char* arow = As + (wm * 64 + r31) * ROW + h * 16;
-    const unsigned char* brow = Bs + (wn * 64 + r31) * ROW + h * 16;
-    auto frags = [&](int ks, bf16x8_t (&fa)[2], bf16x8_t (&fb)[2]) {
+    const unsigned char* brow = Bs + (wn * 32 * NJ + r31) * ROW + h * 16;
+    auto frags = [&](int ks, bf16x8_t (&fa)[2], bf16x8_t (&fb)[NJ]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            fa[i] = *reinterpret_cast<const bf16x8_t*>(arow + i * 32 * ROW + ks * 32);
-            fb[i] = *reinterpret_cast<const bf16x8_t*>(brow + i * 32 * ROW + ks * 32);
-        }
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(arow + i * 32 * ROW + ks * 32);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(brow + j * 32 * ROW + ks * 32);
     };
-    auto mmas = [&](const bf16x8_t (&fa)[2], const bf16x8_t (&fb)[2]) {
+    auto mmas = [&](const bf16x8_t (&fa)[2], const bf16x8_t (&fb)[NJ]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j)      // operands swapped (rows of D = n, columns = m): a lane ends up with 4 consecutive n of one m
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     };
 
     issue(0);
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmParams p) {
         commit();
         __syncthreads();
         if (k0 + BK < p.K) issue(k0 + BK);                             // in flight during the MFMAs below
-        bf16x8_t fa0[2], fb0[2], fa1[2], fb1[2];
+        bf16x8_t fa0[2], fb0[NJ], fa1[2], fb1[NJ];
         frags(0, fa0, fb0);
         __builtin_amdgcn_s_setprio(1);
         frags(1, fa1, fb1); mmas(fa0, fb0);
@@ -220,23 +227,47 @@ __global__ __launch_bounds__(256, 2) void gemm_nt128_kernel(GemmParams p) {
         mmas(fa1, fb1);
         __builtin_amdgcn_s_setprio(0);
     }
-    // epilogue: col (n) = lane&31, row (m) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // epilogue: column (m) = lane&31, rows (n) = (reg&3) + 8*(reg>>2) + 4*(lane>>5): 4 consecutive n per register quad ->
+    // vector bias / residual loads and 8-byte (bf16) or 16-byte (fp32) stores
     const long long coff = b1 * p.sC1 + b2 * p.sC2, roff = b1 * p.sR1 + b2 * p.sR2;
+    const bool vec_ok = (p.ldc & 3) == 0 && (p.N & 3) == 0 && (!p.R || (p.ldr & 3) == 0) && ((coff | roff) & 3) == 0;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + r31;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + r31;
+        if (m >= p.M) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m >= p.M) continue;
-                float v = gemm_act(p.alpha * acc[i][j][e] + bv, p.act);
-                if (p.R) v += to_f32(reinterpret_cast<const bf16_t*>(p.R)[roff + (long long)m * p.ldr + n]);
-                if (p.c_f32) reinterpret_cast<float*>(p.C)[coff + (long long)m * p.ldc + n] = v;
-                else reinterpret_cast<bf16_t*>(p.C)[coff + (long long)m * p.ldc + n] = from_f32<bf16_t>(v);
+            for (int gq = 0; gq < 4; ++gq) {
+                const int n4 = n0 + wn * 32 * NJ + j * 32 + gq * 8 + h * 4;
+                if (n4 >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gemm_act(p.alpha * acc[i][j][gq * 4 + e] + ((p.bias && n4 + e < p.N) ? p.bias[n4 + e] : 0.f), p.act);
+                if (vec_ok) {
+                    if (p.R) {
+                        const uint2 rv = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.R) + roff + (long long)m * p.ldr + n4);
+                        v[0] += __uint_as_float(rv.x << 16); v[1] += __uint_as_float(rv.x & 0xffff0000u);
+                        v[2] += __uint_as_float(rv.y << 16); v[3] += __uint_as_float(rv.y & 0xffff0000u);
+                    }
+                    if (p.c_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + coff + (long long)m * p.ldc + n4) = make_float4(v[0], v[1], v[2], v[3]);
+                    else {
+                        uint2 pk;
+                        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + coff + (long long)m * p.ldc + n4) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = n4 + e;
+                        if (n >= p.N) continue;
+                        float w = v[e];
+                        if (p.R) w += to_f32(reinterpret_cast<const bf16_t*>(p.R)[roff + (long long)m * p.ldr + n]);
+                        if (p.c_f32) reinterpret_cast<float*>(p.C)[coff + (long long)m * p.ldc + n] = w;
+                        else reinterpret_cast<bf16_t*>(p.C)[coff + (long long)m * p.ldc + n] = from_f32<bf16_t>(w);
+                    }
+                }
             }
     }
 }
@@ -500,8 +531,16 @@ template <typename T>
 int launch_gemm(const GemmParams& p, int transB, int batch, hipStream_t st) {
     using M_ = GMma<T>;
     if (sizeof(T) == 2 && transB && p.M >= 128 && p.N >= 96 && p.K % 8 == 0) {          // the large A * B^T products
-        dim3 grid2((p.N + 127) / 128, (p.M + 127) / 128, batch);
-        hipLaunchKernelGGL(gemm_nt128_kernel, grid2, dim3(256), (size_t)2 * 128 * (64 * 2 + 16), st, p);
+        // 128 x 256 tiles (32 MFMAs per wave between barriers) when they still give every CU a few workgroups, else 128 x 128
+        // 256 x 128 tiles (8 waves; 1/170 staged byte per FLOP instead of 1/128) when they still give every CU two workgroups
+        const long long wg256 = (long long)((p.N + 127) / 128) * ((p.M + 255) / 256) * batch;
+        if (p.M >= 256 && wg256 >= 512) {
+            dim3 grid2((p.N + 127) / 128, (p.M + 255) / 256, batch);
+            hipLaunchKernelGGL((gemm_nt128_kernel<2, 4>), grid2, dim3(512), (size_t)(256 + 128) * (64 * 2 + 16), st, p);
+        } else {
+            dim3 grid2((p.N + 127) / 128, (p.M + 127) / 128, batch);
+            hipLaunchKernelGGL((gemm_nt128_kernel<2, 2>), grid2, dim3(256), (size_t)(128 + 128) * (64 * 2 + 16), st, p);
+        }
         EGM_CHECK_LAUNCH("gemm_nt128");
         return EGM_OK;
     }
