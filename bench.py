@@ -217,12 +217,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if os.environ.get("EGM_BENCH_SINGLE_DEVICE"):          # rehearsal of the N>1 code path on a one-GPU box (with EGM_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("EGM_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.workload in ("clipseg_infer", "clipseg_train"):
         return clipseg_bench(args, dev, rank, world)
@@ -289,9 +295,13 @@ def main():
 
     roofline = None
     cpu = None
+    # instrumented eager step outside the timed region.  EVERY rank runs it (its gradient exchange must match on all ranks);
+    # rank 0 reports.  After a captured graph the reducer's autograd hooks are off: switch them back on for this eager step.
+    if reducer is not None:
+        reducer.hooks_enabled = True
+    with KernelTimer(lib()) as kt:
+        eager_step()
     if rank == 0:
-        with KernelTimer(lib()) as kt:
-            eager_step()
         agg = kt.summary()
         total_ms = sum(v[1] for v in agg.values())
         dom_key, dom = max(((k, v) for k, v in agg.items() if v[2] > 0), key=lambda kv: kv[1][1])

@@ -67,3 +67,21 @@ def test_two_ranks_stay_in_sync(graphed):
     for k in res[0]:
         a, b = torch.tensor(res[0][k]), torch.tensor(res[1][k])
         assert torch.allclose(a, b, rtol=0, atol=0), k          # bitwise: same reduced gradients, same update
+
+
+def test_bench_two_rank_code_path_rehearsal():
+    """bench.py's N>1 path end to end (torch.distributed.run, graph capture with the reducer, exchange + SGD after each replay,
+    instrumented step on every rank, max-over-ranks timing) with two ranks sharing this GPU over gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EGM_BENCH_SINGLE_DEVICE="1", EGM_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "128",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["value"] > 0 and line["roofline"] is not None
