@@ -185,3 +185,42 @@ def test_fullsize_train_step_fp32_vs_oracle(big_model):
     print(f"gradient rel-L2 error vs float64 oracle: HIP fp32 median {med_h:.2e} max {hip_err[-1]:.2e}; CPU fp32 median {med_c:.2e} max {cpu_err[-1]:.2e}")
     assert med_h <= 2.0 * med_c + 1e-4 and hip_err[-1] <= 2.0 * cpu_err[-1] + 1e-2, (med_h, med_c, hip_err[-1], cpu_err[-1])
     big_model.load_state_dict(sd0)
+
+
+@pytest.mark.parametrize("shape", [(3, 40, 56), (2, 72, 104), (1, 90, 150)], ids=lambda s: "x".join(map(str, s)))
+def test_odd_sizes_train_step_fp32_vs_oracle(shape):
+    """Sizes that are not multiples of the tile / pooling factors (ragged conv tiles, odd MCA strips, the zero-pad branch of
+    Up at 90x150): EGM-UNet(3,2,base_c=8), train mode, fp32, logits / loss / gradients against the CPU oracle."""
+    from oracle import egm_ref as R, loss_ref as L
+    from egm_unet_amd import GRFBUNet
+    from egm_unet_amd.train_utils import criterion
+    n, h, w = shape
+    torch.manual_seed(h * 1000 + w)
+    m = GRFBUNet(3, 2, base_c=8)
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x, t = synth(n, h, w, 17)
+    lw = torch.tensor([1.0, 2.0])
+    work = {k: v.clone() for k, v in sd0.items()}
+    for k, v in work.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+    out_r = R.egm_unet_forward(work, x, True)["out"]
+    loss_r = L.criterion({"out": out_r}, t, lw, num_classes=2, ignore_index=255)
+    loss_r.backward()
+    m.to(DEV).train()
+    out = m(x.to(DEV))["out"]
+    loss = criterion({"out": out}, t.to(DEV), lw.to(DEV), num_classes=2, ignore_index=255)
+    loss.backward()
+    assert out.shape == out_r.shape
+    assert_close(out.detach().cpu(), out_r.detach(), rtol=2e-3, atol=5e-4, what=f"logits {shape}")
+    assert abs(float(loss) - float(loss_r)) <= 2e-4 * abs(float(loss_r)) + 1e-5
+    rels = []
+    for k, p in m.named_parameters():
+        g = work[k].grad
+        if g is not None and float(g.norm()) > 1e-5:
+            rels.append(float((p.grad.cpu().double() - g.double()).norm() / g.double().norm()))
+    rels.sort()
+    assert rels[len(rels) // 2] < 5e-3 and rels[-1] < 0.1, (rels[len(rels) // 2], rels[-1])
+    for k, v in m.state_dict().items():                       # BatchNorm running statistics took the same step
+        if "running_" in k:
+            assert_close(v.cpu(), work[k], rtol=2e-3, atol=2e-4, what=k)
