@@ -15,7 +15,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "egm_hip.h")
 LIB_PATH = os.path.join(_HERE, "lib", "libegm_hip.so")
 
 EGM_F32, EGM_BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU = 0, 1, 2, 3
 
 _CTYPES = {
     "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "long long": ctypes.c_longlong,

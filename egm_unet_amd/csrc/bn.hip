@@ -11,12 +11,14 @@ constexpr int kMaxPartialBlocks = 1024;
 __device__ __forceinline__ float act_fwd(float v, int act) {
     if (act == EGM_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == EGM_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    if (act == EGM_ACT_SILU) return v / (1.f + expf(-v));
     return v;
 }
 // derivative of act at pre-activation v
 __device__ __forceinline__ float act_grad(float v, int act) {
     if (act == EGM_ACT_RELU) return v > 0.f ? 1.f : 0.f;
     if (act == EGM_ACT_SIGMOID) { const float z = 1.f / (1.f + expf(-v)); return z * (1.f - z); }
+    if (act == EGM_ACT_SILU) { const float z = 1.f / (1.f + expf(-v)); return z * (1.f + v * (1.f - z)); }
     return 1.f;
 }
 

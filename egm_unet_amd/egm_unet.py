@@ -203,6 +203,28 @@ class EdgeEnhancedGRFB(nn.Module):
         return ops.gate3(o_b, t)                                                # out*(1 + mean_c sigmoid(t))
 
 
+class Conv(nn.Module):
+    """conv (no bias, 'same' auto-padding) -> BatchNorm2d -> SiLU (src/EGM-UNet.py:25-43): the standard block of the reference's
+    unused edge variants; stride 1 only, like every conv on this path."""
+    default_act = nn.SiLU()
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, d=1, act=True):
+        super().__init__()
+        if s != 1 or not isinstance(k, int) or (p is not None and p != d * (k - 1) // 2):
+            raise NotImplementedError("egm_unet_amd: Conv is built for square kernels, stride 1, 'same' padding")
+        self.conv = nn.Conv2d(c1, c2, k, s, d * (k - 1) // 2, groups=g, dilation=d, bias=False)
+        self.bn = nn.BatchNorm2d(c2)
+        self.act = self.default_act if act is True else act if isinstance(act, nn.Module) else nn.Identity()
+        if not isinstance(self.act, (nn.SiLU, nn.Identity, nn.ReLU, nn.Sigmoid)):
+            raise NotImplementedError("egm_unet_amd: Conv activation must be SiLU, ReLU, Sigmoid or identity")
+        self._dil, self._groups = d, g
+
+    def forward(self, x):
+        from ._lib import ACT_SIGMOID, ACT_SILU
+        code = {nn.SiLU: ACT_SILU, nn.Identity: ACT_NONE, nn.ReLU: ACT_RELU, nn.Sigmoid: ACT_SIGMOID}[type(self.act)]
+        return ops.conv_bn_act(x, self.conv, self.bn, code, dil=self._dil, groups=self._groups)
+
+
 class GRFB(nn.Module):
     """The plain receptive-field block the edge-enhanced one grew out of (src/EGM-UNet.py:977-1023): three dilated branches on
     the raw input, 1x1 `ConvLinear` over cat(x, branches), relu(out*scale + shortcut).  Kept as the block-level ablation twin."""

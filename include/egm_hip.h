@@ -36,7 +36,7 @@ typedef void* egm_stream_t; /* hipStream_t */
 
 enum egm_status { EGM_OK = 0, EGM_ERR_ARG = -1, EGM_ERR_LAUNCH = -2, EGM_ERR_UNSUPPORTED = -3 };
 enum egm_dtype { EGM_F32 = 0, EGM_BF16 = 1 };
-enum egm_act { EGM_ACT_NONE = 0, EGM_ACT_RELU = 1, EGM_ACT_SIGMOID = 2 };
+enum egm_act { EGM_ACT_NONE = 0, EGM_ACT_RELU = 1, EGM_ACT_SIGMOID = 2, EGM_ACT_SILU = 3 /* x*sigmoid(x): Conv, src/EGM-UNet.py:25-43 */ };
 
 int egm_version(void);
 const char* egm_last_error(void);

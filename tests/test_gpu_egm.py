@@ -216,3 +216,30 @@ def test_yuan_twin_fixture_fp32():
                 rels.append(float((params[k[5:]].grad.cpu().double() - ref).norm() / ref.norm()))
     rels.sort()
     assert rels[len(rels) // 2] < 2e-3 and rels[-1] < 3e-2, (rels[len(rels) // 2], rels[-1])
+
+
+@pytest.mark.parametrize("k,d,g", [(1, 1, 1), (3, 1, 1), (3, 2, 4)])
+def test_conv_bn_silu_block_vs_torch(k, d, g):
+    """Conv (conv -> BatchNorm2d -> SiLU, src/EGM-UNet.py:25-43) forward and backward against the same torch modules on the CPU."""
+    from egm_unet_amd.egm_unet import Conv
+    from egm_unet_amd import ops
+    gen = torch.Generator().manual_seed(k * 10 + d)
+    torch.manual_seed(3)
+    m = Conv(16, 24 if g == 1 else 16, k, d=d, g=g)
+    ref = torch.nn.Sequential(torch.nn.Conv2d(16, m.conv.out_channels, k, 1, d * (k - 1) // 2, groups=g, dilation=d, bias=False),
+                              torch.nn.BatchNorm2d(m.conv.out_channels), torch.nn.SiLU())
+    ref[0].load_state_dict(m.conv.state_dict()); ref[1].load_state_dict(m.bn.state_dict())
+    x = torch.randn(2, 16, 20, 28, generator=gen)
+    gz = torch.randn(2, m.conv.out_channels, 20, 28, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    zr = ref(xr); zr.backward(gz)
+    m.to(DEV).train()
+    xg = ops.to_nhwc(x.to(DEV), torch.float32).requires_grad_(True)
+    z = m(xg)
+    z.backward(ops.to_nhwc(gz.to(DEV), torch.float32))
+    C = m.conv.out_channels
+    assert_close(ops.to_nchw(z.detach(), C).cpu(), zr.detach(), rtol=2e-4, atol=2e-5, what="z")
+    assert_close(ops.to_nchw(xg.grad, 16).cpu(), xr.grad, rtol=2e-3, atol=2e-5, what="dx")
+    assert_close(m.conv.weight.grad.cpu(), ref[0].weight.grad, rtol=2e-3, atol=2e-4, what="dw")
+    assert_close(m.bn.weight.grad.cpu(), ref[1].weight.grad, rtol=2e-3, atol=2e-4, what="dgamma")
+    assert_close(m.bn.running_var.cpu(), ref[1].running_var, rtol=1e-4, atol=1e-5, what="running_var")
