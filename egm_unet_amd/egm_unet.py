@@ -225,6 +225,20 @@ class Conv(nn.Module):
         return ops.conv_bn_act(x, self.conv, self.bn, code, dil=self._dil, groups=self._groups)
 
 
+class ELA(nn.Module):
+    """Efficient Local Attention (src/EGM-UNet.py:56-79): strip means along W and H -> shared depthwise Conv1d(k) -> GroupNorm(16)
+    -> sigmoid; out = x * g_h * g_w.  One of the reference's unused ablation blocks, NHWC in / out like every block here."""
+
+    def __init__(self, channel, kernel_size=7):
+        super().__init__()
+        self.conv = nn.Conv1d(channel, channel, kernel_size=kernel_size, padding=kernel_size // 2, groups=channel, bias=False)
+        self.gn = nn.GroupNorm(16, channel)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, x):
+        return ops.ela(x, self.conv, self.gn)
+
+
 class GRFB(nn.Module):
     """The plain receptive-field block the edge-enhanced one grew out of (src/EGM-UNet.py:977-1023): three dilated branches on
     the raw input, 1x1 `ConvLinear` over cat(x, branches), relu(out*scale + shortcut).  Kept as the block-level ablation twin."""

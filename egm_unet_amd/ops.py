@@ -902,6 +902,49 @@ def dwconv3(x, w, b, scale):
 
 
 # ----------------------------------------------------------------------------------------------------------
+# ELA (Efficient Local Attention, src/EGM-UNet.py:56-79)
+# ----------------------------------------------------------------------------------------------------------
+class _ELA(Function):
+    @staticmethod
+    def forward(ctx, x, conv_w, gamma, beta, groups, eps):
+        x, ldx = _nhwc(x)
+        N, H, W, C = x.shape
+        L, dt, st, dev = lib(), dtype_code(x.dtype), stream(), x.device
+        ks = conv_w.shape[-1]
+        cw = conv_w.detach().reshape(C, ks).contiguous()
+        mh, mw = _f32((N, H, C), dev), _f32((N, W, C), dev)
+        L.call("egm_ela_strip_means", dt, ptr(x), ldx, ptr(mh), ptr(mw), N, H, W, C, st)
+        yh, yw, gh, gw = _f32((N, H, C), dev), _f32((N, W, C), dev), _f32((N, H, C), dev), _f32((N, W, C), dev)
+        stats = _f32((N, 2, groups, 2), dev)
+        L.call("egm_ela_gates_fwd", ptr(mh), ptr(mw), ptr(cw), ks, ptr(gamma.detach()), ptr(beta.detach()), float(eps), ptr(yh), ptr(yw), ptr(gh),
+               ptr(gw), ptr(stats), N, H, W, C, groups, st)
+        out = torch.empty((N, H, W, C), dtype=x.dtype, device=dev)
+        L.call("egm_ela_apply", dt, ptr(x), ldx, ptr(gh), ptr(gw), ptr(out), C, N, H, W, C, st)
+        ctx.save_for_backward(x, mh, mw, yh, yw, gh, gw, stats, cw, gamma)
+        ctx.meta = (groups, ks, conv_w.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mh, mw, yh, yw, gh, gw, stats, cw, gamma = ctx.saved_tensors
+        groups, ks, wshape = ctx.meta
+        x, ldx = _nhwc(x); g, ldg = _nhwc(g)
+        N, H, W, C = x.shape
+        L, dt, st, dev = lib(), dtype_code(x.dtype), stream(), x.device
+        ws = torch.empty(L.query("egm_ela_bwd_workspace", N, H, W, C, ks) // 4 + 4, dtype=torch.float32, device=dev)
+        dx = torch.empty((N, H, W, C), dtype=x.dtype, device=dev)
+        dcw, dgamma, dbeta = _f32((C, ks), dev), _f32(C, dev), _f32(C, dev)
+        L.call("egm_ela_bwd", dt, ptr(g), ldg, ptr(x), ldx, ptr(mh), ptr(mw), ptr(yh), ptr(yw), ptr(gh), ptr(gw), ptr(stats), ptr(cw), ks,
+               ptr(gamma.detach()), ptr(dx), C, ptr(dcw), ptr(dgamma), ptr(dbeta), ptr(ws), N, H, W, C, groups, st)
+        return dx, dcw.reshape(wshape), dgamma, dbeta, None, None
+
+
+def ela(x, conv, gn):
+    """conv: nn.Conv1d(C, C, k, padding=k//2, groups=C, bias=False); gn: nn.GroupNorm(G, C) -- parameter holders"""
+    return _ELA.apply(x, conv.weight, gn.weight, gn.bias, gn.num_groups, gn.eps)
+
+
+# ----------------------------------------------------------------------------------------------------------
 # MCALayer
 # ----------------------------------------------------------------------------------------------------------
 class _MCALayer(Function):

@@ -329,6 +329,20 @@ int egm_sgd_multi(const void* table_dev, int ntensors, long long total_chunks, c
 /* table of {float* dst; const float* src; long long n;}: gradient bucket gather/scatter for the RCCL all-reduce. */
 int egm_copy_multi(const void* table_dev, int ntensors, egm_stream_t s);
 
+/* ---- ELA, Efficient Local Attention (src/EGM-UNet.py:56-79; an unused ablation block of the reference) -----------
+ * strip means mh [N][H][C] (over W) and mw [N][W][C] (over H), fp32 -> shared depthwise Conv1d(ks, no bias, conv_w [C][ks]) ->
+ * GroupNorm(groups, C) -> sigmoid gates gh, gw -> out = x * gh[n,h,c] * gw[n,w,c].  yh/yw (conv outputs) and stats
+ * [N][2][groups][2] (mean, rstd) are kept for egm_ela_bwd, which returns dx and the parameter gradients. */
+int egm_ela_strip_means(int dtype, const void* x, int ldx, float* mh, float* mw, int N, int H, int W, int C, egm_stream_t s);
+int egm_ela_gates_fwd(const float* mh, const float* mw, const float* conv_w, int ks, const float* gamma, const float* beta, float eps,
+                      float* yh, float* yw, float* gh, float* gw, float* stats, int N, int H, int W, int C, int groups, egm_stream_t s);
+int egm_ela_apply(int dtype, const void* x, int ldx, const float* gh, const float* gw, void* out, int ldo, int N, int H, int W, int C,
+                  egm_stream_t s);
+long long egm_ela_bwd_workspace(int N, int H, int W, int C, int ks);
+int egm_ela_bwd(int dtype, const void* g, int ldg, const void* x, int ldx, const float* mh, const float* mw, const float* yh, const float* yw,
+                const float* gh, const float* gw, const float* stats, const float* conv_w, int ks, const float* gamma, void* dx, int lddx,
+                float* dconv_w, float* dgamma, float* dbeta, float* workspace, int N, int H, int W, int C, int groups, egm_stream_t s);
+
 /* ---- device-side data path (transforms.py, my_dataset.py:118-132) ----------------------------------------------
  * Decoded uint8 images [H][W][C] already in device memory.
  * egm_resample_u8: one separable pass of Pillow's antialiased resize (F.resize -> Image.resize(BILINEAR), transforms.py:39):

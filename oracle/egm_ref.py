@@ -158,6 +158,18 @@ def edge_grfb(state: State, p: str, x, train: bool, scale: float = 0.1, visual: 
     return out * (1 + t.mean(dim=1, keepdim=True))
 
 
+def ela(state: State, p: str, x, groups: int = 16, eps: float = 1e-5):
+    """ELA (src/EGM-UNet.py:56-79): strip means -> shared depthwise Conv1d -> GroupNorm(16) -> sigmoid; x * g_h * g_w."""
+    B, C, H, W = x.shape
+    w = state[p + ".conv.weight"]
+    k = w.shape[-1]
+
+    def gate(v):
+        v = F.conv1d(v, w, None, padding=k // 2, groups=C)
+        return torch.sigmoid(F.group_norm(v, groups, state[p + ".gn.weight"], state[p + ".gn.bias"], eps))
+    return x * gate(x.mean(dim=3)).view(B, C, H, 1) * gate(x.mean(dim=2)).view(B, C, 1, W)
+
+
 def plain_grfb(state: State, p: str, x, train: bool, scale: float = 0.1, visual: int = 12):
     """GRFB without the edge machinery (src/EGM-UNet.py:977-1023), the block-level ablation twin."""
     i = x.shape[1] // 8

@@ -243,3 +243,13 @@ def test_conv_bn_silu_block_vs_torch(k, d, g):
     assert_close(m.conv.weight.grad.cpu(), ref[0].weight.grad, rtol=2e-3, atol=2e-4, what="dw")
     assert_close(m.bn.weight.grad.cpu(), ref[1].weight.grad, rtol=2e-3, atol=2e-4, what="dgamma")
     assert_close(m.bn.running_var.cpu(), ref[1].running_var, rtol=1e-4, atol=1e-5, what="running_var")
+
+
+@pytest.mark.parametrize("name,c,k", [("ela_c64", 64, 7), ("ela_c32_k5", 32, 5)])
+def test_ela_fixture(name, c, k):
+    """ELA (src/EGM-UNet.py:56-79, GroupNorm(16) strip attention) forward / input gradient / parameter gradients vs its fixture."""
+    from egm_unet_amd.egm_unet import ELA
+    fx = load_fixture(name)
+    m = ELA(c, kernel_size=k)
+    load_module_state(m, fx)
+    run_block(m, fx, 1, grad_tol=dict(rtol=2e-3, atol=2e-4))

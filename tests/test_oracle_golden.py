@@ -201,3 +201,17 @@ def test_plain_grfb_block():
     assert_close(out.detach(), fx["out"], what="plain grfb out", **TOL)
     (out * torch.from_numpy(fx["gout"])).sum().backward()
     assert_close(x.grad, fx["gin0"], rtol=5e-3, atol=5e-4, what="gin")
+
+
+@pytest.mark.parametrize("name", ["ela_c64", "ela_c32_k5"])
+def test_ela_block(name):
+    fx = load_fixture(name)
+    st = fixture_state(fx, prefix="m")
+    x = torch.from_numpy(fx["in0"]).requires_grad_(True)
+    out = R.ela(st, "m", x)
+    assert_close(out.detach(), fx["out"], what="ela out", **TOL)
+    (out * torch.from_numpy(fx["gout"])).sum().backward()
+    assert_close(x.grad, fx["gin0"], rtol=2e-3, atol=1e-5, what="gin")
+    for k, v in fx.items():
+        if k.startswith("grad/"):
+            assert_close(st["m." + k[5:]].grad, v, rtol=2e-3, atol=1e-4, what=k)

@@ -241,6 +241,12 @@ def main():
     torch.manual_seed(77)
     m = egm.GRFB(64, 64, stride=1, scale=0.1, visual=12); randomize_bn(m, g2)
     block_fixture("plain_grfb_c64", m, [torch.relu(torch.randn(2, 64, 40, 44, generator=g2))])
+    m = egm.ELA(64, kernel_size=7)
+    with torch.no_grad():
+        m.gn.weight.copy_(1.0 + 0.2 * torch.randn(64, generator=g2)); m.gn.bias.copy_(0.2 * torch.randn(64, generator=g2))
+    block_fixture("ela_c64", m, [torch.randn(2, 64, 24, 36, generator=g2) + 0.3])
+    m = egm.ELA(32, kernel_size=5)
+    block_fixture("ela_c32_k5", m, [torch.randn(1, 32, 17, 9, generator=g2)])
 
 
 if __name__ == "__main__":
