@@ -225,6 +225,49 @@ class Conv(nn.Module):
         return ops.conv_bn_act(x, self.conv, self.bn, code, dil=self._dil, groups=self._groups)
 
 
+class HEGDC(nn.Module):
+    """Hybrid edge-guided density convolution (src/EGM-UNet.py:210-340), an unused ablation block of the reference: a double conv whose
+    first stage is modulated by gates computed from fixed Scharr + Sobel edge responses of the channel mean (no_grad branch with
+    batch-global min-max normalisation) and whose first weight is scaled by sigmoid(den).  NHWC in / out."""
+
+    def __init__(self, in_channels, out_channels, mid_channels=None, den=0.5):
+        super().__init__()
+        mid_channels = out_channels if mid_channels is None else mid_channels
+        self.in_channels = in_channels
+        self.edge_conv = nn.Conv2d(1, 4, kernel_size=3, padding=1, bias=False)       # fixed stencils; evaluated inside the edge kernel
+        sx = torch.tensor([[3., 0., -3.], [10., 0., -10.], [3., 0., -3.]]) / 16.0
+        sy = torch.tensor([[3., 10., 3.], [0., 0., 0.], [-3., -10., -3.]]) / 16.0
+        ox = torch.tensor([[1., 0., -1.], [2., 0., -2.], [1., 0., -1.]]) / 4.0
+        oy = torch.tensor([[1., 2., 1.], [0., 0., 0.], [-1., -2., -1.]]) / 4.0
+        self.edge_conv.weight.data = torch.stack([sx, sy, ox, oy], dim=0).unsqueeze(1)
+        self.edge_conv.weight.requires_grad = False
+        self.den = nn.Parameter(torch.tensor([den]))
+        self.alpha = nn.Parameter(torch.tensor(1.0))
+        self.conv1 = nn.Sequential(nn.Conv2d(in_channels, mid_channels, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(mid_channels),
+                                   nn.ReLU(inplace=True))
+        self.conv2 = nn.Sequential(nn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(out_channels))
+        self.edge_fusion = nn.Sequential(nn.Conv2d(5, 8, kernel_size=1), nn.ReLU(inplace=True), nn.Conv2d(8, mid_channels, kernel_size=1),
+                                         nn.Sigmoid())
+        self.register_buffer("phi_base", torch.ones(1, 1, 3, 3))
+        for c in (self.edge_conv, self.conv1[0]):
+            c._egm_no_prepack = True                      # edge_conv is never a conv launch; conv1's operand is weight * sigmoid(den)
+
+    def forward(self, x):
+        feats = ops.hegdc_edge_features(x, self.in_channels)
+        ef = self.edge_fusion
+        w = ops.act(ops.conv2d(feats, ef[0].weight, ef[0].bias), ACT_RELU)
+        w = ops.act(ops.conv2d(w, ef[2].weight, ef[2].bias), ACT_SIGMOID)
+        w1 = ops.scale_sigmoid(self.conv1[0].weight, self.den)
+        bn1 = self.conv1[1]
+        if bn1.training:
+            y, stats = ops.conv2d(x, w1, None, want_stats=True)
+            h = ops.bn_act(y, bn1, ACT_RELU, stats)
+        else:
+            h = ops.bn_act(ops.conv2d(x, w1, None), bn1, ACT_RELU)
+        h = ops.mul2_scalar(h, w, self.alpha)
+        return ops.conv_bn_act(h, self.conv2[0], self.conv2[1], ACT_RELU)
+
+
 class ELA(nn.Module):
     """Efficient Local Attention (src/EGM-UNet.py:56-79): strip means along W and H -> shared depthwise Conv1d(k) -> GroupNorm(16)
     -> sigmoid; out = x * g_h * g_w.  One of the reference's unused ablation blocks, NHWC in / out like every block here."""

@@ -902,6 +902,76 @@ def dwconv3(x, w, b, scale):
 
 
 # ----------------------------------------------------------------------------------------------------------
+# HEGDC pieces (src/EGM-UNet.py:210-340)
+# ----------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def hegdc_edge_features(x, c_real):
+    """The block's no_grad branch -> [N, H, W, 8] (5 real channels: scharr_x, scharr_y, sobel_x, sobel_y, blended magnitude)."""
+    x, ldx = _nhwc(x)
+    N, H, W, _ = x.shape
+    L = lib()
+    ws = torch.empty(L.query("egm_hegdc_edge_workspace", N, H, W) // 4 + 4, dtype=torch.float32, device=x.device)
+    feats = torch.empty((N, H, W, 8), dtype=x.dtype, device=x.device)
+    L.call("egm_hegdc_edge_features", dtype_code(x.dtype), ptr(x), ldx, c_real, ptr(feats), ptr(ws), N, H, W, stream())
+    return feats
+
+
+class _ScaleSigmoid(Function):
+    """w * sigmoid(den): conv1_weight * Phi with Phi = phi_base (ones) * sigmoid(den)  (src/EGM-UNet.py:262-265,325-327)"""
+
+    @staticmethod
+    def forward(ctx, w, den):
+        wc = w.detach().contiguous()
+        out = torch.empty_like(wc)
+        lib().call("egm_scale_sigmoid_fwd", ptr(wc), ptr(den.detach()), ptr(out), wc.numel(), stream())
+        ctx.save_for_backward(wc, den)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, den = ctx.saved_tensors
+        g = g.contiguous()
+        dw, dden = torch.empty_like(w), torch.empty_like(den, dtype=torch.float32)
+        part = _f32(256, w.device)
+        lib().call("egm_scale_sigmoid_bwd", ptr(g), ptr(w), ptr(den.detach()), ptr(dw), ptr(dden), ptr(part), w.numel(), stream())
+        return dw, dden.reshape(den.shape)
+
+
+def scale_sigmoid(w, den):
+    return _ScaleSigmoid.apply(w, den)
+
+
+class _Mul2Scalar(Function):
+    """a * b * alpha (alpha: learnable scalar parameter)  (src/EGM-UNet.py:332)"""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        a, lda = _nhwc(a); b, ldb = _nhwc(b)
+        out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+        al = alpha.detach().reshape(1).float()
+        lib().call("egm_mul2_scalar_fwd", dtype_code(a.dtype), ptr(a), lda, ptr(b), ldb, ptr(al), ptr(out), a.shape[3], _npix(a), a.shape[3], stream())
+        ctx.save_for_backward(a, b, al)
+        ctx.ashape = alpha.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, al = ctx.saved_tensors
+        a, lda = _nhwc(a); b, ldb = _nhwc(b); g, ldg = _nhwc(g)
+        C = a.shape[3]
+        da = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+        db = torch.empty(b.shape, dtype=b.dtype, device=b.device) if ctx.needs_input_grad[1] else None
+        dalpha, part = _f32(1, a.device), _f32(1024, a.device)
+        lib().call("egm_mul2_scalar_bwd", dtype_code(a.dtype), ptr(g), ldg, ptr(a), lda, ptr(b), ldb, ptr(al), ptr(da), C, ptr(db), C, ptr(dalpha),
+                   ptr(part), _npix(a), C, stream())
+        return da, db, dalpha.reshape(ctx.ashape)
+
+
+def mul2_scalar(a, b, alpha):
+    return _Mul2Scalar.apply(a, b, alpha)
+
+
+# ----------------------------------------------------------------------------------------------------------
 # ELA (Efficient Local Attention, src/EGM-UNet.py:56-79)
 # ----------------------------------------------------------------------------------------------------------
 class _ELA(Function):

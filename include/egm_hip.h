@@ -343,6 +343,23 @@ int egm_ela_bwd(int dtype, const void* g, int ldg, const void* x, int ldx, const
                 const float* gh, const float* gw, const float* stats, const float* conv_w, int ks, const float* gamma, void* dx, int lddx,
                 float* dconv_w, float* dgamma, float* dbeta, float* workspace, int N, int H, int W, int C, int groups, egm_stream_t s);
 
+/* ---- HEGDC (src/EGM-UNet.py:210-340; an unused ablation block of the reference) ---------------------------------------
+ * egm_hegdc_edge_features: the block's no_grad branch: channel mean -> fixed Scharr/16 + Sobel/4 stencils -> magnitudes ->
+ * min-max over the WHOLE batch -> sqrt (gamma 0.5) -> blend a*scharr + (1-a)*sobel, a = sigmoid(mean difference); feats
+ * [N][H][W][8] in the activation dtype holds (scharr_x, scharr_y, sobel_x, sobel_y, blend, 0, 0, 0).
+ * egm_scale_sigmoid_*: W * sigmoid(den) ("density" scaling of conv1's weight) and its gradients.
+ * egm_mul2_scalar_*: a * b * alpha with a learnable device scalar alpha and its gradients (db may be NULL). */
+long long egm_hegdc_edge_workspace(int N, int H, int W);
+int egm_hegdc_edge_features(int dtype, const void* x, int ldx, int C_real, void* feats, float* workspace, int N, int H, int W,
+                            egm_stream_t s);
+int egm_scale_sigmoid_fwd(const float* w, const float* den, float* out, long long n, egm_stream_t s);
+int egm_scale_sigmoid_bwd(const float* g, const float* w, const float* den, float* dw, float* dden, float* partials, long long n,
+                          egm_stream_t s);
+int egm_mul2_scalar_fwd(int dtype, const void* a, int lda, const void* b, int ldb, const float* alpha, void* out, int ldo, long long npix,
+                        int C, egm_stream_t s);
+int egm_mul2_scalar_bwd(int dtype, const void* g, int ldg, const void* a, int lda, const void* b, int ldb, const float* alpha, void* da,
+                        int ldda, void* db, int lddb, float* dalpha, float* partials, long long npix, int C, egm_stream_t s);
+
 /* ---- device-side data path (transforms.py, my_dataset.py:118-132) ----------------------------------------------
  * Decoded uint8 images [H][W][C] already in device memory.
  * egm_resample_u8: one separable pass of Pillow's antialiased resize (F.resize -> Image.resize(BILINEAR), transforms.py:39):

@@ -158,6 +158,24 @@ def edge_grfb(state: State, p: str, x, train: bool, scale: float = 0.1, visual: 
     return out * (1 + t.mean(dim=1, keepdim=True))
 
 
+def hegdc(state: State, p: str, x, train: bool):
+    """HEGDC (src/EGM-UNet.py:210-340): edge-guided, density-scaled double conv."""
+    with torch.no_grad():
+        edges = F.conv2d(x.mean(dim=1, keepdim=True), state[p + ".edge_conv.weight"], padding=1)
+        sx, sy, ox, oy = edges[:, 0:1], edges[:, 1:2], edges[:, 2:3], edges[:, 3:4]
+        sm = torch.sqrt(sx ** 2 + sy ** 2 + 1e-6)
+        sm = torch.pow((sm - sm.min()) / (sm.max() - sm.min() + 1e-6), 0.5)
+        om = ox.abs() + oy.abs()
+        om = (om - om.min()) / (om.max() - om.min() + 1e-6)
+        a = torch.sigmoid(sm.mean() - om.mean())
+        feats = torch.cat([edges, a * sm + (1 - a) * om], dim=1)
+    w = torch.sigmoid(_conv(state, p + ".edge_fusion.2", F.relu(_conv(state, p + ".edge_fusion.0", feats))))
+    w1 = state[p + ".conv1.0.weight"] * (state[p + ".phi_base"] * torch.sigmoid(state[p + ".den"]))
+    h = F.relu(_bn(state, p + ".conv1.1", F.conv2d(x, w1, padding=1), train))
+    h = h * w * state[p + ".alpha"]
+    return F.relu(_bn(state, p + ".conv2.1", _conv(state, p + ".conv2.0", h, padding=1), train))
+
+
 def ela(state: State, p: str, x, groups: int = 16, eps: float = 1e-5):
     """ELA (src/EGM-UNet.py:56-79): strip means -> shared depthwise Conv1d -> GroupNorm(16) -> sigmoid; x * g_h * g_w."""
     B, C, H, W = x.shape

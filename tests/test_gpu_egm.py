@@ -253,3 +253,13 @@ def test_ela_fixture(name, c, k):
     m = ELA(c, kernel_size=k)
     load_module_state(m, fx)
     run_block(m, fx, 1, grad_tol=dict(rtol=2e-3, atol=2e-4))
+
+
+def test_hegdc_fixture():
+    """HEGDC (src/EGM-UNet.py:210-340): edge features under no_grad with batch-global min-max, sigmoid(den) weight scaling, gated
+    double conv -- forward, input gradient and every parameter gradient (incl. den, alpha, edge_fusion) vs the reference fixture."""
+    from egm_unet_amd.egm_unet import HEGDC
+    fx = load_fixture("hegdc_16_24")
+    m = HEGDC(16, 24)
+    load_module_state(m, fx)
+    run_block(m, fx, 1, grad_tol=dict(rtol=5e-3, atol=5e-4))

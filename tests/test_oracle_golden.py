@@ -215,3 +215,16 @@ def test_ela_block(name):
     for k, v in fx.items():
         if k.startswith("grad/"):
             assert_close(st["m." + k[5:]].grad, v, rtol=2e-3, atol=1e-4, what=k)
+
+
+def test_hegdc_block():
+    fx = load_fixture("hegdc_16_24")
+    st = fixture_state(fx, prefix="m")
+    x = torch.from_numpy(fx["in0"]).requires_grad_(True)
+    out = R.hegdc(st, "m", x, True)
+    assert_close(out.detach(), fx["out"], what="hegdc out", **TOL)
+    (out * torch.from_numpy(fx["gout"])).sum().backward()
+    assert_close(x.grad, fx["gin0"], rtol=5e-3, atol=5e-5, what="gin")
+    for k, v in fx.items():
+        if k.startswith("grad/"):
+            assert_close(st["m." + k[5:]].grad, v, rtol=5e-3, atol=5e-4, what=k)

@@ -247,6 +247,11 @@ def main():
     block_fixture("ela_c64", m, [torch.randn(2, 64, 24, 36, generator=g2) + 0.3])
     m = egm.ELA(32, kernel_size=5)
     block_fixture("ela_c32_k5", m, [torch.randn(1, 32, 17, 9, generator=g2)])
+    torch.manual_seed(78)
+    m = egm.HEGDC(16, 24); randomize_bn(m, g2)
+    with torch.no_grad():
+        m.alpha.fill_(0.8); m.den.fill_(0.3)
+    block_fixture("hegdc_16_24", m, [torch.randn(2, 16, 20, 28, generator=g2)])
 
 
 if __name__ == "__main__":
