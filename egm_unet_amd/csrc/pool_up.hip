@@ -510,6 +510,84 @@ extern "C" int egm_dwconv3_bwd(int dtype, const void* x, int ldx, const void* dy
     return EGM_OK;
 }
 
+// ---- ConvTranspose2d(k=2, s=2) of Up(bilinear=False) (src/unet.py:36): a per-pixel GEMM (run as a 1x1 conv with 4*CoutP output
+// channels ordered (i, j, co)) followed by this 2x2 pixel shuffle, which also adds the bias and places the result at (oy, ox)
+// inside a zero-filled [Ho][Wo] frame (the F.pad of Up.forward, src/unet.py:46-47).
+namespace {
+template <typename T>
+__global__ void shuffle2x2_fwd_kernel(const T* __restrict__ y4, int ld4, const float* __restrict__ bias, int bias_n, T* __restrict__ out, int ldo,
+                                      int N, int H, int W, int C, int Ho, int Wo, int oy, int ox) {
+    const int ncv = C >> 3;
+    const long long total = (long long)N * Ho * Wo * ncv;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % ncv); const long long q = i / ncv;
+        const int X = (int)(q % Wo), Y = (int)((q / Wo) % Ho), n = (int)(q / ((long long)Wo * Ho));
+        const int yy = Y - oy, xx = X - ox;
+        float v[8];
+        zero8(v);
+        if (yy >= 0 && yy < 2 * H && xx >= 0 && xx < 2 * W) {
+            const long long pin = ((long long)n * H + (yy >> 1)) * W + (xx >> 1);
+            load8(y4 + pin * ld4 + (((yy & 1) * 2 + (xx & 1)) * C) + cv * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int c = cv * 8 + e; if (bias != nullptr && c < bias_n) v[e] = to_f32(from_f32<T>(v[e] + bias[c])); }
+        }
+        store8(out + q * ldo + cv * 8, v);
+    }
+}
+template <typename T>
+__global__ void shuffle2x2_bwd_kernel(const T* __restrict__ g, int ldg, T* __restrict__ d4, int ld4, int N, int H, int W, int C, int Ho, int Wo, int oy,
+                                      int ox) {
+    const int ncv = C >> 3;
+    const long long total = (long long)N * H * W * 4 * ncv;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int cv = (int)(i % ncv); long long q = i / ncv;
+        const int ij = (int)(q % 4); q /= 4;
+        const int x = (int)(q % W), y = (int)((q / W) % H), n = (int)(q / ((long long)W * H));
+        const int Y = 2 * y + (ij >> 1) + oy, X = 2 * x + (ij & 1) + ox;
+        float v[8];
+        zero8(v);
+        if (Y >= 0 && Y < Ho && X >= 0 && X < Wo) load8(g + (((long long)n * Ho + Y) * Wo + X) * ldg + cv * 8, v);
+        store8(d4 + (((long long)n * H + y) * W + x) * ld4 + ij * C + cv * 8, v);
+    }
+}
+// w [Cin][Cout][2][2] fp32  <->  w4 [(i*2+j)*CoutP + co][Cin] fp32 (rows of padded channels are zero)
+__global__ void convT_pack_kernel(const float* __restrict__ w, float* __restrict__ w4, int Cin, int Cout, int CoutP, int to_packed) {
+    const long long total = (long long)4 * CoutP * Cin;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ci = (int)(i % Cin); const long long r = i / Cin;
+        const int co = (int)(r % CoutP), ij = (int)(r / CoutP);
+        if (to_packed) w4[i] = co < Cout ? w[((long long)ci * Cout + co) * 4 + ij] : 0.f;
+        else if (co < Cout) const_cast<float*>(w)[((long long)ci * Cout + co) * 4 + ij] = w4[i];
+    }
+}
+}  // namespace
+
+extern "C" int egm_shuffle2x2_fwd(int dtype, const void* y4, int ld4, const float* bias, int bias_n, void* out, int ldo, int N, int H, int W, int C,
+                                  int Ho, int Wo, int oy, int ox, egm_stream_t s) {
+    EGM_REQ_VEC("shuffle2x2_fwd", out, ldo, C);
+    EGM_REQUIRE(y4 && ld4 >= 4 * C && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "shuffle2x2_fwd: bad args");
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((shuffle2x2_fwd_kernel<T>), dim3(stream_grid((long long)N * Ho * Wo * (C / 8))), dim3(256), 0,
+                                                 (hipStream_t)s, (const T*)y4, ld4, bias, bias_n, (T*)out, ldo, N, H, W, C, Ho, Wo, oy, ox));
+    EGM_CHECK_LAUNCH("shuffle2x2_fwd");
+    return EGM_OK;
+}
+extern "C" int egm_shuffle2x2_bwd(int dtype, const void* g, int ldg, void* d4, int ld4, int N, int H, int W, int C, int Ho, int Wo, int oy, int ox,
+                                  egm_stream_t s) {
+    EGM_REQ_VEC("shuffle2x2_bwd", g, ldg, C);
+    EGM_REQUIRE(d4 && ld4 >= 4 * C && N > 0 && H > 0 && W > 0, "shuffle2x2_bwd: bad args");
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((shuffle2x2_bwd_kernel<T>), dim3(stream_grid((long long)N * H * W * 4 * (C / 8))), dim3(256), 0,
+                                                 (hipStream_t)s, (const T*)g, ldg, (T*)d4, ld4, N, H, W, C, Ho, Wo, oy, ox));
+    EGM_CHECK_LAUNCH("shuffle2x2_bwd");
+    return EGM_OK;
+}
+extern "C" int egm_convT2x2_pack(float* w_iohw, float* w4, int Cin, int Cout, int CoutP, int to_packed, egm_stream_t s) {
+    EGM_REQUIRE(w_iohw && w4 && Cin > 0 && Cout > 0 && CoutP >= Cout, "convT2x2_pack: bad args");
+    hipLaunchKernelGGL(convT_pack_kernel, dim3(stream_grid((long long)4 * CoutP * Cin)), dim3(256), 0, (hipStream_t)s, w_iohw, w4, Cin, Cout, CoutP,
+                       to_packed);
+    EGM_CHECK_LAUNCH("convT2x2_pack");
+    return EGM_OK;
+}
+
 extern "C" int egm_axpby(int dtype, const void* a, int lda, float alpha, const void* b, int ldb, float beta, void* out, int ldo,
                          long long npix, int C, egm_stream_t s) {
     EGM_REQ_VEC("axpby", a, lda, C);

@@ -902,6 +902,71 @@ def dwconv3(x, w, b, scale):
 
 
 # ----------------------------------------------------------------------------------------------------------
+# ConvTranspose2d(k=2, s=2) of Up(bilinear=False)
+# ----------------------------------------------------------------------------------------------------------
+class _ConvTPack(Function):
+    """[Cin][Cout][2][2] parameter -> OIHW [4*CoutP, Cin, 1, 1] matrix of the equivalent 1x1 conv (rows ordered (i, j, co))"""
+
+    @staticmethod
+    def forward(ctx, w):
+        Cin, Cout = w.shape[0], w.shape[1]
+        CoutP = pad8(Cout)
+        w4 = torch.empty((4 * CoutP, Cin, 1, 1), dtype=torch.float32, device=w.device)
+        lib().call("egm_convT2x2_pack", ptr(w.detach().contiguous()), ptr(w4), Cin, Cout, CoutP, 1, stream())
+        ctx.shape = tuple(w.shape)
+        return w4
+
+    @staticmethod
+    def backward(ctx, g):
+        Cin, Cout = ctx.shape[0], ctx.shape[1]
+        dw = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        lib().call("egm_convT2x2_pack", ptr(dw), ptr(g.contiguous()), Cin, Cout, pad8(Cout), 0, stream())
+        return dw
+
+
+class _Shuffle2x2(Function):
+    @staticmethod
+    def forward(ctx, y4, bias, C, Ho, Wo):
+        y4, ld4 = _nhwc(y4)
+        N, H, W, _ = y4.shape
+        CP = pad8(C)
+        oy, ox = (Ho - 2 * H) // 2, (Wo - 2 * W) // 2          # F.pad(x1, [dx//2, dx - dx//2, dy//2, dy - dy//2])
+        out = torch.empty((N, Ho, Wo, CP), dtype=y4.dtype, device=y4.device)
+        lib().call("egm_shuffle2x2_fwd", dtype_code(y4.dtype), ptr(y4), ld4, ptr(bias.detach() if bias is not None else None), C, ptr(out), CP,
+                   N, H, W, CP, Ho, Wo, oy, ox, stream())
+        ctx.meta = (N, H, W, CP, Ho, Wo, oy, ox, C, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, H, W, CP, Ho, Wo, oy, ox, C, has_bias = ctx.meta
+        g, ldg = _nhwc(g)
+        d4 = torch.empty((N, H, W, 4 * CP), dtype=g.dtype, device=g.device)
+        lib().call("egm_shuffle2x2_bwd", dtype_code(g.dtype), ptr(g), ldg, ptr(d4), 4 * CP, N, H, W, CP, Ho, Wo, oy, ox, stream())
+        db = None
+        if has_bias and ctx.needs_input_grad[1]:
+            # frame positions outside the shuffled image get no bias: sum the gradient over the image region only = over d4
+            db4 = _channel_sum(d4)[0]
+            db = _fold4(db4, CP)[:C]
+        return d4, db, None, None, None
+
+
+def _fold4(v, CP):
+    """v [4*CP] fp32 -> [CP]: sum of the four (i, j) slices, on the device with the axpby kernel (no torch arithmetic)."""
+    t = v.reshape(1, 1, 4, CP)
+    a = _axpby(t[:, :, 0:1], 1.0, t[:, :, 1:2], 1.0)
+    b = _axpby(t[:, :, 2:3], 1.0, t[:, :, 3:4], 1.0)
+    return _axpby(a, 1.0, b, 1.0).reshape(CP)
+
+
+def conv_transpose2x2(x, convT, out_hw):
+    """nn.ConvTranspose2d(Cin, Cout, 2, stride=2) + F.pad to out_hw (src/unet.py:36,40-47).  x NHWC -> [N, Ho, Wo, pad8(Cout)]"""
+    w4 = _ConvTPack.apply(convT.weight)
+    y4 = conv2d(x, w4)
+    return _Shuffle2x2.apply(y4, convT.bias, convT.weight.shape[1], out_hw[0], out_hw[1])
+
+
+# ----------------------------------------------------------------------------------------------------------
 # HEGDC pieces (src/EGM-UNet.py:210-340)
 # ----------------------------------------------------------------------------------------------------------
 @torch.no_grad()

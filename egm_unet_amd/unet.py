@@ -42,17 +42,23 @@ class Down(nn.Sequential):
 
 
 class Up(nn.Module):
-    """bilinear x2 (align_corners=True) -> pad -> cat([skip, up]) -> DoubleConv   (src/unet.py:29-51)"""
+    """bilinear x2 (align_corners=True) or ConvTranspose2d(2, stride 2) -> pad -> cat([skip, up]) -> DoubleConv   (src/unet.py:29-51)"""
 
     def __init__(self, in_channels, out_channels, bilinear=True, use_attention=False):
         super().__init__()
-        if not bilinear:
-            raise NotImplementedError("egm_unet_amd: only the bilinear Up path of the reference is implemented")
-        self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
-        self.conv = DoubleConv(in_channels, out_channels, in_channels // 2)
+        self.bilinear = bilinear
+        if bilinear:
+            self.up = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+            self.conv = DoubleConv(in_channels, out_channels, in_channels // 2)
+        else:
+            self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
+            self.conv = DoubleConv(in_channels, out_channels)
 
     def forward(self, x1, x2):       # x1: low-res, x2: skip (both NHWC)
-        return self.conv(ops.upcat(x2, x1))
+        if self.bilinear:
+            return self.conv(ops.upcat(x2, x1))
+        x1 = ops.conv_transpose2x2(x1, self.up, (x2.shape[1], x2.shape[2]))
+        return self.conv(ops.cat_channels([x2, x1]))
 
 
 class OutConv(nn.Sequential):

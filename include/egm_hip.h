@@ -329,6 +329,16 @@ int egm_sgd_multi(const void* table_dev, int ntensors, long long total_chunks, c
 /* table of {float* dst; const float* src; long long n;}: gradient bucket gather/scatter for the RCCL all-reduce. */
 int egm_copy_multi(const void* table_dev, int ntensors, egm_stream_t s);
 
+/* ---- Up(bilinear=False): nn.ConvTranspose2d(Cin, Cout, 2, stride 2) (src/unet.py:36, src/EGM-UNet.py:941) ------------------
+ * Run as a 1x1 convolution with 4*CoutP output channels ordered (i, j, co) -- egm_convT2x2_pack rearranges the [Cin][Cout][2][2]
+ * parameter into that OIHW matrix (to_packed = 1) or scatters a gradient back (to_packed = 0) -- followed by the 2x2 pixel shuffle,
+ * which adds the bias and writes at offset (oy, ox) inside a zero-filled [Ho][Wo] frame (F.pad of Up.forward). */
+int egm_convT2x2_pack(float* w_iohw, float* w4, int Cin, int Cout, int CoutP, int to_packed, egm_stream_t s);
+int egm_shuffle2x2_fwd(int dtype, const void* y4, int ld4, const float* bias, int bias_n, void* out, int ldo, int N, int H, int W, int C,
+                       int Ho, int Wo, int oy, int ox, egm_stream_t s);
+int egm_shuffle2x2_bwd(int dtype, const void* g, int ldg, void* d4, int ld4, int N, int H, int W, int C, int Ho, int Wo, int oy, int ox,
+                       egm_stream_t s);
+
 /* ---- ELA, Efficient Local Attention (src/EGM-UNet.py:56-79; an unused ablation block of the reference) -----------
  * strip means mh [N][H][C] (over W) and mw [N][W][C] (over H), fp32 -> shared depthwise Conv1d(ks, no bias, conv_w [C][ks]) ->
  * GroupNorm(groups, C) -> sigmoid gates gh, gw -> out = x * gh[n,h,c] * gw[n,w,c].  yh/yw (conv outputs) and stats

@@ -50,6 +50,15 @@ def up_block(state: State, p: str, x_low, x_skip, train: bool):
     return double_conv(state, p + ".conv", torch.cat([x_skip, x_low], dim=1), train)
 
 
+def up_block_convT(state: State, p: str, x_low, x_skip, train: bool):
+    """Up.forward, bilinear=False branch: ConvTranspose2d(2, stride 2) instead of the upsample (src/unet.py:35-51)."""
+    x_low = F.conv_transpose2d(x_low, state[p + ".up.weight"], state[p + ".up.bias"], stride=2)
+    dy = x_skip.shape[2] - x_low.shape[2]
+    dx = x_skip.shape[3] - x_low.shape[3]
+    x_low = F.pad(x_low, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+    return double_conv(state, p + ".conv", torch.cat([x_skip, x_low], dim=1), train)
+
+
 # --------------------------------------------------------------------------- #
 # vanilla UNet (src/unet.py:61-96)
 # --------------------------------------------------------------------------- #

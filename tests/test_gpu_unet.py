@@ -57,6 +57,30 @@ def test_up_block_fixture(name):
     run_block(m, fx, 2)
 
 
+@pytest.mark.parametrize("name", ["up_block_convT", "up_block_convT_pad"])
+def test_up_block_conv_transpose_fixture(name):
+    """Up(bilinear=False): ConvTranspose2d(2, stride 2) as 1x1 conv + pixel shuffle (+ the zero pad for odd skip sizes)."""
+    from egm_unet_amd.unet import Up
+    fx = load_fixture(name)
+    m = Up(32, 16, bilinear=False)
+    load_module_state(m, fx)
+    run_block(m, fx, 2)
+
+
+def test_unet_conv_transpose_state_dict_and_step():
+    import json, os
+    from helpers import GOLDEN
+    from egm_unet_amd import UNet, GRFBUNet
+    man = json.load(open(os.path.join(GOLDEN, "unet_convT_manifest.json")))
+    m = UNet(3, 2, bilinear=False, base_c=8)
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == man
+    g = GRFBUNet(3, 2, bilinear=False, base_c=8).to(DEV).train()
+    out = g(torch.randn(2, 3, 64, 64, device=DEV))["out"]
+    assert out.shape == (2, 2, 64, 64)
+    out.sum().backward()
+    assert g.up1.up.weight.grad is not None and float(g.up1.up.weight.grad.abs().sum()) > 0
+
+
 def test_unet_b8_fixture_fp32():
     from egm_unet_amd import UNet
     fx = load_fixture("unet_b8")

@@ -42,6 +42,11 @@ def test_double_conv():
     assert _run_block("double_conv", lambda st, x: R.double_conv(st, "m", x, True)) == 6
 
 
+@pytest.mark.parametrize("name", ["up_block_convT", "up_block_convT_pad"])
+def test_up_block_conv_transpose(name):
+    _run_block(name, lambda st, a, b: R.up_block_convT(st, "m", a, b, True), n_in=2)
+
+
 @pytest.mark.parametrize("name", ["up_block", "up_block_pad"])
 def test_up_block(name):
     _run_block(name, lambda st, a, b: R.up_block(st, "m", a, b, True), n_in=2)

@@ -247,6 +247,14 @@ def main():
     block_fixture("ela_c64", m, [torch.randn(2, 64, 24, 36, generator=g2) + 0.3])
     m = egm.ELA(32, kernel_size=5)
     block_fixture("ela_c32_k5", m, [torch.randn(1, 32, 17, 9, generator=g2)])
+    # Up(bilinear=False): ConvTranspose2d(2, stride 2) + pad + cat + DoubleConv (src/unet.py:35-51); even and odd skip sizes
+    torch.manual_seed(79)
+    m = unet.Up(32, 16, bilinear=False); randomize_bn(m, g2)
+    block_fixture("up_block_convT", m, [torch.randn(2, 32, 10, 12, generator=g2), torch.randn(2, 16, 20, 24, generator=g2)])
+    m = unet.Up(32, 16, bilinear=False); randomize_bn(m, g2)
+    block_fixture("up_block_convT_pad", m, [torch.randn(1, 32, 7, 9, generator=g2), torch.randn(1, 16, 15, 19, generator=g2)])
+    mm = unet.UNet(3, 2, bilinear=False, base_c=8)
+    json.dump({k: list(v.shape) for k, v in mm.state_dict().items()}, open(os.path.join(OUT, "unet_convT_manifest.json"), "w"))
     torch.manual_seed(78)
     m = egm.HEGDC(16, 24); randomize_bn(m, g2)
     with torch.no_grad():
