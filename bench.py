@@ -215,6 +215,127 @@ def clipseg_bench(args, dev, rank, world):
                                      "global_batch": B * world, "parallelism": f"replicas x{world}"}}))
 
 
+def ablation_bench(args, dev, rank, world):
+    """BASELINE.json configs[4]: edge-guided attention + GRFB ablation at 3x1024x1024.
+    (a) the HBM-bound blocks in isolation on shapes derived from a Bx3x1024x1024 input with base_c = 32 (forward and backward timed
+    separately with HIP events on the launch stream); their GB/s is ALGORITHMIC bytes (inputs + outputs once each, bf16; backward:
+    incoming gradient + saved input + outgoing gradient) over the measured time, i.e. the fraction of a perfectly fused
+    implementation's HBM roofline.  (b) the full EGM-UNet(3,2,32) train step on Bx3x1024x1024 through the hipGraph path."""
+    from egm_unet_amd import GRFBUNet, ops
+    from egm_unet_amd._lib import require_gpu
+    from egm_unet_amd.egm_unet import Down, EdgeAwareFeatureEnhancer, EdgeEnhancedGRFB, MCALayer
+    from egm_unet_amd.optim import SGD
+    from egm_unet_amd.train_utils import criterion
+    from egm_unet_amd.unet import Up
+    require_gpu()
+    B = args.batch if args.batch != 8 else 2
+    S = args.size if args.size != 512 else 1024
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    esz = 2 if args.dtype == "bf16" else 4
+    g = torch.Generator().manual_seed(7 + rank)
+    reps = 10
+
+    def nhwc(c, s):
+        return torch.randn(B, s, s, c, generator=g).to(dev).to(dt)
+
+    # everything of part (a) lives on ONE non-default stream: tensors, autograd accumulators, warm-up, capture and replay
+    # (an AccumulateGrad node tied to another stream would put a cross-stream wait into the capture)
+    work = torch.cuda.Stream()
+
+    def timed(fn):
+        """mean device time of fn() replayed from a captured hipGraph (eager launches of the multi-kernel blocks are host-bound)"""
+        for _ in range(2):
+            fn()
+        work.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=work):
+            fn()
+        graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(work)
+        for _ in range(reps):
+            graph.replay()
+        e1.record(work)
+        work.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def block(name, row, module, ins, bytes_fwd=None, bytes_bwd=None):
+        """forward / backward of one block; algorithmic bytes default to in + out (fwd) and gout + in + gin (bwd)"""
+        if isinstance(module, torch.nn.Module):
+            module.to(dev).train()
+        xs = [x.clone().requires_grad_(True) for x in ins]
+        with torch.no_grad():
+            out = module(*ins)
+        go = torch.ones_like(out)
+        nin, nout = sum(x.numel() for x in ins), out.numel()
+        bf = bytes_fwd if bytes_fwd is not None else (nin + nout) * esz
+        bb = bytes_bwd if bytes_bwd is not None else (nout + 2 * nin) * esz
+        def f():
+            with torch.no_grad():
+                module(*ins)
+        t_f = timed(f)
+
+        def fb():
+            for x in xs:
+                x.grad = None
+            module(*xs).backward(go)
+        t_fb = timed(fb)
+        t_b = max(t_fb - t_f, 1e-6)
+        return {"block": name, "row": row, "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4),
+                "fwd_GBs": round(bf / t_f / 1e6, 1), "bwd_GBs": round(bb / t_b / 1e6, 1),
+                "fwd_frac_hbm": round(bf / t_f / 1e6 / HBM_PEAK_GBS, 3), "bwd_frac_hbm": round(bb / t_b / 1e6 / HBM_PEAK_GBS, 3)}
+
+    torch.manual_seed(0)
+    rows = []
+    h = S // 2
+    torch.cuda.synchronize()
+    _ctx = torch.cuda.stream(work)
+    _ctx.__enter__()
+    rows.append(block("MaxPool2d(2) 32ch @%d" % S, "K3", ops.maxpool2, [nhwc(32, S)]))
+    rows.append(block("bilinear x2 + concat (32ch @%d skip, 32ch @%d low)" % (S, h), "K10", lambda sk, lo: ops.upcat(sk, lo),
+                      [nhwc(32, S), nhwc(32, h)]))
+    rows.append(block("MCALayer(64) @%d" % h, "K4", MCALayer(64), [nhwc(64, h)]))
+    rows.append(block("EdgeAwareFeatureEnhancer(64) @%d" % h, "K5", EdgeAwareFeatureEnhancer(64), [nhwc(64, h)]))
+    rows.append(block("EdgeEnhancedGRFB(64,64) @%d" % h, "K5-K8", EdgeEnhancedGRFB(64, 64), [nhwc(64, h)]))
+    rows.append(block("Down(32,64) from @%d" % S, "K3+K1/K2+K4+K5-K8", Down(32, 64), [nhwc(32, S)]))
+    rows.append(block("Up(64,32) @%d" % S, "K10+K1/K2", Up(64, 32), [nhwc(32, h), nhwc(32, S)]))
+    work.synchronize()
+    _ctx.__exit__(None, None, None)
+    if rank == 0:
+        for r in rows:
+            print("[ablation] " + json.dumps(r), file=sys.stderr)
+    torch.cuda.empty_cache()
+
+    # (b) the whole network at 1024 x 1024
+    torch.manual_seed(0)
+    model = GRFBUNet(3, 2, base_c=32).to(dev).train()
+    model.set_compute_dtype(dt)
+    opt = SGD(model.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+    x, t = synth_batch(B, S, S, 1000 + rank, dev)
+    lw = torch.tensor([1.0, 2.0], device=dev)
+    from egm_unet_amd.graph import GraphedTrainStep
+    step = GraphedTrainStep(model, opt, x, t, lw, num_classes=2, ignore_index=255, reducer=None, warmup=2)
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if rank == 0:
+        k10 = rows[1]
+        print(json.dumps({
+            "metric": f"train images/sec at 3x{S}x{S} bs={B}/GPU (ablation, BASELINE.json configs[4])", "value": round(B * world * args.steps / el, 3),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"EGM-UNet GRFBUNet(3,2,base_c=32) fwd+loss+bwd+SGD, {B}x3x{S}x{S} per GPU + block table (replicas, no exchange)",
+                       "global_batch": B * world, "launch": "hipGraph replay", "final_loss": round(float(loss.detach()), 4)},
+            "roofline": {"bound": "hbm", "achieved": k10["fwd_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k10["fwd_frac_hbm"],
+                         "traffic": None, "kernel": "egm_upcat_fwd (K10 bilinear x2 + pad + concat, one kernel)"},
+            "blocks": rows}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,7 +345,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="egm_unet_train", choices=["egm_unet_train", "clipseg_infer", "clipseg_train"],
+    ap.add_argument("--workload", default="egm_unet_train", choices=["egm_unet_train", "clipseg_infer", "clipseg_train", "ablation_1024"],
                     help="egm_unet_train = the headline metric (BASELINE.json configs[1]); clipseg_infer = configs[3] (ViT-B/16 image+text "
                          "encode + decoder on 352x352), reported as a secondary line")
     ap.add_argument("--eager", action="store_true", help="issue every kernel from Python instead of replaying the captured hipGraph")
@@ -251,6 +372,8 @@ def main():
 
     if args.workload in ("clipseg_infer", "clipseg_train"):
         return clipseg_bench(args, dev, rank, world)
+    if args.workload == "ablation_1024":
+        return ablation_bench(args, dev, rank, world)
     from egm_unet_amd import GRFBUNet
     from egm_unet_amd._lib import lib, require_gpu
     from egm_unet_amd.optim import SGD
