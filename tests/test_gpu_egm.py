@@ -263,3 +263,77 @@ def test_hegdc_fixture():
     m = HEGDC(16, 24)
     load_module_state(m, fx)
     run_block(m, fx, 1, grad_tol=dict(rtol=5e-3, atol=5e-4))
+
+
+def _blob_dataset(n, size, seed):
+    """Learnable synthetic segmentation data: noise + a rectangular foreground blob with a colour offset; 1 % ignore pixels."""
+    g = torch.Generator().manual_seed(seed)
+    x = 0.6 * torch.randn(n, 3, size, size, generator=g)
+    t = torch.zeros(n, size, size, dtype=torch.int64)
+    for i in range(n):
+        cy, cx = torch.randint(size // 4, 3 * size // 4, (2,), generator=g).tolist()
+        hh, ww = torch.randint(size // 6, size // 3, (2,), generator=g).tolist()
+        t[i, max(0, cy - hh):cy + hh, max(0, cx - ww):cx + ww] = 1
+    fg = (t == 1).float().unsqueeze(1)
+    x = x + fg * torch.tensor([1.0, -0.6, 0.4]).view(1, 3, 1, 1)
+    t[torch.rand(n, size, size, generator=g) < 0.01] = 255
+    return x, t
+
+
+def test_training_run_val_miou_matches_oracle():
+    """SURVEY 8d mIoU check (ii): train the HIP build and the CPU oracle from the same seeded init on the same synthetic batches with
+    the reference's recipe (SGD 0.9 / 1e-4, warm-up + poly LR stepped per iteration, 5-term criterion, weights [1, 2]) and compare the
+    held-out mIoU: within +-0.1 points (north_star), every per-step loss within 2 %."""
+    from egm_unet_amd import GRFBUNet
+    from egm_unet_amd.optim import SGD
+    from egm_unet_amd.train_utils import create_lr_scheduler, criterion
+    from egm_unet_amd.train_utils.distributed_utils import ConfusionMatrix
+    from oracle import egm_ref as R, loss_ref as L
+    size, bs, nb, epochs, lr0 = 64, 4, 6, 8, 0.02
+    xs, ts = _blob_dataset(bs * nb, size, 31)
+    xv, tv = _blob_dataset(16, size, 32)
+    st = R.make_egm_unet_state(3, 2, 8, seed=9)
+    lw = torch.tensor([1.0, 2.0])
+    # ---- oracle run (CPU fp32; few threads: these tensors are small and a many-core host only adds fork/join overhead)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(8, nthreads))
+    params = {k: v.clone() for k, v in st.items() if v.is_floating_point() and "running_" not in k}
+    work, bufs, ref_losses = dict(st), {}, []
+    for step in range(epochs * nb):
+        b = step % nb
+        for k in params:
+            work[k] = params[k].detach().clone().requires_grad_(True)
+        loss = L.criterion(R.egm_unet_forward(work, xs[b * bs:(b + 1) * bs], True), ts[b * bs:(b + 1) * bs], lw, num_classes=2, ignore_index=255)
+        loss.backward()
+        with torch.no_grad():
+            L.sgd_step(params, {k: work[k].grad for k in params}, bufs, lr=lr0 * L.lr_factor(step, nb, epochs))
+        ref_losses.append(float(loss.detach()))
+    for k in params:
+        work[k] = params[k].detach()
+    with torch.no_grad():
+        ref_pred = R.egm_unet_forward(work, xv, False)["out"].argmax(1)
+    ref_mat = L.confusion_matrix(tv.flatten(), ref_pred.flatten(), 2)
+    ref_miou = float(L.confusion_metrics(ref_mat)[2].mean()) * 100
+    torch.set_num_threads(nthreads)
+    # ---- HIP run (fp32 path)
+    m = GRFBUNet(3, 2, base_c=8)
+    m.load_state_dict(st, strict=True)
+    m.to(DEV).train().set_compute_dtype(torch.float32)
+    opt = SGD(m.parameters(), lr=lr0, momentum=0.9, weight_decay=1e-4)
+    sched = create_lr_scheduler(opt, nb, epochs, warmup=True)
+    lwd, losses = lw.to(DEV), []
+    for step in range(epochs * nb):
+        b = step % nb
+        loss = criterion(m(xs[b * bs:(b + 1) * bs].to(DEV)), ts[b * bs:(b + 1) * bs].to(DEV), lwd, num_classes=2, ignore_index=255)
+        opt.zero_grad(); loss.backward(); opt.step(); sched.step()
+        losses.append(float(loss.detach()))
+    m.eval()
+    cm = ConfusionMatrix(2)
+    with torch.no_grad():
+        cm.update_from_logits(tv.to(DEV), m(xv.to(DEV))["out"])
+    miou = float(cm.compute()[2].mean()) * 100
+    worst = max(abs(a - b) / abs(b) for a, b in zip(losses, ref_losses))
+    print(f"val mIoU hip {miou:.3f} oracle {ref_miou:.3f}; loss first/last hip {losses[0]:.4f}/{losses[-1]:.4f} oracle {ref_losses[0]:.4f}/{ref_losses[-1]:.4f}; worst step rel {worst:.2e}")
+    assert ref_losses[-1] < 0.9 * ref_losses[0], "the synthetic task must be learnable for the comparison to mean anything"
+    assert worst < 2e-2, worst
+    assert abs(miou - ref_miou) <= 0.1, (miou, ref_miou)

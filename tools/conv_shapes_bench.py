@@ -15,6 +15,8 @@ SHAPES = [  # N, H, W, Cin, Cout, K, dil
     (8, 256, 256, 16, 16, 1, 1), (8, 256, 256, 64, 16, 1, 1), (8, 256, 256, 16, 64, 1, 1), (8, 512, 512, 32, 8, 1, 1),
     (8, 64, 64, 64, 64, 1, 1), (8, 32, 32, 64, 64, 1, 1), (8, 256, 256, 112, 16, 1, 1), (8, 128, 128, 224, 32, 1, 1),
     (8, 256, 256, 16, 16, 3, 12), (8, 128, 128, 32, 32, 3, 24), (8, 64, 64, 64, 64, 3, 12), (8, 32, 32, 64, 64, 3, 12),
+    (8, 256, 256, 16, 16, 3, 36), (8, 128, 128, 32, 32, 3, 12), (8, 256, 256, 8, 8, 1, 1), (8, 128, 128, 32, 32, 1, 1),
+    (8, 128, 128, 32, 128, 1, 1), (8, 512, 512, 8, 32, 1, 1), (8, 128, 128, 16, 16, 1, 1), (8, 256, 256, 32, 64, 1, 1),
 ]
 for N, H, W, Cin, Cout, K, dil in SHAPES:
     x = torch.randn(N, H, W, Cin, device="cuda").bfloat16()
