@@ -125,11 +125,13 @@ __device__ __forceinline__ Lerp lerp_coord(int dst, int in_size, int out_size) {
 template <typename T>
 __global__ void upcat_fwd_kernel(const T* __restrict__ skip, int lds, const T* __restrict__ low, int ldl, T* __restrict__ out,
                                  int ldo, int N, int Hs, int Ws, int Cs, int Hl, int Wl, int Cl) {
-    const int ncs = Cs >> 3, ncv = (Cs + Cl) >> 3;
+    // skip == nullptr: the skip channels already sit in out[..., :Cs] (their producer wrote them there); only the Cl upsampled channels
+    // are written
+    const int ncs = Cs >> 3, ncv = (Cs + Cl) >> 3, first = skip ? 0 : ncs, nw = ncv - first;
     const int Hu = 2 * Hl, Wu = 2 * Wl, py = (Hs - Hu) / 2, px = (Ws - Wu) / 2;
-    const long long total = (long long)N * Hs * Ws * ncv;
+    const long long total = (long long)N * Hs * Ws * nw;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv); const long long p = i / ncv;
+        const int cv = first + (int)(i % nw); const long long p = i / nw;
         float v[8];
         if (cv < ncs) {
             load8(skip + p * lds + cv * 8, v);
@@ -444,11 +446,12 @@ extern "C" int egm_maxpool2_bwd(int dtype, const void* x, int ldx, const void* d
 
 extern "C" int egm_upcat_fwd(int dtype, const void* skip, int lds, const void* low, int ldl, void* out, int ldo, int N, int Hs, int Ws,
                              int Cs, int Hl, int Wl, int Cl, egm_stream_t s) {
-    EGM_REQ_VEC("upcat_fwd", skip, lds, Cs);
+    if (skip != nullptr) EGM_REQ_VEC("upcat_fwd", skip, lds, Cs);
+    EGM_REQUIRE(Cs > 0 && Cs % 8 == 0, "upcat_fwd: bad Cs %d", Cs);
     EGM_REQ_VEC("upcat_fwd", low, ldl, Cl);
     EGM_REQ_VEC("upcat_fwd", out, ldo, Cs + Cl);
     EGM_REQUIRE(N > 0 && Hl > 0 && Wl > 0 && Hs >= 2 * Hl && Ws >= 2 * Wl, "upcat_fwd: skip must be at least 2x the low-res size");
-    const long long total = (long long)N * Hs * Ws * ((Cs + Cl) / 8);
+    const long long total = (long long)N * Hs * Ws * ((skip ? Cs + Cl : Cl) / 8);
     EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((upcat_fwd_kernel<T>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)s,
                                                  (const T*)skip, lds, (const T*)low, ldl, (T*)out, ldo, N, Hs, Ws, Cs, Hl, Wl, Cl));
     EGM_CHECK_LAUNCH("upcat_fwd");

@@ -84,9 +84,9 @@ class BasicConv(nn.Module):
         self.relu = nn.ReLU(inplace=True) if relu else None
         self._dil, self._groups = dilation, groups
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         return ops.conv_bn_act(x, self.conv, self.bn, ACT_RELU if self.relu is not None else ACT_NONE, dil=self._dil,
-                               groups=self._groups)
+                               groups=self._groups, out=out)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -188,19 +188,33 @@ class EdgeEnhancedGRFB(nn.Module):
         self.relu = nn.ReLU(inplace=False)
         self.target_enhancer = nn.Sequential(nn.Conv2d(out_channels, 3, 3, padding=1), nn.Sigmoid())
 
-    def forward(self, x):
+    @staticmethod
+    def _seq(seq, x, out):
+        """nn.Sequential of blocks whose last BasicConv writes into the concat slot `out`"""
+        for m in list(seq)[:-1]:
+            x = m(x)
+        return seq[-1](x, out=out)
+
+    def forward(self, x, out=None):
         x_e, x_e2, x_cat, x_sc = ops.fork(x, 4)
         xe = self.edge_enhancer(x_e, x_e2)
         xe_d, xe_e, xe_c = ops.fork(xe, 3)
-        d = self.branch_dir(xe_d)
-        e = self.branch_edge(xe_e)
-        c = self.branch_ctx(xe_c)
-        cat = ops.cat_channels([x_cat, d, e, c])
-        out = self.fusion_conv(cat)
-        out = ops.scale_add_relu(out, self.scale, self.shortcut(x_sc))          # relu(out*scale + short)
-        o_a, o_b = ops.fork(out, 2)
+        # the three branch tails write straight into their slots of the concat destination (no copy, one tensor write less each)
+        N, H, W, C = x.shape
+        i2 = ops.pad8(2 * self.inter_planes)
+        if i2 == 2 * self.inter_planes and C == self.shortcut.conv.in_channels:
+            buf, (_, sd, se, sc) = ops.cat_slots(N, H, W, [C, i2, i2, i2], x.dtype, x.device)
+        else:
+            buf, sd, se, sc = None, None, None, None
+        d = self._seq(self.branch_dir, xe_d, sd)
+        e = self._seq(self.branch_edge, xe_e, se)
+        c = self._seq(self.branch_ctx, xe_c, sc)
+        cat = ops.cat_channels([x_cat, d, e, c], buf)
+        out_f = self.fusion_conv(cat)
+        out_f = ops.scale_add_relu(out_f, self.scale, self.shortcut(x_sc))      # relu(out*scale + short)
+        o_a, o_b = ops.fork(out_f, 2)
         t = ops.conv2d(o_a, self.target_enhancer[0].weight, self.target_enhancer[0].bias)
-        return ops.gate3(o_b, t)                                                # out*(1 + mean_c sigmoid(t))
+        return ops.gate3(o_b, t, out)                                           # out*(1 + mean_c sigmoid(t))
 
 
 class Conv(nn.Module):
@@ -386,21 +400,21 @@ class DoubleConv1(nn.Sequential):
         super().__init__(*layers)
         self._mca = use_mca
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         o = 1 if self._mca else 0
         x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU)
         if self._mca:
             x = self[3](x)
         x = ops.conv_bn_act(x, self[3 + o], self[4 + o], ACT_RELU)
-        return self[6 + o](x)
+        return self[6 + o](x, out)
 
 
 class Down(nn.Sequential):
     def __init__(self, in_channels, out_channels, use_mca=True):
         super().__init__(nn.MaxPool2d(2, stride=2), DoubleConv1(in_channels, out_channels, use_mca=use_mca))
 
-    def forward(self, x):
-        return self[1](ops.maxpool2(x))
+    def forward(self, x, out=None):
+        return self[1](ops.maxpool2(x), out)
 
 
 class GRFBUNet(_SegNetBase):
@@ -426,13 +440,23 @@ class GRFBUNet(_SegNetBase):
 
     def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         x = self._enter(x)
-        x1, x1s = ops.fork(self.in_conv(x), 2)
-        x2, x2s = ops.fork(self.down1(x1), 2)
-        x3, x3s = ops.fork(self.down2(x2), 2)
-        x4, x4s = ops.fork(self.down3(x3), 2)
+        # skip tensors are produced straight into the first channels of the decoder's concat buffers (Up only adds the upsampled half)
+        bufs, slots = [None] * 4, [None] * 4
+        if self.bilinear:
+            N, H, W, _ = x.shape
+            for k, up in enumerate((self.up4, self.up3, self.up2, self.up1)):
+                cin = up.conv[0].in_channels
+                cs = cin // 2
+                h, w = H >> k, W >> k
+                if cs % 8 == 0 and cin % 8 == 0 and (h << k) == H and (w << k) == W:
+                    bufs[k], (slots[k], _) = ops.cat_slots(N, h, w, [cs, cin - cs], x.dtype, x.device)
+        x1, x1s = ops.fork(self.in_conv(x, slots[0]), 2)
+        x2, x2s = ops.fork(self.down1(x1, slots[1]), 2)
+        x3, x3s = ops.fork(self.down2(x2, slots[2]), 2)
+        x4, x4s = ops.fork(self.down3(x3, slots[3]), 2)
         x5 = self.attn1(self.down4(x4))
-        y = self.up1(x5, x4s)
-        y = self.up2(y, x3s)
-        y = self.up3(y, x2s)
-        y = self.up4(y, x1s)
+        y = self.up1(x5, x4s, bufs[3])
+        y = self.up2(y, x3s, bufs[2])
+        y = self.up3(y, x2s, bufs[1])
+        y = self.up4(y, x1s, bufs[0])
         return self._exit(self.out_conv(y))

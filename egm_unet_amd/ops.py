@@ -287,7 +287,7 @@ def conv2d(x, weight, bias=None, dil=1, groups=1, want_stats=False, bias_grad_ze
 # ----------------------------------------------------------------------------------------------------------
 class _BnAct(Function):
     @staticmethod
-    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, eps, momentum, act, training):
+    def forward(ctx, y, stats, gamma, beta, running_mean, running_var, eps, momentum, act, training, out_slot=None):
         y, ldy = _nhwc(y)
         N, H, W, CP = y.shape
         C, npix, dev = gamma.shape[0], _npix(y), y.device
@@ -304,8 +304,8 @@ class _BnAct(Function):
         else:
             L.call("egm_bn_eval_coeffs", ptr(gamma.detach()), ptr(beta.detach()), ptr(running_mean), ptr(running_var), eps,
                    ptr(scale), ptr(shift), ptr(mean), ptr(rstd), CP, C, st)
-        z = torch.empty((N, H, W, CP), dtype=y.dtype, device=dev)
-        L.call("egm_bn_act_fwd", dt, ptr(y), ldy, ptr(scale), ptr(shift), act, ptr(z), CP, npix, CP, st)
+        z, ldz = _slot_or_new(out_slot, (N, H, W, CP), y.dtype, dev)
+        L.call("egm_bn_act_fwd", dt, ptr(y), ldy, ptr(scale), ptr(shift), act, ptr(z), ldz, npix, CP, st)
         ctx.save_for_backward(y, coef)
         ctx.meta = (act, training, C)
         return z
@@ -333,25 +333,50 @@ class _BnAct(Function):
                    1 if training else 0, ptr(sums), ptr(gy), CP, npix, CP, st)
         ggamma = sums[1, :C] if ctx.needs_input_grad[2] else None
         gbeta = sums[0, :C] if ctx.needs_input_grad[3] else None
-        return gy, None, ggamma, gbeta, None, None, None, None, None, None
+        return gy, None, ggamma, gbeta, None, None, None, None, None, None, None
 
 
-def bn_act(y, bn, act, stats=None):
+def _slot_or_new(out_slot, shape, dtype, device):
+    """Output placement: `out_slot` is None or a one-element list holding a kernel-addressable NHWC view (a channel slice of a wider
+    buffer, e.g. of a concat destination) the result is written into -- the concat copy and its extra tensor write disappear.  The
+    list keeps the tensor out of autograd's sight: it is returned as a fresh output, not as an input passed through."""
+    if out_slot is None:
+        t = torch.empty(shape, dtype=dtype, device=device)
+        return t, shape[3]
+    t = out_slot[0]
+    v, ld = _nhwc(t)
+    if v.data_ptr() != t.data_ptr() or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+        raise RuntimeError(f"egm_unet_amd: output slot {tuple(t.shape)}/{t.dtype} does not fit result {tuple(shape)}/{dtype}")
+    return t, ld
+
+
+def cat_slots(N, H, W, channels, dtype, device):
+    """A concat destination [N, H, W, sum(channels)] and its channel-slice views, for producers that write in place."""
+    buf = torch.empty((N, H, W, sum(channels)), dtype=dtype, device=device)
+    views, off = [], 0
+    for c in channels:
+        views.append(buf[..., off:off + c])
+        off += c
+    return buf, views
+
+
+def bn_act(y, bn, act, stats=None, out=None):
     """bn: an nn.BatchNorm2d used as the parameter/buffer holder."""
     training = bn.training or bn.running_mean is None
     if bn.training and bn.num_batches_tracked is not None and not getattr(bn, "_egm_counter_managed", False):
         bn.num_batches_tracked.add_(1)                  # bookkeeping counter (int64), as nn.BatchNorm2d does
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    return _BnAct.apply(y, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, act, training)
+    return _BnAct.apply(y, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, act, training,
+                        None if out is None else [out])
 
 
-def conv_bn_act(x, conv, bn, act, dil=1, groups=1):
-    """conv -> BatchNorm -> activation with the BN statistics produced by the conv epilogue."""
+def conv_bn_act(x, conv, bn, act, dil=1, groups=1, out=None):
+    """conv -> BatchNorm -> activation with the BN statistics produced by the conv epilogue.  `out`: optional destination view."""
     if bn.training:
         # a conv bias feeding a train-mode BN has an identically zero gradient (the batch mean absorbs it)
         y, stats = conv2d(x, conv.weight, conv.bias, dil, groups, want_stats=True, bias_grad_zero=True)
-        return bn_act(y, bn, act, stats)
-    return bn_act(conv2d(x, conv.weight, conv.bias, dil, groups), bn, act)
+        return bn_act(y, bn, act, stats, out)
+    return bn_act(conv2d(x, conv.weight, conv.bias, dil, groups), bn, act, None, out)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -386,14 +411,26 @@ class _UpCat(Function):
     """cat([skip, pad(bilinear_x2(low))], channel)"""
 
     @staticmethod
-    def forward(ctx, skip, low):
+    def forward(ctx, skip, low, catbuf=None):
         skip, lds = _nhwc(skip)
         low, ldl = _nhwc(low)
         N, Hs, Ws, Cs = skip.shape
         _, Hl, Wl, Cl = low.shape
-        out = torch.empty((N, Hs, Ws, Cs + Cl), dtype=skip.dtype, device=skip.device)
-        lib().call("egm_upcat_fwd", dtype_code(skip.dtype), ptr(skip), lds, ptr(low), ldl, ptr(out), Cs + Cl, N, Hs, Ws, Cs,
-                   Hl, Wl, Cl, stream())
+        inplace = False
+        if catbuf is not None:
+            # the skip tensor was produced straight into the first Cs channels of the concat destination: only the upsampled half is
+            # written (a tensor write costs about twice a read on this part, and the skip copy was two thirds of this kernel's bytes)
+            cb = catbuf[0]
+            inplace = (cb.is_contiguous() and tuple(cb.shape) == (N, Hs, Ws, Cs + Cl) and cb.dtype == skip.dtype
+                       and cb.data_ptr() == skip.data_ptr() and lds == Cs + Cl)
+        if inplace:
+            out = cb
+            lib().call("egm_upcat_fwd", dtype_code(skip.dtype), None, lds, ptr(low), ldl, ptr(out), Cs + Cl, N, Hs, Ws, Cs,
+                       Hl, Wl, Cl, stream())
+        else:
+            out = torch.empty((N, Hs, Ws, Cs + Cl), dtype=skip.dtype, device=skip.device)
+            lib().call("egm_upcat_fwd", dtype_code(skip.dtype), ptr(skip), lds, ptr(low), ldl, ptr(out), Cs + Cl, N, Hs, Ws, Cs,
+                       Hl, Wl, Cl, stream())
         ctx.shape = (N, Hs, Ws, Cs, Hl, Wl, Cl)
         return out
 
@@ -407,11 +444,12 @@ class _UpCat(Function):
         if ctx.needs_input_grad[1]:
             glow = torch.empty((N, Hl, Wl, Cl), dtype=g.dtype, device=g.device)
             lib().call("egm_upcat_bwd_low", dtype_code(g.dtype), ptr(g), ldo, ptr(glow), Cl, N, Hs, Ws, Cs, Hl, Wl, Cl, stream())
-        return gskip, glow
+        return gskip, glow, None
 
 
-def upcat(skip, low):
-    return _UpCat.apply(skip, low)
+def upcat(skip, low, catbuf=None):
+    """catbuf: the concat destination whose first channels ARE `skip` (see cat_slots), or None for a fresh tensor + copy."""
+    return _UpCat.apply(skip, low, None if catbuf is None else [catbuf])
 
 
 class _Fork2(Function):
@@ -516,28 +554,35 @@ def split_channels(x, c0):
 
 class _CatC(Function):
     @staticmethod
-    def forward(ctx, *xs):
+    def forward(ctx, buf_slot, *xs):
         N, H, W = xs[0].shape[:3]
         cs = [x.shape[3] for x in xs]
-        out = torch.empty((N, H, W, sum(cs)), dtype=xs[0].dtype, device=xs[0].device)
+        buf = buf_slot[0] if buf_slot is not None else None
+        if buf is not None and not (buf.is_contiguous() and tuple(buf.shape) == (N, H, W, sum(cs)) and buf.dtype == xs[0].dtype):
+            raise RuntimeError("cat_channels: destination buffer does not match the inputs")
+        out = buf if buf is not None else torch.empty((N, H, W, sum(cs)), dtype=xs[0].dtype, device=xs[0].device)
         off = 0
         for x, c in zip(xs, cs):
-            _axpby(x, 1.0, None, 0.0, out[..., off:off + c])
+            dst = out[..., off:off + c]
+            # an input that was produced straight into its slot (bn_act / gate3 with out=) needs no copy
+            if not (x.data_ptr() == dst.data_ptr() and x.stride() == dst.stride()):
+                _axpby(x, 1.0, None, 0.0, dst)
             off += c
         ctx.cs = cs
         return out
 
     @staticmethod
     def backward(ctx, g):
-        outs, off = [], 0
+        outs, off = [None], 0
         for c in ctx.cs:
             outs.append(g[..., off:off + c])
             off += c
         return tuple(outs)
 
 
-def cat_channels(xs):
-    return _CatC.apply(*xs)
+def cat_channels(xs, buf=None):
+    """buf: optional destination from cat_slots(); inputs already living in their slot are not copied."""
+    return _CatC.apply(None if buf is None else [buf], *xs)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -619,11 +664,11 @@ def scale_add_relu(a, alpha, b):
 
 class _Gate3(Function):
     @staticmethod
-    def forward(ctx, x, t):
+    def forward(ctx, x, t, out_slot=None):
         x, ldx = _nhwc(x); t, ldt = _nhwc(t)
         C = x.shape[3]
-        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
-        lib().call("egm_gate3_fwd", dtype_code(x.dtype), ptr(x), ldx, ptr(t), ldt, ptr(out), C, _npix(x), C, stream())
+        out, ldo = _slot_or_new(out_slot, tuple(x.shape), x.dtype, x.device)
+        lib().call("egm_gate3_fwd", dtype_code(x.dtype), ptr(x), ldx, ptr(t), ldt, ptr(out), ldo, _npix(x), C, stream())
         ctx.save_for_backward(x, t)
         return out
 
@@ -635,11 +680,11 @@ class _Gate3(Function):
         dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
         dt = torch.empty(t.shape[:3] + (8,), dtype=x.dtype, device=x.device)
         lib().call("egm_gate3_bwd", dtype_code(x.dtype), ptr(g), ldg, ptr(x), ldx, ptr(t), ldt, ptr(dx), C, ptr(dt), 8, _npix(x), C, stream())
-        return dx, dt
+        return dx, dt, None
 
 
-def gate3(x, t):
-    return _Gate3.apply(x, t)
+def gate3(x, t, out=None):
+    return _Gate3.apply(x, t, None if out is None else [out])
 
 
 class _BcastGate(Function):

@@ -26,9 +26,9 @@ class DoubleConv(nn.Sequential):
             nn.ReLU(inplace=True),
         )
 
-    def forward(self, x):            # x: NHWC
+    def forward(self, x, out=None):  # x: NHWC; out: optional destination view (a concat slot)
         x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU)
-        return ops.conv_bn_act(x, self[3], self[4], ACT_RELU)
+        return ops.conv_bn_act(x, self[3], self[4], ACT_RELU, out=out)
 
 
 class Down(nn.Sequential):
@@ -54,9 +54,9 @@ class Up(nn.Module):
             self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
             self.conv = DoubleConv(in_channels, out_channels)
 
-    def forward(self, x1, x2):       # x1: low-res, x2: skip (both NHWC)
+    def forward(self, x1, x2, catbuf=None):   # x1: low-res, x2: skip (both NHWC); catbuf: concat destination that already holds x2
         if self.bilinear:
-            return self.conv(ops.upcat(x2, x1))
+            return self.conv(ops.upcat(x2, x1, catbuf))
         x1 = ops.conv_transpose2x2(x1, self.up, (x2.shape[1], x2.shape[2]))
         return self.conv(ops.cat_channels([x2, x1]))
 

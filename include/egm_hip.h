@@ -132,7 +132,8 @@ int egm_maxpool2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, int N,
 int egm_maxpool2_bwd(int dtype, const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int N, int H, int W,
                      int C, egm_stream_t s);
 /* Up.forward front half (src/EGM-UNet.py:937-947): out = cat([skip, pad(bilinear_x2_align_corners(low))], C).
- * Writes BOTH halves of `out` (ld = ldo >= Cs + Cl): skip [N,Hs,Ws,Cs], low [N,Hl,Wl,Cl]. */
+ * Writes BOTH halves of `out` (ld = ldo >= Cs + Cl): skip [N,Hs,Ws,Cs], low [N,Hl,Wl,Cl].
+ * skip == NULL: the skip channels were produced straight into out[..., :Cs] by their own kernel; only the Cl upsampled channels are written. */
 int egm_upcat_fwd(int dtype, const void* skip, int lds, const void* low, int ldl, void* out, int ldo, int N, int Hs, int Ws,
                   int Cs, int Hl, int Wl, int Cl, egm_stream_t s);
 /* dlow = transposed bilinear of dout[..., Cs:Cs+Cl]; (dskip is dout[..., :Cs], a view). */
