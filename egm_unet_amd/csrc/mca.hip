@@ -14,6 +14,7 @@
 // element in window scan order (the forward stencil records the arg-max/arg-min window positions as one byte per
 // element for the backward gather).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -280,6 +281,177 @@ __global__ void add_avg3_kernel(const T* __restrict__ a, int lda, const T* __res
         store8(out + p * ldo + cv * 8, c);
     }
 }
+// ---- fused forward tail: x, gates -> x_out (optional) / out / codes in ONE pass --------------------------------------------------
+// Replaces mca_xout + mca_stencil1 + add_avg3 (9.5 tensor passes, 4.5 of them writes, which cost about twice a read on this part) by
+// x read once (+ a 2-pixel halo that comes out of L2) and out / codes / x_out written once.  Measured at 8x256x256x64 bf16: 166 us
+// against 180 us for the three kernels; phase C (window max / min with arg codes: ~700 VALU operations per 8-channel vector) is
+// VALU-bound at ~75 us, phase A (the only HBM phase) takes 50 us.  A workgroup owns a 16 x 16 pixel tile
+// of a 32-channel chunk: phase A stages x_out = x * gate of the tile + 2-pixel halo in LDS (rounded to the storage type exactly as
+// the unfused kernels did through memory; out-of-image pixels are zeros = the avg pools' zero padding), phase B the squared high-pass
+// u2 on the tile + 1-pixel halo, phase C the window max / min (with arg codes), the channel shuffle and the final sum.  Same
+// summation order as the unfused kernels.
+constexpr int MF_TY = 16, MF_TX = 16, MF_CB = 32, MF_PY = MF_TY + 4, MF_PX = MF_TX + 4, MF_UY = MF_TY + 2, MF_UX = MF_TX + 2;
+template <typename T>
+__global__ __launch_bounds__(256) void mca_fused_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ gates,
+                                                            T* __restrict__ xo, int ldxo, T* __restrict__ out, int ldo,
+                                                            unsigned char* __restrict__ codes, int N, int H, int W, int C, int tiles_x,
+                                                            int tiles_y, int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
+    T* sxo = reinterpret_cast<T*>(mf_smem);                         // [PY*PX][CB]
+    T* su2 = sxo + MF_PY * MF_PX * MF_CB;                           // [UY*UX][CB]
+    const int tid = threadIdx.x, L = H + W + C;
+    int b = blockIdx.x;
+    const int chunk = b % nchunk; b /= nchunk;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y; const int n = b / tiles_y;
+    const int y0 = ty * MF_TY, x0 = tx * MF_TX, c0 = chunk * MF_CB;
+    const int nvec = (C - c0 < MF_CB ? C - c0 : MF_CB) >> 3;
+    const float* __restrict__ g = gates + (long long)n * L;
+    const long long img = (long long)n * H * W;
+    // gate terms: the thread's channel vector is fixed (256 % 4 == 0 -> v = tid & 3), so its eight channel gates and the eight of its
+    // shuffle sources live in registers; the row / column gates of the patch go through LDS
+    __shared__ float sgh[MF_PY], sgw[MF_PX];
+    if (tid < MF_PY) { const int gy = y0 + tid - 2; sgh[tid] = (gy >= 0 && gy < H) ? g[gy] : 0.f; }
+    else if (tid >= 64 && tid < 64 + MF_PX) { const int gx = x0 + tid - 64 - 2; sgw[tid - 64] = (gx >= 0 && gx < W) ? g[H + gx] : 0.f; }
+    const int vt = tid & 3;
+    float gc8[8], gs8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool okv = vt < nvec;
+        gc8[j] = okv ? g[H + W + c0 + vt * 8 + j] : 0.f;
+        gs8[j] = okv ? g[H + W + shuffle_src(c0 + vt * 8 + j, C)] : 0.f;
+    }
+
+    // ---- shuffle sources of this thread's phase-C items: issued first, consumed last (their latency hides behind phases A and B)
+    constexpr int NC = MF_TY * MF_TX * 4 / 256;
+    // out channel c = c0 + 8v + j takes source (j & 3) * C/4 + (c0 + 8v)/4 + (j >> 2): per group two adjacent channels
+    T shv[NC][8];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int i = tid + k * 256, pix = i >> 2, v = i & 3, ly = pix / MF_TX, lx = pix - ly * MF_TX;
+        const int gy = y0 + ly, gx = x0 + lx;
+        const bool ok = v < nvec && gy < H && gx < W;
+        const long long p = img + (long long)(ok ? gy : 0) * W + (ok ? gx : 0);
+        const int q0 = ok ? ((c0 + v * 8) >> 2) : 0;
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const T* sp = x + p * ldx + (ok ? grp * (C >> 2) : 0) + q0;
+            if (sizeof(T) == 2 && ((C >> 2) & 1) == 0) {          // both channels in one aligned 4-byte load
+                const uint32_t two = *reinterpret_cast<const uint32_t*>(sp);
+                __builtin_memcpy(&shv[k][grp], &two, 2);
+                const uint16_t hi = (uint16_t)(two >> 16);
+                __builtin_memcpy(&shv[k][grp + 4], &hi, 2);
+            } else {
+                shv[k][grp] = sp[0]; shv[k][grp + 4] = sp[1];
+            }
+        }
+    }
+    // ---- phase A: x_out patch (all loads of the thread issued before the first LDS store)
+    constexpr int NA = (MF_PY * MF_PX * 4 + 255) / 256;
+    uint4 raw[NA];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const int i = tid + k * 256, pix = i >> 2, v = i & 3, py = pix / MF_PX, px = pix - py * MF_PX;
+        const int gy = y0 + py - 2, gx = x0 + px - 2;
+        raw[k] = make_uint4(0, 0, 0, 0);
+        if (i < MF_PY * MF_PX * 4 && v < nvec && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const T* src = x + (img + (long long)gy * W + gx) * ldx + c0 + v * 8;
+            if (sizeof(T) == 2) raw[k] = *reinterpret_cast<const uint4*>(src);
+        }
+    }
+    __syncthreads();                                            // sgh / sgw visible
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const int i = tid + k * 256, pix = i >> 2, v = i & 3, py = pix / MF_PX, px = pix - py * MF_PX;
+        const int gy = y0 + py - 2, gx = x0 + px - 2;
+        if (i >= MF_PY * MF_PX * 4) continue;
+        float val[8];
+        zero8(val);
+        if (v < nvec && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const long long p = img + (long long)gy * W + gx;
+            if (sizeof(T) == 2) load8(reinterpret_cast<const T*>(&raw[k]), val);
+            else load8(x + p * ldx + c0 + v * 8, val);
+            const float ghw = sgh[py] + sgw[px];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) val[j] = to_f32(from_f32<T>(val[j] * ((ghw + gc8[j]) * (1.f / 3.f))));
+            if (xo != nullptr && py >= 2 && py < MF_TY + 2 && px >= 2 && px < MF_TX + 2) store8(xo + p * ldxo + c0 + v * 8, val);
+        }
+        store8(sxo + pix * MF_CB + v * 8, val);
+    }
+    __syncthreads();
+    // ---- phase B: u2 = (x_out - avg3 x_out)^2 on the tile + 1-pixel halo (zero outside the image)
+    for (int i = tid; i < MF_UY * MF_UX * 4; i += 256) {
+        const int pix = i >> 2, v = i & 3, uy = pix / MF_UX, ux = pix - uy * MF_UX;
+        const int gy = y0 + uy - 1, gx = x0 + ux - 1;
+        float o2[8];
+        zero8(o2);
+        if (v < nvec && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            float c[8], s8[8], t[8];
+            zero8(s8);
+            const T* ctr = sxo + ((uy + 1) * MF_PX + ux + 1) * MF_CB + v * 8;
+            load8(ctr, c);
+#pragma unroll
+            for (int r = -1; r <= 1; ++r)
+#pragma unroll
+                for (int q = -1; q <= 1; ++q) {
+                    load8(ctr + (r * MF_PX + q) * MF_CB, t);               // out-of-image neighbours are zeros in LDS
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s8[j] += t[j];
+                }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float u = c[j] - s8[j] * (1.f / 9.f); o2[j] = u * u; }
+        }
+        store8(su2 + pix * MF_CB + v * 8, o2);
+    }
+    __syncthreads();
+    // ---- phase C: out = 0.51 xo + 0.2 (max3 - min3) + 0.1 shuffle(xo) + 0.2 avg3(u2)
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int i = tid + k * 256;
+        const int pix = i >> 2, v = i & 3, ly = pix / MF_TX, lx = pix - ly * MF_TX;
+        const int gy = y0 + ly, gx = x0 + lx;
+        if (v >= nvec || gy >= H || gx >= W) continue;
+        const long long p = img + (long long)gy * W + gx;
+        float c[8], mx[8], mn[8], t[8], s2[8];
+        int amx[8], amn[8];
+        const T* ctr = sxo + ((ly + 2) * MF_PX + lx + 2) * MF_CB + v * 8;
+        const T* uctr = su2 + ((ly + 1) * MF_UX + lx + 1) * MF_CB + v * 8;
+        load8(ctr, c);
+        zero8(s2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mx[j] = -INFINITY; mn[j] = INFINITY; amx[j] = 4; amn[j] = 4; }
+#pragma unroll
+        for (int r = -1; r <= 1; ++r)
+#pragma unroll
+            for (int q = -1; q <= 1; ++q) {
+                load8(uctr + (r * MF_UX + q) * MF_CB, t);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s2[j] += t[j];
+                if (gy + r < 0 || gy + r >= H || gx + q < 0 || gx + q >= W) continue;   // max pool pads with -inf: skip
+                load8(ctr + (r * MF_PX + q) * MF_CB, t);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (t[j] > mx[j]) { mx[j] = t[j]; amx[j] = (r + 1) * 3 + (q + 1); }     // strict: first maximum wins
+                    if (t[j] < mn[j]) { mn[j] = t[j]; amn[j] = (r + 1) * 3 + (q + 1); }
+                }
+            }
+        const float ghw = sgh[ly + 2] + sgw[lx + 2];
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sh = to_f32(from_f32<T>(to_f32(shv[k][j]) * ((ghw + gs8[j]) * (1.f / 3.f))));
+            const float o1 = to_f32(from_f32<T>(0.51f * c[j] + 0.2f * (mx[j] - mn[j]) + 0.1f * sh));
+            o[j] = o1 + 0.2f * s2[j] * (1.f / 9.f);
+        }
+        store8(out + p * ldo + c0 + v * 8, o);
+        if (codes != nullptr) {
+            uint2 cd;
+            cd.x = (amx[0] | (amn[0] << 4)) | ((amx[1] | (amn[1] << 4)) << 8) | ((amx[2] | (amn[2] << 4)) << 16) | ((amx[3] | (amn[3] << 4)) << 24);
+            cd.y = (amx[4] | (amn[4] << 4)) | ((amx[5] | (amn[5] << 4)) << 8) | ((amx[6] | (amn[6] << 4)) << 16) | ((amx[7] | (amn[7] << 4)) << 24);
+            *reinterpret_cast<uint2*>(codes + p * C + c0 + v * 8) = cd;
+        }
+    }
+}
 // du = 0.4 * (xo - avg3(xo)) * avg3(g)          (= 2u * d(u^2), d(u^2) = 0.2*avg3(g))
 template <typename T>
 __global__ void mca_bwd_du_kernel(const T* __restrict__ xo, int ld, const T* __restrict__ g, int ldg, T* __restrict__ du, int ldd, int N, int H,
@@ -463,6 +635,34 @@ extern "C" int egm_add_avg3(int dtype, const void* a, int lda, const void* b, in
                                                  (const T*)b, ldb, scale, (T*)out, ldo, N, H, W, C));
     EGM_CHECK_LAUNCH("add_avg3");
     return EGM_OK;
+}
+template <typename T>
+static int launch_mca_fused(const void* x, int ldx, const float* gates, void* xo, int ldxo, void* out, int ldo, unsigned char* codes, int N, int H,
+                            int W, int C, hipStream_t st) {
+    const size_t smem = (size_t)(MF_PY * MF_PX + MF_UY * MF_UX) * MF_CB * sizeof(T);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mca_fused_fwd_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)smem);
+        if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "mca_fused_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    const int tiles_x = (W + MF_TX - 1) / MF_TX, tiles_y = (H + MF_TY - 1) / MF_TY, nchunk = (C + MF_CB - 1) / MF_CB;
+    const long long grid = (long long)N * tiles_x * tiles_y * nchunk;
+    EGM_REQUIRE(grid < (1LL << 31), "mca_fused_fwd: grid too large");
+    hipLaunchKernelGGL((mca_fused_fwd_kernel<T>), dim3((unsigned)grid), dim3(256), smem, st, (const T*)x, ldx, gates, (T*)xo, ldxo, (T*)out, ldo,
+                       codes, N, H, W, C, tiles_x, tiles_y, nchunk);
+    EGM_CHECK_LAUNCH("mca_fused_fwd");
+    return EGM_OK;
+}
+extern "C" int egm_mca_fused_fwd(int dtype, const void* x, int ldx, const float* gates, void* xo, int ldxo, void* out, int ldo,
+                                 unsigned char* codes, int N, int H, int W, int C, egm_stream_t s) {
+    EGM_REQ_VEC("mca_fused_fwd", x, ldx, C); EGM_REQ_VEC("mca_fused_fwd", out, ldo, C); EGM_REQ_SHAPE("mca_fused_fwd");
+    if (xo != nullptr) EGM_REQ_VEC("mca_fused_fwd", xo, ldxo, C);
+    EGM_REQUIRE(gates && C % 4 == 0 && (codes == nullptr || (reinterpret_cast<uintptr_t>(codes) & 7) == 0), "mca_fused_fwd: bad gates / codes buffer");
+    if (dtype == EGM_BF16) return launch_mca_fused<bf16_t>(x, ldx, gates, xo, ldxo, out, ldo, codes, N, H, W, C, (hipStream_t)s);
+    if (dtype == EGM_F32) return launch_mca_fused<float>(x, ldx, gates, xo, ldxo, out, ldo, codes, N, H, W, C, (hipStream_t)s);
+    EGM_FAIL(EGM_ERR_ARG, "mca_fused_fwd: unknown dtype %d", dtype);
 }
 extern "C" int egm_mca_bwd_du(int dtype, const void* xo, int ld, const void* g, int ldg, void* du, int ldd, int N, int H, int W, int C,
                               egm_stream_t s) {

@@ -1142,14 +1142,11 @@ class _MCALayer(Function):
         ks = (kh.numel(), kw.numel(), kc.numel())
         L.call("egm_mca_gates_fwd", ptr(sums), ptr(ps[0]), ptr(ps[1]), ks[0], ptr(ps[2]), ptr(ps[3]), ks[1], ptr(ps[4]), ptr(ps[5]), ks[2],
                ptr(stats), ptr(o), ptr(gates), N, H, W, C, st)
-        xo = torch.empty((N, H, W, C), dtype=x.dtype, device=dev)
-        L.call("egm_mca_xout", dt, ptr(x), ldx, ptr(gates), ptr(xo), C, N, H, W, C, st)
-        r1 = torch.empty_like(xo)
-        u2 = torch.empty_like(xo)
+        # x_out = x * gate, the 3x3 stencils (range, squared high-pass, its average), the channel shuffle and the sum: one fused pass
+        xo = torch.empty((N, H, W, C), dtype=x.dtype, device=dev) if training else None
         codes = torch.empty((N, H, W, C), dtype=torch.uint8, device=dev) if training else None
-        L.call("egm_mca_stencil1", dt, ptr(xo), C, ptr(r1), C, ptr(u2), C, ptr(codes), N, H, W, C, st)
-        out = torch.empty_like(xo)
-        L.call("egm_add_avg3", dt, ptr(r1), C, ptr(u2), C, 0.2, ptr(out), C, N, H, W, C, st)
+        out = torch.empty((N, H, W, C), dtype=x.dtype, device=dev)
+        L.call("egm_mca_fused_fwd", dt, ptr(x), ldx, ptr(gates), ptr(xo), C, ptr(out), C, ptr(codes), N, H, W, C, st)
         if training:
             ctx.save_for_backward(x, xo, codes, stats, o, gates, *ps)
             ctx.ks = ks

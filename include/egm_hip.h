@@ -243,6 +243,11 @@ int egm_mca_stencil1(int dtype, const void* xo, int ld, void* r1, int ldr, void*
                      int W, int C, egm_stream_t s);
 int egm_add_avg3(int dtype, const void* a, int lda, const void* b, int ldb, float scale, void* out, int ldo, int N, int H, int W,
                  int C, egm_stream_t s);
+/* The three calls above in ONE pass (x read once with a 2-pixel halo; out / codes / optionally x_out written once): 16 x 16 pixel tiles
+ * of 32-channel chunks staged through LDS.  xo may be NULL (the backward recomputes x_out = x * gate).  Same arithmetic, rounding points
+ * and summation order as egm_mca_xout + egm_mca_stencil1 + egm_add_avg3. */
+int egm_mca_fused_fwd(int dtype, const void* x, int ldx, const float* gates, void* xo, int ldxo, void* out, int ldo, unsigned char* codes,
+                      int N, int H, int W, int C, egm_stream_t s);
 /* backward chain: du = 0.4*(xo - avg3 xo)*avg3(g); dxo = 0.51 g + 0.1 unshuffle(g) + du - avg3(du) + 0.2*range_bwd(codes, g);
  * dx = dxo*(g_h+g_w+g_c)/3 + sum_axes(A + B*x) */
 int egm_mca_bwd_du(int dtype, const void* xo, int ld, const void* g, int ldg, void* du, int ldd, int N, int H, int W, int C,
