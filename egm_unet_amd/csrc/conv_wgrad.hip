@@ -31,6 +31,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 namespace {
 
 constexpr int TH = 8, TW = 32;
+constexpr int kMaxRowDil = 36;            // widest dilated kernel row staged as one patch (EGM-UNet: 12 / 24 / 36)
 
 template <typename T> struct WMma;
 template <> struct WMma<bf16_t> {
@@ -77,14 +78,21 @@ template <int NTAPS> struct Window;   // staged window of a tap group
 template <> struct Window<9> { static constexpr int WH = 3, WW = 3; };
 template <> struct Window<7> { static constexpr int WH = 1, WW = 7; };
 template <> struct Window<5> { static constexpr int WH = 1, WW = 5; };
+template <> struct Window<3> { static constexpr int WH = 1, WW = 3; };   // one kernel row of a DILATED 3x3: taps p.dil apart
 template <> struct Window<1> { static constexpr int WH = 1, WW = 1; };
 
 template <typename T, int NTAPS>
-__global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradParams p) {
+__global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2) ? 2 : 1) void conv_wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using M = WMma<T>;
     constexpr int WH = Window<NTAPS>::WH, WW = Window<NTAPS>::WW;
-    constexpr int PH = TH + WH - 1, PW = TW + WW - 1;
+    // NTAPS == 3 is the dilated 3x3 conv, one kernel row per tap group: the three taps of a row sit p.dil pixels apart inside ONE
+    // staged patch of TW + 2*dil columns (dil <= kMaxRowDil), so a dy tile is staged 3 times instead of 9 and a workgroup walks a
+    // third of the stages of the tap-by-tap form (which was stage-latency bound: 112 us for 16 -> 16 channels at 8x256x256).
+    constexpr bool DROW = (NTAPS == 3);
+    constexpr int PH = TH + WH - 1;
+    constexpr int PWC = DROW ? TW + 2 * kMaxRowDil : TW + WW - 1;     // compile-time bound of the patch width (staging slots)
+    const int PW = DROW ? TW + 2 * p.dil : TW + WW - 1;
     constexpr int RB = M::kRowBytes;
     constexpr int VEC = 16 / sizeof(T);           // elements per 16-byte vector
     constexpr int VPR = 32 / VEC;                 // vectors per 32-channel row
@@ -98,7 +106,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradParams p) {
 
     // tap group geometry: offset of the staged window relative to the output pixel, first tap index
     int offy, offx, tap0;
-    if (p.dil == 1) {
+    if (DROW) {
+        offy = (grp - 1) * p.dil; offx = -p.dil; tap0 = grp * 3;
+    } else if (p.dil == 1) {
         if (NTAPS == 9 || NTAPS == 1) { offy = -(p.KH / 2); offx = -(p.KW / 2); tap0 = 0; }
         else { offy = grp - p.KH / 2; offx = -(p.KW / 2); tap0 = grp * p.KW; }        // one kernel row
     } else {
@@ -118,8 +128,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradParams p) {
 
     const int tpi = p.tiles_y * p.tiles_x;
     // staging slots: thread handles 16-byte vectors i = tid + k*256 of the dy tile / x patch images
-    constexpr int DYVEC = (2 * TH * TW * VPR + 255) / 256;            // sized for A = 2
-    constexpr int XVEC = (2 * PH * PW * VPR + 255) / 256;             // sized for B = 2
+    constexpr int DYVEC = ((DROW ? 1 : 2) * TH * TW * VPR + 255) / 256;   // sized for A = 2 (dilated-row variant: A = 1 only)
+    constexpr int XVEC = ((DROW ? 1 : 2) * PH * PWC * VPR + 255) / 256;   // sized for B = 2 (dilated-row variant: B = 1 only)
     constexpr bool PIPE = (sizeof(T) == 2);                           // bf16: register prefetch (issue early / write late)
     uint4 pre_dy[PIPE ? DYVEC : 1], pre_x[PIPE ? XVEC : 1];
     const int ndy = p.A * TH * TW * VPR, nx = p.B * PH * PW * VPR;
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradParams p) {
         n = pt / tpi; const int trem = pt - n * tpi;
         oy0 = (trem / p.tiles_x) * TH; ox0 = (trem % p.tiles_x) * TW;
         // dilated taps: shifted tile wholly outside the image contributes zero (block-uniform)
-        return !(p.dil > 1 && (oy0 + offy >= p.H || oy0 + offy + TH <= 0 || ox0 + offx >= p.W || ox0 + offx + TW <= 0));
+        return !(p.dil > 1 && (oy0 + offy >= p.H || oy0 + offy + TH <= 0 || ox0 + offx >= p.W || ox0 + offx + (DROW ? PW : TW) <= 0));
     };
     auto load_dy = [&](int i, int n, int oy0, int ox0) {
         const int v = i % VPR, pix = (i / VPR) % (TH * TW), blk = i / (VPR * TH * TW);
@@ -146,8 +156,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradParams p) {
             val = *reinterpret_cast<const uint4*>(xg + ((long long)(n * p.H + iy) * p.W + ix) * p.ldx + c);
         return val;
     };
-    auto dy_lds = [&](int i) { return dyl + ((i / (VPR * TH * TW)) * TH * TW + (i / VPR) % (TH * TW)) * RB + (i % VPR) * 16; };
-    auto x_lds = [&](int i) { return xl + ((i / (VPR * PH * PW)) * PH * PW + (i / VPR) % (PH * PW)) * RB + (i % VPR) * 16; };
+    // vector i sits at block-major [32-ch block][pixel][v]: (i / VPR) * RB + (i % VPR) * 16 == 16 i
+    auto dy_lds = [&](int i) { return dyl + i * 16; };
+    auto x_lds = [&](int i) { return xl + i * 16; };
     auto next_tile = [&](int pt, int& n, int& oy0, int& ox0) {      // first contributing tile at or after pt (stride nsplit)
         while (pt < p.npt && !tile_ok(pt, n, oy0, ox0)) pt += p.nsplit;
         return pt;
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_kernel(WgradParams p) {
         auto load_step = [&](int ry, int k0, typename M::Frag& fa, typename M::Frag (&fb)[NTAPS]) __attribute__((always_inline)) {
             fa = M::load(ablk, ry * TW + k0, lane);
 #pragma unroll
-            for (int t = 0; t < NTAPS; ++t) fb[t] = M::load(bblk, (ry + t / WW) * PW + k0 + t % WW, lane);
+            for (int t = 0; t < NTAPS; ++t) fb[t] = M::load(bblk, DROW ? ry * PW + k0 + t * p.dil : (ry + t / WW) * PW + k0 + t % WW, lane);
         };
         auto mma_step = [&](const typename M::Frag& fa, const typename M::Frag (&fb)[NTAPS]) __attribute__((always_inline)) {
 #pragma unroll
@@ -416,20 +427,33 @@ int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW
         else if (KW == 5) { pl->ntaps = 5; pl->ngroups = KH; }
         else if (KW == 7) { pl->ntaps = 7; pl->ngroups = KH; }
         else return EGM_ERR_UNSUPPORTED;
-    } else { pl->ntaps = 1; pl->ngroups = KH * KW; }
+    } else {
+        // dilated 3x3: one kernel row (3 taps in one wide patch) per group when the patch fits LDS, else tap by tap
+        const int rbp = dtype == EGM_BF16 ? 64 : 128;
+        const int Ap = (dtype == EGM_F32 && Cout > 32 && Cin > 32) ? 1 : (Cout > 32 ? 2 : 1), Bp = Cin > 32 ? 2 : 1;
+        const size_t row_smem = (size_t)Ap * TH * TW * rbp + (size_t)Bp * TH * (TW + 2 * dil) * rbp;
+        // (small images: most of a wide patch lies outside the image and tap-by-tap with its whole-tile skips is faster -- measured)
+        if (KH == 3 && KW == 3 && dil <= kMaxRowDil && row_smem <= 156 * 1024 && W >= 128 && H >= 128 && Cin <= 32 && Cout <= 32) { pl->ntaps = 3; pl->ngroups = 3; }
+        else { pl->ntaps = 1; pl->ngroups = KH * KW; }
+    }
     int A = Cout > 32 ? 2 : 1, B = Cin > 32 ? 2 : 1;
     if (dtype == EGM_F32 && A * B == 4) A = 1;          // keep the fp32 LDS image under 160 KiB
     pl->A = A; pl->B = B; pl->C = 4 / (A * B);
     pl->nco_tiles = egm_cdiv(Cout, 32 * A); pl->nci_tiles = egm_cdiv(Cin, 32 * B);
     pl->tiles_y = egm_cdiv(H, TH); pl->tiles_x = egm_cdiv(W, TW); pl->npt = N * pl->tiles_y * pl->tiles_x;
     const int blocks_per_split = pl->nco_tiles * pl->nci_tiles * pl->ngroups;
-    int nsplit = 256 / blocks_per_split;          // ~one workgroup per CU
+    // ~one workgroup per CU; the 1- and 3-tap kernels are light on registers and stage-latency bound (a stage is two barriers around
+    // a handful of MFMAs), so they get as many co-resident workgroups per CU as EGM_WGRAD_PER_CU says (default 2)
+    static const int per_cu_small = getenv("EGM_WGRAD_PER_CU") ? atoi(getenv("EGM_WGRAD_PER_CU")) : 2;
+    const int per_cu = (pl->ntaps <= 3 && dtype == EGM_BF16) ? per_cu_small : 1;
+    int nsplit = 256 * per_cu / blocks_per_split;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > pl->npt) nsplit = pl->npt;
     pl->nsplit = nsplit;
     const int rb = dtype == EGM_BF16 ? 64 : 128;
     const int wh = pl->ntaps == 9 ? 3 : 1, ww = pl->ntaps == 9 ? 3 : pl->ntaps;
-    pl->smem = (size_t)A * TH * TW * rb + (size_t)B * (TH + wh - 1) * (TW + ww - 1) * rb;
+    const int pw = (dil > 1 && pl->ntaps == 3) ? TW + 2 * dil : TW + ww - 1;
+    pl->smem = (size_t)A * TH * TW * rb + (size_t)B * (TH + wh - 1) * pw * rb;
     // bf16: two LDS images filled by LDS-DMA (tile t+1 streams in while tile t is multiplied) when both fit
     static const int dma_off = getenv("EGM_WGRAD_NO_DMA") != nullptr;
     // (measured: 9 % faster on the 2 x 2-block layers, i.e. Cin, Cout > 32; slower on the narrow and the dilated ones, which keep
@@ -463,6 +487,7 @@ int dispatch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
         case 9: return launch_wgrad<T, 9>(p, pl, st);
         case 7: return launch_wgrad<T, 7>(p, pl, st);
         case 5: return launch_wgrad<T, 5>(p, pl, st);
+        case 3: return launch_wgrad<T, 3>(p, pl, st);
         case 1: return launch_wgrad<T, 1>(p, pl, st);
     }
     EGM_FAIL(EGM_ERR_UNSUPPORTED, "conv_wgrad: unsupported tap group %d", pl.ntaps);
