@@ -294,6 +294,18 @@ def ablation_bench(args, dev, rank, world):
     rows.append(block("MaxPool2d(2) 32ch @%d" % S, "K3", ops.maxpool2, [nhwc(32, S)]))
     rows.append(block("bilinear x2 + concat (32ch @%d skip, 32ch @%d low)" % (S, h), "K10", lambda sk, lo: ops.upcat(sk, lo),
                       [nhwc(32, S), nhwc(32, h)]))
+    # the product path: the skip tensor's producer wrote it into the concat buffer, the kernel adds only the upsampled half
+    cbuf, (cslot, _) = ops.cat_slots(B, S, S, [32, 32], dt, dev)
+    low_in = nhwc(32, h)
+
+    def upcat_inplace():
+        with torch.no_grad():
+            ops.upcat(cslot, low_in, cbuf)
+    t_ip = timed(upcat_inplace)
+    b_ip = (low_in.numel() + cbuf.numel() // 2) * esz
+    rows.append({"block": "bilinear x2 into the concat buffer that already holds the skip (32ch @%d low -> @%d)" % (h, S), "row": "K10 in place",
+                 "fwd_ms": round(t_ip, 4), "fwd_GBs": round(b_ip / t_ip / 1e6, 1), "fwd_frac_hbm": round(b_ip / t_ip / 1e6 / HBM_PEAK_GBS, 3)})
+    del cbuf, cslot, low_in
     rows.append(block("MCALayer(64) @%d" % h, "K4", MCALayer(64), [nhwc(64, h)]))
     rows.append(block("EdgeAwareFeatureEnhancer(64) @%d" % h, "K5", EdgeAwareFeatureEnhancer(64), [nhwc(64, h)]))
     rows.append(block("EdgeEnhancedGRFB(64,64) @%d" % h, "K5-K8", EdgeEnhancedGRFB(64, 64), [nhwc(64, h)]))

@@ -383,13 +383,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 // deferred reduction of MANY convolutions' slabs in one launch (end of backward): block -> (conv, 64-element chunk)
 struct WredEntry { const float* slab; float* dw; int nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate; };
+// block = kWredElems consecutive packed elements of one conv: 64 float4 columns x 4 slab lanes, two slabs per lane in flight.  (One
+// float per lane left 8 KiB in flight per CU: 1 GB of slabs per step read at 2.6 TB/s.)  Summation order per element is fixed:
+// lane sl adds slabs sl, sl+4, ... in order, the four lanes are combined as (0+1)+(2+3).
+constexpr int kWredElems = 256;
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WredEntry* __restrict__ tab, int n) {
-    __shared__ float red[256];
+    __shared__ float4 red[256];
     __shared__ int s_t, s_c;
     if (threadIdx.x == 0) {
         long long b = blockIdx.x; int t = 0;
         for (; t < n; ++t) {
-            const long long nch = ((long long)tab[t].taps * tab[t].CoutP * tab[t].CinP + 63) / 64;
+            const long long nch = ((long long)tab[t].taps * tab[t].CoutP * tab[t].CinP + kWredElems - 1) / kWredElems;
             if (b < nch) break;
             b -= nch;
         }
@@ -398,21 +402,39 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WredEntry
     __syncthreads();
     if (s_t >= n) return;
     const WredEntry w = tab[s_t];
-    const long long total = (long long)w.taps * w.CoutP * w.CinP;
+    const long long total = (long long)w.taps * w.CoutP * w.CinP;           // multiple of 8 (CinP is)
     const int cin_g = w.CinR / w.groups, cout_g = w.CoutR / w.groups;
     const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const long long i = (long long)s_c * 64 + e;
-    float s = 0.f;
-    if (i < total)
-        for (int k = sl; k < w.nslab; k += 4) s += w.slab[(long long)k * total + i];
+    const long long i0 = (long long)s_c * kWredElems + e * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i0 < total) {
+        const float* src = w.slab + i0;
+        int k = sl;
+        for (; k + 4 < w.nslab; k += 8) {
+            const float4 a = *reinterpret_cast<const float4*>(src + (long long)k * total);
+            const float4 c = *reinterpret_cast<const float4*>(src + (long long)(k + 4) * total);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+        }
+        if (k < w.nslab) {
+            const float4 a = *reinterpret_cast<const float4*>(src + (long long)k * total);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+    }
     red[threadIdx.x] = s;
     __syncthreads();
-    if (sl == 0 && i < total) {
-        s = (red[e] + red[64 + e]) + (red[128 + e] + red[192 + e]);
-        const int ci = (int)(i % w.CinP), co = (int)((i / w.CinP) % w.CoutP), tap = (int)(i / ((long long)w.CinP * w.CoutP));
-        if (co < w.CoutR && ci < w.CinR && (co / cout_g) == (ci / cin_g)) {
-            const long long o = ((long long)co * cin_g + (ci % cin_g)) * w.taps + tap;
-            w.dw[o] = w.accumulate ? w.dw[o] + s : s;
+    if (sl == 0 && i0 < total) {
+        const float4 r0 = red[e], r1 = red[64 + e], r2 = red[128 + e], r3 = red[192 + e];
+        const float v[4] = {(r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y), (r0.z + r1.z) + (r2.z + r3.z),
+                            (r0.w + r1.w) + (r2.w + r3.w)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long i = i0 + j;
+            const int ci = (int)(i % w.CinP), co = (int)((i / w.CinP) % w.CoutP), tap = (int)(i / ((long long)w.CinP * w.CoutP));
+            if (co < w.CoutR && ci < w.CinR && (co / cout_g) == (ci / cin_g)) {
+                const long long o = ((long long)co * cin_g + (ci % cin_g)) * w.taps + tap;
+                w.dw[o] = w.accumulate ? w.dw[o] + v[j] : v[j];
+            }
         }
     }
 }
@@ -516,6 +538,7 @@ extern "C" int egm_conv_wgrad_slabs(int dtype, int N, int H, int W, int Cin, int
     return pl.nsplit;
 }
 /* table: device array of {const float* slab; float* dw; int nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate;} (48 bytes) */
+extern "C" int egm_wgrad_reduce_chunk(void) { return kWredElems; }
 extern "C" int egm_wgrad_reduce_multi(const void* table_dev, int n, long long total_chunks, egm_stream_t s) {
     EGM_REQUIRE(table_dev && n > 0 && total_chunks > 0 && total_chunks < (1LL << 30), "wgrad_reduce_multi: bad args");
     hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)s, (const WredEntry*)table_dev, n);

@@ -188,6 +188,7 @@ def _flush_wgrads():
     if not _pending_wgrad:
         return
     blob, chunks = bytearray(), 0
+    per = lib().cdll.egm_wgrad_reduce_chunk()
     for ws, weight, nslab, taps, CoutP, CinP, Cout, Cin, groups in _pending_wgrad:
         # the gradient tensor returned from backward() was handed over to autograd (no reference kept here, so it is adopted
         # as weight.grad without a copy); fill it now, in place
@@ -195,7 +196,7 @@ def _flush_wgrads():
         if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != weight.shape:
             raise RuntimeError("egm_unet_amd: deferred weight gradient lost its destination")
         blob += struct.pack("<QQiiiiiiii", ws.data_ptr(), g.data_ptr(), nslab, taps, CoutP, CinP, Cout, Cin, groups, 0)
-        chunks += (taps * CoutP * CinP + 63) // 64
+        chunks += (taps * CoutP * CinP + per - 1) // per
     dev = _pending_wgrad[0][1].device
     table = _wgrad_table.get(bytes(blob), dev)
     lib().call("egm_wgrad_reduce_multi", ptr(table), len(_pending_wgrad), chunks, stream())

@@ -77,8 +77,9 @@ int egm_conv_wgrad(int dtype, const void* x, int ldx, const void* dy, int lddy, 
 /* Deferred form: egm_conv_wgrad with dw == NULL writes only the partial slabs (egm_conv_wgrad_slabs() of them) into the
  * workspace; egm_wgrad_reduce_multi() then finishes MANY convolutions in one launch.  table_dev: device array of 48-byte
  * entries {const float* slab; float* dw; int nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate;};
- * total_chunks = sum over entries of ceil(taps*CoutP*CinP / 64). */
+ * total_chunks = sum over entries of ceil(taps*CoutP*CinP / egm_wgrad_reduce_chunk()). */
 int egm_conv_wgrad_slabs(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
+int egm_wgrad_reduce_chunk(void);   /* packed elements reduced by one workgroup of egm_wgrad_reduce_multi */
 int egm_wgrad_reduce_multi(const void* table_dev, int n, long long total_chunks, egm_stream_t s);
 /* Depthwise 3x3 (RecursiveGatedAttention.dwconv, src/EGM-UNet.py:507-509): y = (dw3x3(x, w) + b) * scale.
  * w fp32 [C][1][3][3], b fp32 [C], scale fp32 [1] (device). */
