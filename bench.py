@@ -103,6 +103,32 @@ class KernelTimer:
                        f"{flop / t / 1e12:7.1f} TF/s {byts / t / 1e9:7.0f} GB/s  total={ms:6.3f}ms")
         return out
 
+    ENCODER_3X3 = [("in_conv.3", 32, 32, 512), ("down1.1.0", 32, 64, 256), ("down1.1.4", 64, 64, 256), ("down2.1.0", 64, 128, 128),
+                   ("down2.1.4", 128, 128, 128), ("down3.1.0", 128, 256, 64), ("down3.1.4", 256, 256, 64), ("down4.1.0/4", 256, 256, 32)]
+
+    def encoder_table(self):
+        """The 3x3 encoder convs north_star names, by shape (forward and data-gradient launches of that shape pooled): achieved
+        TFLOP/s, algorithmic GB/s and the fraction of the layer's own roofline min(MFMA peak, arithmetic intensity x HBM peak)."""
+        out = []
+        for name, cin, cout, hw in self.ENCODER_3X3:
+            n, ms, N = 0, 0.0, 8
+            for rname, args, e0, e1 in self.records:
+                if rname != "egm_conv_fwd":
+                    continue
+                N_, H, W, Cin, Cout, KH, KW, dil = args[9:17]
+                if KH == 3 and dil == 1 and H == hw and ((Cin, Cout) == (cin, cout) or (Cin, Cout) == (cout, cin)):
+                    n += 1; ms += e0.elapsed_time(e1); N = N_
+            if not n:
+                continue
+            flop = 2.0 * N * hw * hw * cin * cout * 9
+            byts = 2.0 * (N * hw * hw * (cin + cout) + 9 * cin * cout)
+            t = ms / n * 1e-3
+            roof_t = max(flop / (MFMA_BF16_PEAK_TFLOPS * 1e12), byts / (HBM_PEAK_GBS * 1e9))
+            out.append({"layer": name, "shape": f"{cin}->{cout}@{hw}", "launches": n, "us": round(t * 1e6, 1), "tflops": round(flop / t / 1e12, 1),
+                        "gbs": round(byts / t / 1e9), "bound": "mfma" if flop / (MFMA_BF16_PEAK_TFLOPS * 1e12) > byts / (HBM_PEAK_GBS * 1e9) else "hbm",
+                        "frac_of_layer_roofline": round(roof_t / t, 3)})
+        return out
+
     def summary(self):
         agg = {}
         for name, args, e0, e1 in self.records:
@@ -473,7 +499,9 @@ def main():
                     "share_of_step_kernel_time": round(dom[1] / total_ms, 3),
                     # sum over the launches of min(MFMA, HBM)-roofline time / measured time: the high-resolution layers of this
                     # U-Net are HBM-bound (AI 144-192 FLOP/B < ridge ~310), so "frac" vs the MFMA peak understates them
-                    "frac_of_per_layer_roofline": round(dom[4] / dom[1], 4) if args.dtype == "bf16" else None}
+                    "frac_of_per_layer_roofline": round(dom[4] / dom[1], 4) if args.dtype == "bf16" else None,
+                    # the layers the north_star target is quoted on, each against its own roofline
+                    "encoder_3x3": kt.encoder_table() if args.dtype == "bf16" and args.batch == 8 and args.size == 512 else None}
         top = sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]
         print(f"[bench] host enqueue {1e3 * t_enqueue / args.steps:.2f} ms/step vs wall {1e3 * elapsed / args.steps:.2f} ms/step", file=sys.stderr)
         print("[bench] kernel time by C-ABI entry (instrumented step, ms): " +
