@@ -238,3 +238,58 @@ def test_upcat(dtype, shapes):
     check(nchw(out, ref.shape[1]), ref.detach(), "out", **t)
     check(nchw(lg.grad, low.shape[1]), lr_.grad, "dlow", rtol=t["rtol"], atol=t["atol"] * 2)
     check(nchw(sg.grad, skip.shape[1]), sr_.grad, "dskip", **t)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 37, 29, 24), (1, 64, 48, 64), (2, 16, 16, 8)], ids=["ragged_c24", "c64", "one_tile_c8"])
+def test_mca_fused_tail_equals_the_three_kernels(dtype, shape):
+    """egm_mca_fused_fwd against egm_mca_xout + egm_mca_stencil1 + egm_add_avg3 on the same x and gates: x_out and the arg codes
+    bit-exact, out equal up to the last bit of the storage type (same rounding points; only FMA contraction may differ), including
+    ragged tiles (H, W not multiples of 16) and a partial 32-channel chunk.  Also the in-place upsample path against the copy path."""
+    from egm_unet_amd._lib import dtype_code, lib, ptr, stream
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(N, H, W, C, generator=g).to(DEV).to(dtype)
+    gates = torch.rand(N, H + W + C, generator=g).to(DEV)
+    L, dt, st = lib(), dtype_code(dtype), stream()
+    xo_a, r1, u2, out_a = (torch.empty_like(x) for _ in range(4))
+    codes_a = torch.empty((N, H, W, C), dtype=torch.uint8, device=DEV)
+    L.call("egm_mca_xout", dt, ptr(x), C, ptr(gates), ptr(xo_a), C, N, H, W, C, st)
+    L.call("egm_mca_stencil1", dt, ptr(xo_a), C, ptr(r1), C, ptr(u2), C, ptr(codes_a), N, H, W, C, st)
+    L.call("egm_add_avg3", dt, ptr(r1), C, ptr(u2), C, 0.2, ptr(out_a), C, N, H, W, C, st)
+    xo_b, out_b = torch.empty_like(x), torch.empty_like(x)
+    codes_b = torch.empty_like(codes_a)
+    L.call("egm_mca_fused_fwd", dt, ptr(x), C, ptr(gates), ptr(xo_b), C, ptr(out_b), C, ptr(codes_b), N, H, W, C, st)
+    torch.cuda.synchronize()
+    assert torch.equal(xo_a, xo_b)
+    assert torch.equal(codes_a, codes_b)
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    diff = (out_a.float() - out_b.float()).abs()
+    assert float(diff.max()) <= tol * (1.0 + float(out_a.float().abs().max())), float(diff.max())
+    assert float((diff > 0).float().mean()) < 0.02          # at most a stray last-bit difference here and there
+    # x_out may be dropped (inference)
+    out_c = torch.empty_like(x)
+    L.call("egm_mca_fused_fwd", dt, ptr(x), C, ptr(gates), None, C, ptr(out_c), C, None, N, H, W, C, st)
+    torch.cuda.synchronize()
+    assert torch.equal(out_b, out_c)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upcat_in_place_equals_copy(dtype):
+    """upcat into a concat buffer that already holds the skip (cat_slots) == upcat that copies the skip; gradients too."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    skip = torch.randn(2, 20, 24, 16, generator=g).to(DEV).to(dtype)
+    low = torch.randn(2, 10, 12, 8, generator=g).to(DEV).to(dtype)
+    s1, l1 = skip.clone().requires_grad_(True), low.clone().requires_grad_(True)
+    ref = ops.upcat(s1, l1)
+    buf, (slot, _) = ops.cat_slots(2, 20, 24, [16, 8], dtype, DEV)
+    l2 = low.clone().requires_grad_(True)
+    ops._axpby(skip, 1.0, None, 0.0, slot)                  # stands in for a producer that writes with out=slot
+    got = ops.upcat(slot, l2, buf)
+    assert got.data_ptr() == buf.data_ptr()
+    assert torch.equal(ref.detach(), got.detach())
+    gout = torch.randn(ref.shape, generator=g).to(DEV).to(dtype)
+    ref.backward(gout)
+    got.backward(gout)
+    assert torch.equal(l1.grad, l2.grad)
