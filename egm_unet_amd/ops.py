@@ -98,14 +98,19 @@ class DeviceTable:
     def __init__(self):
         self.key, self.pinned, self.device = None, None, None
 
+    def reserve(self, device, n=65536):
+        """Allocate the staging buffers now (pinned allocation is not legal inside a hipGraph capture)."""
+        if self.pinned is None or self.pinned.numel() < n:
+            cap = max(n, 65536)
+            self.pinned = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            self.device = torch.empty(cap, dtype=torch.uint8, device=device)
+            self.key = None
+
     def get(self, blob: bytes, device):
         if blob == self.key:
             return self.device
         n = len(blob)
-        if self.pinned is None or self.pinned.numel() < n:
-            cap = max(n, 4096)
-            self.pinned = torch.empty(cap, dtype=torch.uint8).pin_memory()
-            self.device = torch.empty(cap, dtype=torch.uint8, device=device)
+        self.reserve(device, n)
         self.pinned[:n] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
         self.device[:n].copy_(self.pinned[:n], non_blocking=True)
         self.key = blob
@@ -182,25 +187,44 @@ def prepack_model(model, dtype):
 # deferred weight-gradient reductions: the slab kernels run inside backward, ONE multi-conv reduce runs when backward ends
 _pending_wgrad = []
 _wgrad_table = DeviceTable()
+_wgrad_table_partial = DeviceTable()      # mid-backward flushes (eager gradient exchange): never disturbs the bytes a captured graph re-uploads
 
 
-def _flush_wgrads():
+def _flush_wgrads(ready_only=False):
+    """Finish the deferred weight gradients with ONE multi-conv reduction.  Runs as an autograd-engine callback when backward ends;
+    ready_only=True (a gradient bucket is about to be gathered mid-backward, parallel.GradAllReducer) finishes the convs whose
+    gradient tensor autograd has already adopted and leaves the others pending."""
     if not _pending_wgrad:
+        return
+    todo, later = [], []
+    for ent in _pending_wgrad:
+        weight = ent[1]
+        g = weight.grad
+        ok = g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == weight.shape
+        if ok:
+            todo.append(ent)
+        elif ready_only:
+            later.append(ent)
+        else:
+            raise RuntimeError("egm_unet_amd: deferred weight gradient lost its destination")
+    _pending_wgrad[:] = later
+    if not todo:
         return
     blob, chunks = bytearray(), 0
     per = lib().cdll.egm_wgrad_reduce_chunk()
-    for ws, weight, nslab, taps, CoutP, CinP, Cout, Cin, groups in _pending_wgrad:
+    for ws, weight, nslab, taps, CoutP, CinP, Cout, Cin, groups in todo:
         # the gradient tensor returned from backward() was handed over to autograd (no reference kept here, so it is adopted
         # as weight.grad without a copy); fill it now, in place
-        g = weight.grad
-        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != weight.shape:
-            raise RuntimeError("egm_unet_amd: deferred weight gradient lost its destination")
-        blob += struct.pack("<QQiiiiiiii", ws.data_ptr(), g.data_ptr(), nslab, taps, CoutP, CinP, Cout, Cin, groups, 0)
+        blob += struct.pack("<QQiiiiiiii", ws.data_ptr(), weight.grad.data_ptr(), nslab, taps, CoutP, CinP, Cout, Cin, groups, 0)
         chunks += (taps * CoutP * CinP + per - 1) // per
-    dev = _pending_wgrad[0][1].device
-    table = _wgrad_table.get(bytes(blob), dev)
-    lib().call("egm_wgrad_reduce_multi", ptr(table), len(_pending_wgrad), chunks, stream())
-    _pending_wgrad.clear()
+    dev = todo[0][1].device
+    _wgrad_table.reserve(dev); _wgrad_table_partial.reserve(dev)      # both exist before any capture can need them
+    table = (_wgrad_table_partial if ready_only else _wgrad_table).get(bytes(blob), dev)
+    lib().call("egm_wgrad_reduce_multi", ptr(table), len(todo), chunks, stream())
+
+
+def flush_ready_wgrads():
+    _flush_wgrads(ready_only=True)
 
 
 def _channel_sum(t):

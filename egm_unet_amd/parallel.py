@@ -73,6 +73,11 @@ class GradAllReducer:
             self._launch(b)
 
     def _launch(self, b):
+        # conv weight gradients are finished by one deferred multi-conv reduction (ops._flush_wgrads, normally when backward ends):
+        # bring the ones of this bucket up to date before they are gathered
+        if self.device.type == "cuda":
+            from . import ops
+            ops.flush_ready_wgrads()
         entries = [(self.views[p], p.grad) for p in self.buckets[b]]
         if self.side is not None:
             ev = torch.cuda.Event()

@@ -85,3 +85,31 @@ def test_bench_two_rank_code_path_rehearsal():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["value"] > 0 and line["roofline"] is not None
+
+
+def test_eager_bucket_gather_sees_finished_conv_gradients():
+    """The hook-driven (eager) exchange gathers bucket 0 in the middle of backward, while conv weight gradients are finished by a
+    deferred multi-conv reduction: every bucket view must equal the parameter's final .grad (world size 1: gather only)."""
+    sys.path.insert(0, ROOT)
+    from egm_unet_amd import GRFBUNet
+    from egm_unet_amd.parallel import GradAllReducer
+    from egm_unet_amd.train_utils import criterion
+    torch.manual_seed(0)
+    m = GRFBUNet(3, 2, base_c=8).to("cuda").train()
+    red = GradAllReducer(m, world_size=1)
+    assert len(red.buckets) == 2
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 64, 64, generator=g).cuda()
+    t = torch.randint(0, 2, (2, 64, 64), generator=g).cuda()
+    for p in m.parameters():
+        p.grad = None
+    # poison the allocator's free memory so that an unfinished gradient tensor cannot look right by accident
+    junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(64)]
+    del junk
+    loss = criterion(m(x), t, torch.tensor([1.0, 2.0], device="cuda"), num_classes=2, ignore_index=255)
+    loss.backward()
+    views = red.finish()
+    torch.cuda.synchronize()
+    bad = [n for n, p in m.named_parameters() if not torch.equal(views[p], p.grad)]
+    assert not bad, bad[:8]
+    red.remove()
