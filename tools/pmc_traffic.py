@@ -18,6 +18,10 @@ FAMILIES = [
     ("bn_act_bwd_reduce (channel_partials_kernel<bf16,1>)", re.compile(r"channel_partials_kernel<.*bf16_t, 1>")),
     ("bn_act_fwd", re.compile(r"bn_act_fwd_kernel")),
     ("wgrad_reduce_multi", re.compile(r"wgrad_reduce_multi_kernel")),
+    ("conv_wgrad[dilated rows] (conv_wgrad_kernel<bf16,3>)", re.compile(r"conv_wgrad_kernel<.*bf16_t, 3>")),
+    ("mca_fused_fwd", re.compile(r"mca_fused_fwd_kernel")),
+    ("upcat_fwd (in place: upsampled half only)", re.compile(r"upcat_fwd_kernel")),
+    ("maxpool2_fwd", re.compile(r"maxpool2_fwd_kernel")),
 ]
 
 
