@@ -46,13 +46,25 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(DirectParams p) {
 
     // ---- weights of this cout tile: staged once, zero rows past Cout, zero tail past Cin (the k-loop runs in steps of 16)
     {
+        // eight loads in flight per lane: one at a time, the 18 round trips of a 64 -> 64 dilated conv's 73 KB slab were a flat
+        // ~15 us in front of a kernel whose pixel work takes 5
         const int vec_per_row = nks * 2, total = ntaps * NT * 32 * vec_per_row;
-        for (int i = tid; i < total; i += 256) {
-            const int row = i / vec_per_row, cv = i - row * vec_per_row;
-            const int t = row / (NT * 32), j = row - t * (NT * 32), co = co0 + j;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (co < p.Cout && cv < cvecs) v = *reinterpret_cast<const uint4*>(wg + ((long long)t * p.Cout + co) * p.Cin + cv * 8);
-            *reinterpret_cast<uint4*>(wts + (size_t)row * p.wrow + cv * 16) = v;
+        for (int i0 = tid; i0 < total; i0 += 256 * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                const int row = i / vec_per_row, cv = i - row * vec_per_row;
+                const int t = row / (NT * 32), j = row - t * (NT * 32), co = co0 + j;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (i < total && co < p.Cout && cv < cvecs) v[u] = *reinterpret_cast<const uint4*>(wg + ((long long)t * p.Cout + co) * p.Cin + cv * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                const int row = i / vec_per_row, cv = i - row * vec_per_row;
+                if (i < total) *reinterpret_cast<uint4*>(wts + (size_t)row * p.wrow + cv * 16) = v[u];
+            }
         }
     }
     __syncthreads();
