@@ -113,3 +113,49 @@ def test_eager_bucket_gather_sees_finished_conv_gradients():
     bad = [n for n, p in m.named_parameters() if not torch.equal(views[p], p.grad)]
     assert not bad, bad[:8]
     red.remove()
+
+
+def test_reducer_paths_match_plain_training_bitwise():
+    """World size 1: two SGD steps (a) without a reducer, (b) with the hook-driven eager exchange, (c) as hipGraph replays followed by
+    reduce_now() must leave bit-identical weights -- the exchange only moves gradients around."""
+    sys.path.insert(0, ROOT)
+    import copy
+    from egm_unet_amd import GRFBUNet
+    from egm_unet_amd.graph import GraphedTrainStep
+    from egm_unet_amd.optim import SGD
+    from egm_unet_amd.parallel import GradAllReducer
+    from egm_unet_amd.train_utils import criterion
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 3, 64, 64, generator=g).cuda()
+    t = torch.randint(0, 2, (2, 64, 64), generator=g).cuda()
+    lw = torch.tensor([1.0, 2.0], device="cuda")
+    torch.manual_seed(0)
+    base = GRFBUNet(3, 2, base_c=8).to("cuda").train()
+    sd0 = copy.deepcopy(base.state_dict())
+
+    def run(mode):
+        m = GRFBUNet(3, 2, base_c=8).to("cuda").train()
+        m.load_state_dict(sd0)
+        opt = SGD(m.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+        red = GradAllReducer(m, world_size=1) if mode != "plain" else None
+        if mode == "graph":
+            step = GraphedTrainStep(m, opt, x, t, lw, num_classes=2, ignore_index=255, reducer=red, warmup=1)   # warm-up = step 1
+            step()
+        else:
+            for _ in range(2):
+                loss = criterion(m(x), t, lw, num_classes=2, ignore_index=255)
+                opt.zero_grad()
+                loss.backward()
+                if red is not None:
+                    opt.grad_source = red.finish()
+                opt.step()
+        torch.cuda.synchronize()
+        if red is not None:
+            red.remove()
+        return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    plain, eager, graph = run("plain"), run("eager"), run("graph")
+    bad_e = [k for k in plain if not torch.equal(plain[k], eager[k])]
+    bad_g = [k for k in plain if not torch.equal(plain[k], graph[k])]
+    assert not bad_e, ("eager reducer", bad_e[:6])
+    assert not bad_g, ("graphed reducer", bad_g[:6])
