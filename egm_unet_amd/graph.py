@@ -26,16 +26,19 @@ class GraphedTrainStep:
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
-        with torch.cuda.stream(side):                 # warm-up on a side stream (allocator, lazy kernel attributes, SGD state)
+        # warm-up and capture share one table namespace of their own: the pointer tables the graph re-uploads on every replay are
+        # written here and never again (ops.table_namespace)
+        self._ns = ops.table_namespace(("graph", id(self)))
+        with torch.cuda.stream(side), self._ns:       # warm-up on a side stream (allocator, lazy kernel attributes, SGD state)
             for _ in range(max(1, warmup)):
-                self._eager()
+                self.warmup_loss = self._eager().detach()
         cur.wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
         if self.reducer is not None:
             self.reducer.hooks_enabled = False       # no collectives inside the captured graph
-        with torch.cuda.graph(self.graph):
+        with self._ns, torch.cuda.graph(self.graph):
             loss = criterion(self.model(self.x), self.t, self.lw, num_classes=self.nc, ignore_index=self.ign)
             loss.backward()
             if self.reducer is None:

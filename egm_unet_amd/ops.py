@@ -91,30 +91,52 @@ def to_nchw(x_nhwc, C):
 # ----------------------------------------------------------------------------------------------------------
 # descriptor tables for the multi-tensor kernels
 # ----------------------------------------------------------------------------------------------------------
+# Pointer tables are uploaded through pinned staging buffers.  A captured hipGraph re-copies the SAME pinned bytes on every replay, so
+# the tables a capture uses must never be rewritten by anybody else (an eager step between replays, another capture): everything
+# issued under table_namespace(tag) -- GraphedTrainStep runs its warm-up and its capture under one tag -- gets buffers of its own.
+_table_tag = [None]
+
+
+class table_namespace:
+    def __init__(self, tag):
+        self.tag, self.prev = tag, None
+
+    def __enter__(self):
+        self.prev, _table_tag[0] = _table_tag[0], self.tag
+
+    def __exit__(self, *a):
+        _table_tag[0] = self.prev
+
+
 class DeviceTable:
     """Packed C structs on the device.  Re-uploaded only when the bytes change; the upload is an async copy from a pinned
-    staging buffer, so it is legal inside hipGraph capture (replays re-copy the same bytes)."""
+    staging buffer, so it is legal inside hipGraph capture (replays re-copy the same bytes).  One set of buffers per table namespace."""
 
     def __init__(self):
-        self.key, self.pinned, self.device = None, None, None
+        self.slots = {}                      # tag -> [key, pinned, device]
+
+    def _slot(self):
+        return self.slots.setdefault(_table_tag[0], [None, None, None])
 
     def reserve(self, device, n=65536):
         """Allocate the staging buffers now (pinned allocation is not legal inside a hipGraph capture)."""
-        if self.pinned is None or self.pinned.numel() < n:
+        sl = self._slot()
+        if sl[1] is None or sl[1].numel() < n:
             cap = max(n, 65536)
-            self.pinned = torch.empty(cap, dtype=torch.uint8).pin_memory()
-            self.device = torch.empty(cap, dtype=torch.uint8, device=device)
-            self.key = None
+            sl[1] = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            sl[2] = torch.empty(cap, dtype=torch.uint8, device=device)
+            sl[0] = None
 
     def get(self, blob: bytes, device):
-        if blob == self.key:
-            return self.device
+        sl = self._slot()
+        if blob == sl[0]:
+            return sl[2]
         n = len(blob)
         self.reserve(device, n)
-        self.pinned[:n] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
-        self.device[:n].copy_(self.pinned[:n], non_blocking=True)
-        self.key = blob
-        return self.device
+        sl[1][:n] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        sl[2][:n].copy_(sl[1][:n], non_blocking=True)
+        sl[0] = blob
+        return sl[2]
 
 
 # ----------------------------------------------------------------------------------------------------------

@@ -14,6 +14,8 @@ class SGD(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self.grad_scale = 1.0          # e.g. 1/world_size when gradients arrive as an all-reduced SUM
         self.grad_source = None        # optional {param: fp32 tensor view} overriding p.grad (DDP buckets)
+        self.lr_dev = None             # optional device fp32 scalar read by the kernel instead of the by-value lr (a captured hipGraph
+                                       # bakes by-value arguments in; a per-iteration LR schedule needs the value in memory)
         self._tables = {}              # (group index, first) -> (key, pinned host table, device table)
 
     @staticmethod
@@ -21,6 +23,7 @@ class SGD(torch.optim.Optimizer):
         return torch.empty((cap, 4), dtype=torch.int64).pin_memory(), torch.empty((cap, 4), dtype=torch.int64, device=dev)
 
     def _device_table(self, slot, rows, dev):
+        slot = (ops._table_tag[0],) + slot            # a captured graph's tables are its own (ops.table_namespace)
         """Pointer table on the device.  Re-uploaded only when a pointer changed; the upload is an async copy from a
         pinned staging buffer, so it is legal inside hipGraph capture (and replays re-copy the same bytes)."""
         key = tuple(rows)
@@ -42,9 +45,9 @@ class SGD(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         for gi, group in enumerate(self.param_groups):
             for first in (True, False):           # staging buffers exist before any hipGraph capture can need them
-                if (gi, first) not in self._tables and group["params"]:
+                if (ops._table_tag[0], gi, first) not in self._tables and group["params"]:
                     cap = max(512, len(group["params"]))
-                    self._tables[(gi, first)] = (None,) + self._alloc_table(cap, group["params"][0].device)
+                    self._tables[(ops._table_tag[0], gi, first)] = (None,) + self._alloc_table(cap, group["params"][0].device)
             rows = {True: [], False: []}          # first-step parameters take v = g (no stale buffer read)
             keep = []
             for p in group["params"]:
@@ -69,7 +72,7 @@ class SGD(torch.optim.Optimizer):
                 table = self._device_table((gi, first), rows[first], group["params"][0].device)
                 ch = lib().cdll.egm_sgd_chunk()
                 chunks = sum((r[3] + ch - 1) // ch for r in rows[first])
-                lib().call("egm_sgd_multi", ptr(table), len(rows[first]), chunks, None, float(group["lr"]), float(group["momentum"]),
+                lib().call("egm_sgd_multi", ptr(table), len(rows[first]), chunks, ptr(self.lr_dev), float(group["lr"]), float(group["momentum"]),
                            float(group["weight_decay"]), float(self.grad_scale), 1 if first else 0, stream())
         ops.bump_weight_generation()
         return loss

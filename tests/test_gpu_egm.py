@@ -353,3 +353,34 @@ def test_training_run_val_miou_matches_oracle():
     assert worst < 1e-3, worst
     lo, hi = min(miou_a, miou_b), max(miou_a, miou_b)
     assert lo - 0.75 <= miou <= hi + 0.75, (miou, miou_a, miou_b)
+
+
+def test_train_one_epoch_graph_replay_equals_eager_loop(monkeypatch):
+    """train_utils.train_one_epoch: the hipGraph-replayed loop (default) and the eager loop (EGM_GRAPH_TRAIN=0) give bit-identical
+    weights and the same mean loss / final lr over two epochs with a per-iteration LR schedule and a short last batch."""
+    import copy
+    from egm_unet_amd import GRFBUNet
+    from egm_unet_amd.optim import SGD
+    from egm_unet_amd.train_utils import create_lr_scheduler, train_one_epoch
+    xs, ts = _blob_dataset(14, 64, 41)
+    loader = [(xs[i:i + 4], ts[i:i + 4]) for i in range(0, 14, 4)]        # 4, 4, 4, 2 images
+    torch.manual_seed(3)
+    sd0 = copy.deepcopy(GRFBUNet(3, 2, base_c=8).state_dict())
+
+    def run(graph):
+        monkeypatch.setenv("EGM_GRAPH_TRAIN", "1" if graph else "0")
+        m = GRFBUNet(3, 2, base_c=8)
+        m.load_state_dict(sd0)
+        m.to(DEV)
+        opt = SGD(m.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+        sched = create_lr_scheduler(opt, len(loader), 2, warmup=True)
+        out = [train_one_epoch(m, opt, loader, DEV, ep, 2, sched, print_freq=100) for ep in range(2)]
+        torch.cuda.synchronize()
+        return out, {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    (ra, sa), (rb, sb) = run(True), run(False)
+    assert [round(a[1], 9) for a in ra] == [round(b[1], 9) for b in rb]            # lr after each epoch
+    for a, b in zip(ra, rb):
+        assert abs(a[0] - b[0]) <= 1e-6 * abs(b[0]), (a, b)                        # mean loss of the epoch
+    bad = [k for k in sa if not torch.equal(sa[k], sb[k])]
+    assert not bad, bad[:6]
