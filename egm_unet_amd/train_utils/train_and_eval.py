@@ -68,10 +68,11 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch, num_classes, l
         lr_pinned = torch.zeros(1, dtype=torch.float32).pin_memory()
         # a step captured in an earlier epoch is reused while model, optimizer, precision and class count are the same objects / values
         # (its graph holds the pointer of ITS lr scalar, so that tensor comes back with it)
-        key = (id(optimizer), getattr(core, "compute_dtype", None), num_classes)
+        import weakref
+        key = (getattr(core, "compute_dtype", None), num_classes)
         cached = getattr(model, "_egm_train_graph", None)
-        if cached is not None and cached[0] == key:
-            _, step, step_shape, optimizer.lr_dev = cached
+        if cached is not None and cached[0] == key and cached[4]() is optimizer:      # the very same optimizer object, still alive
+            _, step, step_shape, optimizer.lr_dev, _ = cached
         else:
             model._egm_train_graph = None
             optimizer.lr_dev = torch.zeros(1, dtype=torch.float32, device=device)
@@ -98,7 +99,7 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch, num_classes, l
             # warmup=1: the eager warm-up IS this batch's training step; capture records the next ones without executing anything
             step = GraphedTrainStep(model, optimizer, image, target, loss_weight, num_classes=num_classes, ignore_index=255, warmup=1)
             step_shape = shape
-            model._egm_train_graph = (key, step, step_shape, optimizer.lr_dev)
+            model._egm_train_graph = (key, step, step_shape, optimizer.lr_dev, weakref.ref(optimizer))
             loss = step.warmup_loss
         else:
             output = model(image)
