@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""MFMA utilisation per kernel family from one rocprofv3 counter pass (--pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; no tracing
+flags): MfmaUtil = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE * SIMDs) as in rocprofv3's own derived metric (ROCm 7.2 has no
+gfx950 section; this is the gfx94x formula: GRBM_GUI_ACTIVE is summed over the 8 XCDs, 1024 SIMDs).
+usage: pmc_mfma.py <counter_collection.csv> <out.json>"""
+import collections
+import csv
+import json
+import re
+import sys
+
+FAMILIES = [
+    ("conv fwd/dgrad 3x3, 64-wide cout tiles (conv_igemm_pipe_kernel<2,3,3,2>)", re.compile(r"conv_igemm_pipe_kernel<2, 3, 3, 2>")),
+    ("conv fwd/dgrad 3x3, tall tiles (conv_igemm_pipe_kernel<1,3,3,4>)", re.compile(r"conv_igemm_pipe_kernel<1, 3, 3, 4>")),
+    ("conv fwd/dgrad 1x1 (conv_igemm_pipe_kernel<*,1,1,2>)", re.compile(r"conv_igemm_pipe_kernel<\d, 1, 1, 2>")),
+    ("conv wgrad 3x3 (conv_wgrad_kernel<bf16,9>)", re.compile(r"conv_wgrad_kernel<.*bf16_t, 9>")),
+    ("conv wgrad 1x1 (conv_wgrad_kernel<bf16,1>)", re.compile(r"conv_wgrad_kernel<.*bf16_t, 1>")),
+]
+
+
+def main():
+    per = collections.defaultdict(lambda: collections.defaultdict(float))      # dispatch -> counter -> value
+    name = {}
+    for r in csv.DictReader(open(sys.argv[1])):
+        per[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+        name[r["Dispatch_Id"]] = r["Kernel_Name"]
+    out = {}
+    for fam, rx in FAMILIES:
+        rows = [(c["SQ_VALU_MFMA_BUSY_CYCLES"], c["GRBM_GUI_ACTIVE"]) for d, c in per.items() if rx.search(name[d]) and c["GRBM_GUI_ACTIVE"] > 0]
+        if not rows:
+            continue
+        utils = sorted(100.0 * b / (g / 8.0 * 1024.0) for b, g in rows)          # GRBM_GUI_ACTIVE: sum over 8 XCDs; 1024 SIMDs
+        tot = 100.0 * sum(b for b, _ in rows) / (sum(g for _, g in rows) / 8.0 * 1024.0)
+        out[fam] = {"launches": len(rows), "mfma_util_pct_time_weighted": round(tot, 1), "best_launch_pct": round(utils[-1], 1),
+                    "median_launch_pct": round(utils[len(utils) // 2], 1)}
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
