@@ -32,6 +32,12 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
+    # objects and the library are only reusable under the flags they were built with (a library left over from a diagnostic
+    # build, e.g. -DEGM_CONV_TIMING, must never be picked up by a normal one): the flag set is stamped next to the objects
+    stamp_path = os.path.join(LIBDIR, "flags.stamp")          # next to the library, so it travels with it
+    stamp = " ".join([HIPCC] + FLAGS)
+    if not os.path.exists(stamp_path) or open(stamp_path).read() != stamp:
+        force = True
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "egm_hip.h"))
     jobs = []
@@ -62,6 +68,8 @@ def build(force=False, verbose=True):
             raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
         if verbose:
             print(f"built {LIB} ({len(jobs)} recompiled)")
+    with open(stamp_path, "w") as f:
+        f.write(stamp)
     return LIB
 
 

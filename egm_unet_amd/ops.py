@@ -113,10 +113,10 @@ class DeviceTable:
     staging buffer, so it is legal inside hipGraph capture (replays re-copy the same bytes).  One set of buffers per table namespace."""
 
     def __init__(self):
-        self.slots = {}                      # tag -> [key, pinned, device]
+        self.slots = {}                      # tag -> [key, pinned, device, upload event]
 
     def _slot(self):
-        return self.slots.setdefault(_table_tag[0], [None, None, None])
+        return self.slots.setdefault(_table_tag[0], [None, None, None, None])
 
     def reserve(self, device, n=65536):
         """Allocate the staging buffers now (pinned allocation is not legal inside a hipGraph capture)."""
@@ -125,7 +125,7 @@ class DeviceTable:
             cap = max(n, 65536)
             sl[1] = torch.empty(cap, dtype=torch.uint8).pin_memory()
             sl[2] = torch.empty(cap, dtype=torch.uint8, device=device)
-            sl[0] = None
+            sl[0] = sl[3] = None
 
     def get(self, blob: bytes, device):
         sl = self._slot()
@@ -133,10 +133,26 @@ class DeviceTable:
             return sl[2]
         n = len(blob)
         self.reserve(device, n)
-        sl[1][:n] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
-        sl[2][:n].copy_(sl[1][:n], non_blocking=True)
+        upload_pinned(sl, 1, 2, 3, torch.frombuffer(bytearray(blob), dtype=torch.uint8), n)
         sl[0] = blob
         return sl[2]
+
+
+def upload_pinned(slot, i_pinned, i_device, i_event, host_values, n):
+    """Rewrite the first n elements of a pinned staging buffer and copy them to its device twin (async).  The host write must not
+    overtake the previous upload from the same buffer (the copy engine may not have read it yet when the host runs ahead of the
+    GPU), so every upload records an event and the next rewrite waits for it.  Inside a hipGraph capture neither is possible nor
+    needed: a capture owns its table namespace, whose buffers are written once."""
+    capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    ev = slot[i_event]
+    if ev is not None and not capturing:
+        ev.synchronize()
+    slot[i_pinned][:n] = host_values
+    slot[i_device][:n].copy_(slot[i_pinned][:n], non_blocking=True)
+    if not capturing and slot[i_device].is_cuda:
+        if ev is None:
+            ev = slot[i_event] = torch.cuda.Event()
+        ev.record()
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -206,8 +222,35 @@ def prepack_model(model, dtype):
     st["stamp"] = stamp
 
 
-# deferred weight-gradient reductions: the slab kernels run inside backward, ONE multi-conv reduce runs when backward ends
+# deferred weight-gradient reductions: the slab kernels run inside backward, ONE multi-conv reduce runs when backward ends.
+# Deferral hands autograd a gradient tensor that is filled later, which is only sound when that tensor is the weight's ONLY
+# contribution in this backward (autograd would otherwise sum unfilled buffers): _conv_uses counts the conv forwards a weight has
+# taken part in since its gradients were last produced, and a weight used more than once takes the immediate path.
 _pending_wgrad = []
+_conv_uses = {}                           # id(weight) -> [weakref, weight generation, forwards awaiting their backward, peak of that]
+
+
+def _note_conv_use(weight):
+    ent = _conv_uses.get(id(weight))
+    if ent is None or ent[0]() is not weight or ent[1] != _weight_generation[0]:
+        ent = _conv_uses[id(weight)] = [weakref.ref(weight), _weight_generation[0], 0, 0]
+        if len(_conv_uses) > 4096:                                    # drop entries of dead tensors
+            for k in [k for k, v in _conv_uses.items() if v[0]() is None]:
+                del _conv_uses[k]
+    ent[2] += 1
+    ent[3] = max(ent[3], ent[2])
+
+
+def _sole_conv_use(weight):
+    """True when `weight` fed exactly one conv forward that still awaits its backward (the one running now); consumes that use."""
+    ent = _conv_uses.get(id(weight))
+    if ent is None or ent[0]() is not weight:
+        return False
+    sole = ent[3] == 1
+    ent[2] -= 1
+    if ent[2] <= 0:
+        del _conv_uses[id(weight)]
+    return sole
 _wgrad_table = DeviceTable()
 _wgrad_table_partial = DeviceTable()      # mid-backward flushes (eager gradient exchange): never disturbs the bytes a captured graph re-uploads
 
@@ -220,24 +263,25 @@ def _flush_wgrads(ready_only=False):
         return
     todo, later = [], []
     for ent in _pending_wgrad:
-        weight = ent[1]
-        g = weight.grad
-        ok = g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == weight.shape
-        if ok:
+        weight, gref, gptr = ent[1], ent[9], ent[10]
+        # The gradient tensor returned from backward() was handed over to autograd with no reference kept here, so that it is
+        # adopted as weight.grad without a copy (backward()) or returned to the caller as is (torch.autograd.grad()).  It is still
+        # reachable either through the weak reference or as the storage weight.grad now shares.
+        g = gref()
+        if g is None and weight.grad is not None and weight.grad.data_ptr() == gptr:
+            g = weight.grad
+        if g is not None:
             todo.append(ent)
         elif ready_only:
             later.append(ent)
-        else:
-            raise RuntimeError("egm_unet_amd: deferred weight gradient lost its destination")
+        # else: nobody holds the gradient any more (it was discarded): nothing to finish
     _pending_wgrad[:] = later
     if not todo:
         return
     blob, chunks = bytearray(), 0
     per = lib().cdll.egm_wgrad_reduce_chunk()
-    for ws, weight, nslab, taps, CoutP, CinP, Cout, Cin, groups in todo:
-        # the gradient tensor returned from backward() was handed over to autograd (no reference kept here, so it is adopted
-        # as weight.grad without a copy); fill it now, in place
-        blob += struct.pack("<QQiiiiiiii", ws.data_ptr(), weight.grad.data_ptr(), nslab, taps, CoutP, CinP, Cout, Cin, groups, 0)
+    for ws, weight, nslab, taps, CoutP, CinP, Cout, Cin, groups, gref, gptr in todo:
+        blob += struct.pack("<QQiiiiiiii", ws.data_ptr(), gptr, nslab, taps, CoutP, CinP, Cout, Cin, groups, 0)
         chunks += (taps * CoutP * CinP + per - 1) // per
     dev = todo[0][1].device
     _wgrad_table.reserve(dev); _wgrad_table_partial.reserve(dev)      # both exist before any capture can need them
@@ -282,6 +326,8 @@ class _Conv2d(Function):
         b = bias.detach() if bias is not None else None
         lib().call("egm_conv_fwd", dtype_code(x.dtype), ptr(x), ldx, ptr(wf), ptr(b), Cout if b is not None else 0, ptr(y),
                    CoutP, ptr(stats), N, H, W, CinP, CoutP, KH, KW, dil, stream())
+        if ctx.needs_input_grad[1]:
+            _note_conv_use(weight)
         ctx.save_for_backward(x, weight, wd)
         ctx.meta = (dil, groups, bias is not None, Cin, Cout)
         ctx.bias_grad_zero = bias_grad_zero
@@ -311,15 +357,15 @@ class _Conv2d(Function):
             gw = torch.empty_like(weight)
             nbytes = L.query("egm_conv_wgrad_workspace", N, H, W, CinP, CoutP, KH, KW)
             ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=x.device)
-            # leaf parameter receiving its first gradient of this backward: defer the slab reduction to one multi-conv launch
-            defer = weight.is_leaf and weight.grad is None
+            # leaf parameter whose only gradient contribution this is: defer the slab reduction to one multi-conv launch
+            defer = _sole_conv_use(weight) and weight.is_leaf and weight.grad is None
             L.call("egm_conv_wgrad", dt, ptr(x), ldx, ptr(gy), ldg, None if defer else ptr(gw), ptr(ws), N, H, W, CinP, CoutP, Cin, Cout,
                    KH, KW, dil, groups, 0, st)
             if defer:
                 nslab = L.query("egm_conv_wgrad_slabs", dt, N, H, W, CinP, CoutP, KH, KW, dil)
                 if not _pending_wgrad:
                     Variable._execution_engine.queue_callback(_flush_wgrads)
-                _pending_wgrad.append((ws, weight, nslab, KH * KW, CoutP, CinP, Cout, Cin, groups))
+                _pending_wgrad.append((ws, weight, nslab, KH * KW, CoutP, CinP, Cout, Cin, groups, weakref.ref(gw), gw.data_ptr()))
         if has_bias and ctx.needs_input_grad[2]:
             gb = _f32(Cout, x.device, zero=True) if ctx.bias_grad_zero else _channel_sum(gy)[0, :Cout]
         return gx, gw, gb, None, None, None, None

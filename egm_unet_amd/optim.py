@@ -16,7 +16,7 @@ class SGD(torch.optim.Optimizer):
         self.grad_source = None        # optional {param: fp32 tensor view} overriding p.grad (DDP buckets)
         self.lr_dev = None             # optional device fp32 scalar read by the kernel instead of the by-value lr (a captured hipGraph
                                        # bakes by-value arguments in; a per-iteration LR schedule needs the value in memory)
-        self._tables = {}              # (group index, first) -> (key, pinned host table, device table)
+        self._tables = {}              # (namespace, group index, first) -> [key, pinned host table, device table, upload event]
 
     @staticmethod
     def _alloc_table(cap, dev):
@@ -32,13 +32,11 @@ class SGD(torch.optim.Optimizer):
             return hit[2]
         n = len(rows)
         if hit is None or hit[1].shape[0] < n:
-            pinned, device = self._alloc_table(max(n, 512), dev)
-        else:
-            pinned, device = hit[1], hit[2]
-        pinned[:n] = torch.tensor(rows, dtype=torch.int64)
-        device[:n].copy_(pinned[:n], non_blocking=True)
-        self._tables[slot] = (key, pinned, device)
-        return device
+            hit = self._tables[slot] = [None, *self._alloc_table(max(n, 512), dev), None]
+        # the rewrite of the pinned buffer waits for the previous upload from it (ops.upload_pinned)
+        ops.upload_pinned(hit, 1, 2, 3, torch.tensor(rows, dtype=torch.int64), n)
+        hit[0] = key
+        return hit[2]
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -47,7 +45,7 @@ class SGD(torch.optim.Optimizer):
             for first in (True, False):           # staging buffers exist before any hipGraph capture can need them
                 if (ops._table_tag[0], gi, first) not in self._tables and group["params"]:
                     cap = max(512, len(group["params"]))
-                    self._tables[(ops._table_tag[0], gi, first)] = (None,) + self._alloc_table(cap, group["params"][0].device)
+                    self._tables[(ops._table_tag[0], gi, first)] = [None, *self._alloc_table(cap, group["params"][0].device), None]
             rows = {True: [], False: []}          # first-step parameters take v = g (no stale buffer read)
             keep = []
             for p in group["params"]:

@@ -26,18 +26,29 @@ def _hip_gather(entries, device, stream_handle):
     """entries: [(dst_view, src_grad)] -> one multi-tensor copy on the given stream."""
     rows = tuple((d.data_ptr(), s.data_ptr(), s.numel()) for d, s in entries)
     hit = _gather_tables.get(rows[0][0])
-    if hit is None or hit[0] != rows:            # pointers changed: re-upload through a pinned staging buffer (async)
+    if hit is None or hit[0] != rows:
+        # pointers changed: a FRESH pinned staging buffer and device table per distinct pointer set (an upload still in flight from
+        # the previous buffer is never overwritten; the old pair stays alive in the caller's keep-list until finish())
         pinned = torch.tensor(rows, dtype=torch.int64).pin_memory()
         table = torch.empty(pinned.shape, dtype=torch.int64, device=device)
         table.copy_(pinned, non_blocking=True)
         _gather_tables[rows[0][0]] = hit = (rows, pinned, table)
     lib().call("egm_copy_multi", ptr(hit[2]), len(rows), stream_handle)
-    return hit[2]
+    return hit
 
 
 class GradAllReducer:
-    def __init__(self, model, world_size=None, gather_fn=None, use_side_stream=None):
+    def __init__(self, model, world_size=None, gather_fn=None, use_side_stream=None, broadcast=True):
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        if broadcast and dist.is_initialized() and dist.get_world_size() > 1:
+            # every rank starts from rank 0's parameters and buffers (what DistributedDataParallel does at construction): ranks
+            # that initialised differently would otherwise average gradients of different models and drift apart silently
+            with torch.no_grad():
+                for t in list(model.parameters()) + list(model.buffers()):
+                    dist.broadcast(t, src=0)
+            if next(model.parameters()).is_cuda:
+                from . import ops
+                ops.bump_weight_generation()
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         self.buckets = [[], []]
         for n, p in named:
