@@ -3,24 +3,11 @@
 // All of these are HBM-bound streaming kernels: 16-byte (bf16) / 32-byte (fp32) vectors of 8 channels per lane,
 // channel-contiguous so a wave reads whole pixels; reductions are two-stage with plain stores (deterministic).
 #include "common.h"
+#include "prologue.h"
 
 namespace {
 
 constexpr int kMaxPartialBlocks = 1024;
-
-__device__ __forceinline__ float act_fwd(float v, int act) {
-    if (act == EGM_ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == EGM_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
-    if (act == EGM_ACT_SILU) return v / (1.f + expf(-v));
-    return v;
-}
-// derivative of act at pre-activation v
-__device__ __forceinline__ float act_grad(float v, int act) {
-    if (act == EGM_ACT_RELU) return v > 0.f ? 1.f : 0.f;
-    if (act == EGM_ACT_SIGMOID) { const float z = 1.f / (1.f + expf(-v)); return z * (1.f - z); }
-    if (act == EGM_ACT_SILU) { const float z = 1.f / (1.f + expf(-v)); return z * (1.f + v * (1.f - z)); }
-    return 1.f;
-}
 
 // block = 256 threads = (256 / ncv) pixel rows x ncv channel-vectors; out[blk][2][C]
 // MODE 0: (x, x^2).  MODE 1 (BN backward): (dzp, dzp*xhat) with dzp = dz*act'(y*scale+shift), xhat = (y-mean)*rstd.
@@ -56,7 +43,7 @@ __global__ __launch_bounds__(256) void channel_partials_kernel(const T* __restri
                 load8(y + p * ldy + cv * 8, yv);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float g = v[j] * act_grad(yv[j] * sc[j] + sh[j], act);
+                    const float g = v[j] * act_grad(fmaf(yv[j], sc[j], sh[j]), act);
                     s[j] += g; q[j] += g * (yv[j] - mu[j]) * rs[j];
                 }
             }
@@ -134,6 +121,31 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     }
 }
 
+// BatchNorm backward, second stage: partial tiles [ntiles][2][C] of (sum dzp, sum dzp*xhat) -> sums [2][C] (= dbeta | dgamma) and the
+// coefficient rows cf [4][C] = scale | shift | cb | cc of EGM_PRE_BN_BWD (prologue.h), so that neither a reduce_tiles launch nor a
+// stand-alone apply pass is needed: the data-gradient and weight-gradient kernels of the conv in front compute dy while staging.
+__global__ __launch_bounds__(1024) void bn_bwd_coefs_kernel(const float* __restrict__ st, int ntiles, float inv_count,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd, int train,
+                                                            float* __restrict__ sums, float* __restrict__ cf, int C) {
+    __shared__ double red[2048];
+    double s, q;
+    tiles_reduce(st, ntiles, C, blockIdx.x * 8, s, q, red);
+    const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+    if (threadIdx.x < 8 && c < C) {
+        const float s0 = (float)s, s1 = (float)q;
+        sums[c] = s0; sums[C + c] = s1;
+        const float scv = scale[c];
+        float cbv = 0.f, ccv = 0.f;
+        if (train) {
+            const float m0 = s0 * inv_count, m1 = s1 * inv_count;
+            ccv = -scv * rstd[c] * m1;
+            cbv = -scv * m0 - ccv * mean[c];
+        }
+        cf[c] = scv; cf[C + c] = shift[c]; cf[2 * C + c] = cbv; cf[3 * C + c] = ccv;
+    }
+}
+
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                       float* scale, float* shift, float* save_mean, float* save_rstd, int C, int Creal) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
             load8(y + p * ldy + cv * 8, v);
             load8(y + (p + stride) * ldy + cv * 8, u);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v[j] = act_fwd(v[j] * sc[j] + sh[j], act); u[j] = act_fwd(u[j] * sc[j] + sh[j], act); }
+            for (int j = 0; j < 8; ++j) { v[j] = bn_fwd_elem(v[j], sc[j], sh[j], act); u[j] = bn_fwd_elem(u[j], sc[j], sh[j], act); }
             store8(z + p * ldz + cv * 8, v);
             store8(z + (p + stride) * ldz + cv * 8, u);
         }
@@ -178,7 +190,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
             float v[8];
             load8(y + p * ldy + cv * 8, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j] * sc[j] + sh[j], act);
+            for (int j = 0; j < 8; ++j) v[j] = bn_fwd_elem(v[j], sc[j], sh[j], act);
             store8(z + p * ldz + cv * 8, v);
         }
         return;
@@ -189,7 +201,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
         float v[8];
         load8(y + p * ldy + cv * 8, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j] * scale[cv * 8 + j] + shift[cv * 8 + j], act);
+        for (int j = 0; j < 8; ++j) v[j] = bn_fwd_elem(v[j], scale[cv * 8 + j], shift[cv * 8 + j], act);
         store8(z + p * ldz + cv * 8, v);
     }
 }
@@ -233,8 +245,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
             load8(y + (p + stride) * ldy + cv * 8, y2);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                g[j] = sc[j] * g[j] * act_grad(yv[j] * sc[j] + sh[j], act) + cb[j] + cc[j] * yv[j];
-                g2[j] = sc[j] * g2[j] * act_grad(y2[j] * sc[j] + sh[j], act) + cb[j] + cc[j] * y2[j];
+                g[j] = bn_bwd_elem(g[j], yv[j], sc[j], sh[j], cb[j], cc[j], act);
+                g2[j] = bn_bwd_elem(g2[j], y2[j], sc[j], sh[j], cb[j], cc[j], act);
             }
             store8(dy + p * lddy + cv * 8, g);
             store8(dy + (p + stride) * lddy + cv * 8, g2);
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
             load8(dz + p * lddz + cv * 8, g);
             load8(y + p * ldy + cv * 8, yv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] = sc[j] * g[j] * act_grad(yv[j] * sc[j] + sh[j], act) + cb[j] + cc[j] * yv[j];
+            for (int j = 0; j < 8; ++j) g[j] = bn_bwd_elem(g[j], yv[j], sc[j], sh[j], cb[j], cc[j], act);
             store8(dy + p * lddy + cv * 8, g);
         }
         return;
@@ -258,13 +270,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = cv * 8 + j;
-            const float gp = g[j] * act_grad(yv[j] * scale[c] + shift[c], act);
+            float cbv = 0.f, ccv = 0.f;
             if (train) {
-                const float xh = (yv[j] - mean[c]) * rstd[c];
-                o[j] = scale[c] * (gp - sums[c] * inv_count - xh * sums[C + c] * inv_count);
-            } else {
-                o[j] = scale[c] * gp;
+                const float m0 = sums[c] * inv_count, m1 = sums[C + c] * inv_count;
+                ccv = -scale[c] * rstd[c] * m1;
+                cbv = -scale[c] * m0 - ccv * mean[c];
             }
+            o[j] = bn_bwd_elem(g[j], yv[j], scale[c], shift[c], cbv, ccv, act);
         }
         store8(dy + p * lddy + cv * 8, o);
     }
@@ -363,6 +375,17 @@ extern "C" int egm_bn_act_bwd_reduce(int dtype, const void* dz, int lddz, const 
     EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_partials_kernel<T, 1>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const T*)dz,
                                                  lddz, (const T*)y, ldy, scale, shift, save_mean, save_rstd, act, npix, C, partials));
     EGM_CHECK_LAUNCH("bn_act_bwd_reduce");
+    return EGM_OK;
+}
+
+extern "C" int egm_bn_bwd_coefs(const float* partials, int ntiles, long long count, const float* scale, const float* shift,
+                                const float* save_mean, const float* save_rstd, int train, float* sums, float* cf, int C,
+                                egm_stream_t s) {
+    EGM_REQUIRE(partials && scale && shift && save_mean && save_rstd && sums && cf && ntiles > 0 && count > 0 && C > 0 && C % 8 == 0,
+                "bn_bwd_coefs: bad args");
+    hipLaunchKernelGGL(bn_bwd_coefs_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)s, partials, ntiles, 1.f / (float)count,
+                       scale, shift, save_mean, save_rstd, train, sums, cf, C);
+    EGM_CHECK_LAUNCH("bn_bwd_coefs");
     return EGM_OK;
 }
 

@@ -12,6 +12,7 @@
 //
 // HBM-bound for the narrow layers (C <= 64), MFMA-bound for 256 -> 256; algorithmic work as for conv_igemm.hip.
 #include "common.h"
+#include "prologue.h"
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -23,11 +24,15 @@ struct DirectParams {
     const void* x; const void* w; const float* bias; void* y; float* stats;
     int ldx, ldy, N, H, W, Cin, Cout, KH, KW, dil, bias_n;
     int nblk, nct, G, wrow;      // 32-pixel blocks, cout tiles, pixel groups (workgroups per cout tile), LDS weight row bytes
+    PreArgs pre;                 // operand prologue (prologue.h)
 };
 
 __device__ __forceinline__ bf16x8_t as_frag(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
 
-template <int NT>
+// PRE (EGM_PRE_NONE / EGM_PRE_BN_ACT, prologue.h): the loaded channel vectors are transformed in registers on their way into the
+// MFMA operand (BatchNorm apply + activation of the producing layer); the coefficient rows sit in LDS behind the out tiles; taps
+// that fall outside the image stay exactly zero.
+template <int NT, int PRE>
 __global__ __launch_bounds__(256) void conv_direct_kernel(DirectParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int OROW = NT * 64 + 16, NV = NT * 4;
@@ -43,6 +48,15 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(DirectParams p) {
     const int ntaps = p.KH * p.KW, nks = (p.Cin + 15) >> 4, cvecs = p.Cin >> 3;
     unsigned char* wts = smem;                                               // [ntaps][NT*32][wrow]
     unsigned char* ot = smem + (size_t)ntaps * NT * 32 * p.wrow + wv * 32 * OROW;   // wave-private out tile
+    static_assert(PRE == EGM_PRE_NONE || PRE == EGM_PRE_BN_ACT, "direct conv: prologue must be NONE or BN_ACT");
+    float* cfl = reinterpret_cast<float*>(smem + (size_t)ntaps * NT * 32 * p.wrow + 4 * 32 * OROW);   // [2][nks*16] coefficient rows
+    const int cs = nks * 16;
+    if (PRE != EGM_PRE_NONE) {
+        for (int i = tid; i < 2 * cs; i += 256) {
+            const int r = i / cs, c = i - r * cs;
+            cfl[i] = c < p.Cin ? p.pre.cf[r * p.pre.C + c] : 0.f;
+        }
+    }
 
     // ---- weights of this cout tile: staged once, zero rows past Cout, zero tail past Cin (the k-loop runs in steps of 16)
     {
@@ -107,6 +121,18 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(DirectParams p) {
                 for (int k = 0; k < 8; ++k) {
                     fb[k] = make_uint4(0, 0, 0, 0);
                     if (ok && k0 + k < nks && (k0 + k) * 16 + h * 8 < p.Cin) fb[k] = *reinterpret_cast<const uint4*>(src + (k0 + k) * 16);
+                }
+                if (PRE != EGM_PRE_NONE) {
+                    EGM_ACT_SWITCH(p.pre.act,
+                        _Pragma("unroll")
+                        for (int k = 0; k < 8; ++k) {
+                            if (k0 + k < nks) {
+                                PreCoef8 kf;
+                                pre_load_coef8<PRE>(kf, cfl + (k0 + k) * 16 + h * 8, cs);
+                                const uint4 v = pre_apply8<PRE, ACT>(fb[k], fb[k], kf, p.pre.act);
+                                fb[k] = ok ? v : make_uint4(0, 0, 0, 0);
+                            }
+                        });
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -174,19 +200,27 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(DirectParams p) {
     }
 }
 
-template <int NT>
-int launch_direct(const DirectParams& p, size_t smem, hipStream_t st) {
+template <int NT, int PRE>
+int launch_direct_pre(const DirectParams& p, size_t smem, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct_kernel<NT, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024);
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_direct: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
+    if (PRE != EGM_PRE_NONE) smem += (size_t)2 * ((p.Cin + 15) / 16 * 16) * sizeof(float);
+    EGM_REQUIRE(smem <= 160 * 1024, "conv_direct: LDS budget exceeded (%zu)", smem);
     const int grid = ((p.G + 7) / 8) * 8 * p.nct;
-    hipLaunchKernelGGL((conv_direct_kernel<NT>), dim3(grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((conv_direct_kernel<NT, PRE>), dim3(grid), dim3(256), smem, st, p);
     EGM_CHECK_LAUNCH("conv_direct");
     return EGM_OK;
+}
+template <int NT>
+int launch_direct(const DirectParams& p, size_t smem, hipStream_t st) {
+    if (p.pre.mode == EGM_PRE_BN_ACT) return launch_direct_pre<NT, EGM_PRE_BN_ACT>(p, smem, st);
+    if (p.pre.mode != EGM_PRE_NONE) EGM_FAIL(EGM_ERR_UNSUPPORTED, "conv_direct: prologue mode %d not built", p.pre.mode);
+    return launch_direct_pre<NT, EGM_PRE_NONE>(p, smem, st);
 }
 
 }  // namespace
@@ -221,9 +255,11 @@ int egm_conv_direct_plan(int dtype, int N, int H, int W, int Cin, int Cout, int 
     return 1;
 }
 
-int egm_conv_direct_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, float* stats, int N, int H,
-                           int W, int Cin, int Cout, int KH, int KW, int dil, int NT, int nct, int G, size_t smem, egm_stream_t s) {
+int egm_conv_direct_launch(const void* x, int ldx, const PreArgs& pre, const void* wf, const float* bias, int bias_n, void* y, int ldy,
+                           float* stats, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int NT, int nct, int G, size_t smem,
+                           egm_stream_t s) {
     DirectParams p;
+    p.pre = pre;
     p.x = x; p.w = wf; p.bias = bias; p.y = y; p.stats = stats;
     p.ldx = ldx; p.ldy = ldy; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.dil = (KH == 1) ? 1 : dil;
     p.bias_n = bias ? bias_n : 0;

@@ -21,6 +21,7 @@
 //   * the C waves sharing a dW block are summed through LDS; partial blocks go to a slab [split][tap][CoutP][CinP] with plain stores; a second kernel sums the slabs in
 //     fixed order (bitwise reproducible) and scatters into the fp32 OIHW gradient.
 #include "common.h"
+#include "prologue.h"
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -72,6 +73,10 @@ struct WgradParams {
     int nci_tiles;               // ceil(Cin / (32*B))
     int ngroups;                 // tap groups
     int dma;                     // bf16: stage through LDS-DMA into two LDS images (no VGPR staging, one barrier per tile)
+    PreArgs prex, predy;         // operand prologues (prologue.h): x = act(bn(y_prev)) and dy = bn_backward(dz, y) computed while staging
+    int cf_off;                  // LDS byte offset of the prologue coefficient rows
+    void* dy_out; int ld_dy_out; // by-product: the logical dy, written once per element for the data-gradient kernel (may be null)
+    int out_grp;                 // the tap group whose workgroups write it (one that visits every pixel tile)
 };
 
 template <int NTAPS> struct Window;   // staged window of a tap group
@@ -81,8 +86,14 @@ template <> struct Window<5> { static constexpr int WH = 1, WW = 5; };
 template <> struct Window<3> { static constexpr int WH = 1, WW = 3; };   // one kernel row of a DILATED 3x3: taps p.dil apart
 template <> struct Window<1> { static constexpr int WH = 1, WW = 1; };
 
-template <typename T, int NTAPS>
-__global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2) ? 2 : 1) void conv_wgrad_kernel(WgradParams p) {
+// PRE: the kernel is built with operand prologues (prologue.h).  Both operands may then be LOGICAL tensors: x = act(scale*y_prev +
+// shift) of the BatchNorm in front of this conv, dy = the BatchNorm backward of the one behind it, computed from (dz, y) between the
+// global load and the LDS write of the staging pipeline.  The applied activation is never written to memory; dy is written ONCE, as
+// a by-product (dy_out: by the workgroups of input-channel block 0 and of the centre tap group, which between them stage every dy
+// element exactly once), for the data-gradient kernel that runs next -- the stand-alone BatchNorm-backward apply pass
+// (bn_act_bwd_apply_kernel: read dz, read y, write dy) and one of the two reads of dy disappear.
+template <typename T, int NTAPS, bool PRE>
+__global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2 && !PRE) ? 2 : 1) void conv_wgrad_kernel(WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using M = WMma<T>;
     constexpr int WH = Window<NTAPS>::WH, WW = Window<NTAPS>::WW;
@@ -132,7 +143,23 @@ __global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2) ? 2 : 1) void c
     constexpr int XVEC = ((DROW ? 1 : 2) * PH * PWC * VPR + 255) / 256;   // sized for B = 2 (dilated-row variant: B = 1 only)
     constexpr bool PIPE = (sizeof(T) == 2);                           // bf16: register prefetch (issue early / write late)
     uint4 pre_dy[PIPE ? DYVEC : 1], pre_x[PIPE ? XVEC : 1];
+    uint4 pre_dya[(PIPE && PRE) ? DYVEC : 1];                         // BatchNorm input y next to dz (EGM_PRE_BN_BWD)
     const int ndy = p.A * TH * TW * VPR, nx = p.B * PH * PW * VPR;
+    // ---- prologue coefficient rows of this workgroup's channel blocks: dy rows [4][32 A], x rows [2][32 B] (zero past the tensor)
+    float* cf_dy = reinterpret_cast<float*>(smem + p.cf_off);
+    float* cf_x = cf_dy + 4 * 32 * p.A;
+    const int cs_dy = 32 * p.A, cs_x = 32 * p.B;
+    if (PRE) {
+        for (int i = tid; i < 4 * cs_dy; i += 256) {
+            const int r = i / cs_dy, c = co_base + (i - r * cs_dy);
+            cf_dy[i] = (p.predy.mode != EGM_PRE_NONE && c < p.Cout && (r < 2 || p.predy.mode == EGM_PRE_BN_BWD)) ? p.predy.cf[r * p.predy.C + c] : 0.f;
+        }
+        for (int i = tid; i < 2 * cs_x; i += 256) {
+            const int r = i / cs_x, c = ci_base + (i - r * cs_x);
+            cf_x[i] = (p.prex.mode != EGM_PRE_NONE && c < p.Cin) ? p.prex.cf[r * p.prex.C + c] : 0.f;
+        }
+        __syncthreads();
+    }
 
     auto tile_ok = [&](int pt, int& n, int& oy0, int& ox0) {
         n = pt / tpi; const int trem = pt - n * tpi;
@@ -140,21 +167,59 @@ __global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2) ? 2 : 1) void c
         // dilated taps: shifted tile wholly outside the image contributes zero (block-uniform)
         return !(p.dil > 1 && (oy0 + offy >= p.H || oy0 + offy + TH <= 0 || ox0 + offx >= p.W || ox0 + offx + (DROW ? PW : TW) <= 0));
     };
-    auto load_dy = [&](int i, int n, int oy0, int ox0) {
+    auto dy_slot = [&](int i, int n, int oy0, int ox0, long long& pixoff, int& c, int& cl) __attribute__((always_inline)) {     // -> slot inside the tensor
         const int v = i % VPR, pix = (i / VPR) % (TH * TW), blk = i / (VPR * TH * TW);
-        const int oy = oy0 + pix / TW, ox = ox0 + pix % TW, c = co_base + blk * 32 + v * VEC;
+        const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
+        cl = blk * 32 + v * VEC; c = co_base + cl;
+        pixoff = (long long)(n * p.H + oy) * p.W + ox;
+        return i < ndy && oy < p.H && ox < p.W && c < p.Cout;
+    };
+    auto x_slot = [&](int i, int n, int oy0, int ox0, long long& pixoff, int& c, int& cl) __attribute__((always_inline)) {
+        const int v = i % VPR, pix = (i / VPR) % (PH * PW), blk = i / (VPR * PH * PW);
+        const int iy = oy0 + offy + pix / PW, ix = ox0 + offx + pix % PW;
+        cl = blk * 32 + v * VEC; c = ci_base + cl;
+        pixoff = (long long)(n * p.H + iy) * p.W + ix;
+        return i < nx && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.Cin;
+    };
+    auto load_dy = [&](int i, int n, int oy0, int ox0) __attribute__((always_inline)) {
+        long long po; int c, cl;
         uint4 val = make_uint4(0, 0, 0, 0);
-        if (i < ndy && oy < p.H && ox < p.W && c < p.Cout)
-            val = *reinterpret_cast<const uint4*>(dyg + ((long long)(n * p.H + oy) * p.W + ox) * p.lddy + c);
+        if (dy_slot(i, n, oy0, ox0, po, c, cl)) val = *reinterpret_cast<const uint4*>(dyg + po * p.lddy + c);
         return val;
     };
-    auto load_x = [&](int i, int n, int oy0, int ox0) {
-        const int v = i % VPR, pix = (i / VPR) % (PH * PW), blk = i / (VPR * PH * PW);
-        const int iy = oy0 + offy + pix / PW, ix = ox0 + offx + pix % PW, c = ci_base + blk * 32 + v * VEC;
+    auto load_dya = [&](int i, int n, int oy0, int ox0) __attribute__((always_inline)) {                  // the BatchNorm input y at dz's position
+        long long po; int c, cl;
         uint4 val = make_uint4(0, 0, 0, 0);
-        if (i < nx && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && c < p.Cin)
-            val = *reinterpret_cast<const uint4*>(xg + ((long long)(n * p.H + iy) * p.W + ix) * p.ldx + c);
+        if (p.predy.mode == EGM_PRE_BN_BWD && dy_slot(i, n, oy0, ox0, po, c, cl))
+            val = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.predy.aux) + po * p.predy.ld_aux + c);
         return val;
+    };
+    auto load_x = [&](int i, int n, int oy0, int ox0) __attribute__((always_inline)) {
+        long long po; int c, cl;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (x_slot(i, n, oy0, ox0, po, c, cl)) val = *reinterpret_cast<const uint4*>(xg + po * p.ldx + c);
+        return val;
+    };
+    // logical operands from the loaded vectors; slots outside the tensor (zero padding, ragged tiles) stay exactly zero
+    const bool dy_writer = PRE && p.dy_out != nullptr && cit == 0 && grp == p.out_grp;
+    auto xform_dy = [&](uint4 raw, uint4 aux, int i, int n, int oy0, int ox0) __attribute__((always_inline)) {
+        if (!PRE || p.predy.mode == EGM_PRE_NONE) return raw;
+        long long po; int c, cl;
+        if (!dy_slot(i, n, oy0, ox0, po, c, cl)) return make_uint4(0, 0, 0, 0);
+        uint4 v;
+        if (p.predy.act == EGM_ACT_RELU) v = pre_apply_rt<EGM_ACT_RELU>(T(), raw, aux, cf_dy + cl, cs_dy, p.predy.mode, 0);
+        else if (p.predy.act == EGM_ACT_NONE) v = pre_apply_rt<EGM_ACT_NONE>(T(), raw, aux, cf_dy + cl, cs_dy, p.predy.mode, 0);
+        else v = pre_apply_rt<kActRuntime>(T(), raw, aux, cf_dy + cl, cs_dy, p.predy.mode, p.predy.act);
+        if (dy_writer) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.dy_out) + po * p.ld_dy_out + c) = v;
+        return v;
+    };
+    auto xform_x = [&](uint4 raw, int i, int n, int oy0, int ox0) __attribute__((always_inline)) {
+        if (!PRE || p.prex.mode == EGM_PRE_NONE) return raw;
+        long long po; int c, cl;
+        if (!x_slot(i, n, oy0, ox0, po, c, cl)) return make_uint4(0, 0, 0, 0);
+        if (p.prex.act == EGM_ACT_RELU) return pre_apply_rt<EGM_ACT_RELU>(T(), raw, raw, cf_x + cl, cs_x, EGM_PRE_BN_ACT, 0);
+        if (p.prex.act == EGM_ACT_NONE) return pre_apply_rt<EGM_ACT_NONE>(T(), raw, raw, cf_x + cl, cs_x, EGM_PRE_BN_ACT, 0);
+        return pre_apply_rt<kActRuntime>(T(), raw, raw, cf_x + cl, cs_x, EGM_PRE_BN_ACT, p.prex.act);
     };
     // vector i sits at block-major [32-ch block][pixel][v]: (i / VPR) * RB + (i % VPR) * 16 == 16 i
     auto dy_lds = [&](int i) { return dyl + i * 16; };
@@ -279,6 +344,10 @@ __global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2) ? 2 : 1) void c
     if (PIPE && pt < p.npt) {
 #pragma unroll
         for (int k = 0; k < DYVEC; ++k) pre_dy[k] = load_dy(tid + k * 256, n, oy0, ox0);
+        if (PRE) {
+#pragma unroll
+            for (int k = 0; k < DYVEC; ++k) pre_dya[k] = load_dya(tid + k * 256, n, oy0, ox0);
+        }
 #pragma unroll
         for (int k = 0; k < XVEC; ++k) pre_x[k] = load_x(tid + k * 256, n, oy0, ox0);
     }
@@ -287,12 +356,16 @@ __global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2) ? 2 : 1) void c
         EGM_WTICK(0);
         if (PIPE) {
 #pragma unroll
-            for (int k = 0; k < DYVEC; ++k) if (tid + k * 256 < ndy) *reinterpret_cast<uint4*>(dy_lds(tid + k * 256)) = pre_dy[k];
+            for (int k = 0; k < DYVEC; ++k)
+                if (tid + k * 256 < ndy)
+                    *reinterpret_cast<uint4*>(dy_lds(tid + k * 256)) = xform_dy(pre_dy[k], pre_dya[PRE ? k : 0], tid + k * 256, n, oy0, ox0);
 #pragma unroll
-            for (int k = 0; k < XVEC; ++k) if (tid + k * 256 < nx) *reinterpret_cast<uint4*>(x_lds(tid + k * 256)) = pre_x[k];
+            for (int k = 0; k < XVEC; ++k)
+                if (tid + k * 256 < nx) *reinterpret_cast<uint4*>(x_lds(tid + k * 256)) = xform_x(pre_x[k], tid + k * 256, n, oy0, ox0);
         } else {
-            for (int i = tid; i < ndy; i += 256) *reinterpret_cast<uint4*>(dy_lds(i)) = load_dy(i, n, oy0, ox0);
-            for (int i = tid; i < nx; i += 256) *reinterpret_cast<uint4*>(x_lds(i)) = load_x(i, n, oy0, ox0);
+            for (int i = tid; i < ndy; i += 256)
+                *reinterpret_cast<uint4*>(dy_lds(i)) = xform_dy(load_dy(i, n, oy0, ox0), PRE ? load_dya(i, n, oy0, ox0) : make_uint4(0, 0, 0, 0), i, n, oy0, ox0);
+            for (int i = tid; i < nx; i += 256) *reinterpret_cast<uint4*>(x_lds(i)) = xform_x(load_x(i, n, oy0, ox0), i, n, oy0, ox0);
         }
         EGM_WTICK(1);
         __syncthreads();
@@ -302,6 +375,10 @@ __global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2) ? 2 : 1) void c
         if (PIPE && pt2 < p.npt) {                                    // in flight during the MFMAs below
 #pragma unroll
             for (int k = 0; k < DYVEC; ++k) pre_dy[k] = load_dy(tid + k * 256, n2, oy2, ox2);
+            if (PRE) {
+#pragma unroll
+                for (int k = 0; k < DYVEC; ++k) pre_dya[k] = load_dya(tid + k * 256, n2, oy2, ox2);
+            }
 #pragma unroll
             for (int k = 0; k < XVEC; ++k) pre_x[k] = load_x(tid + k * 256, n2, oy2, ox2);
         }
@@ -439,9 +516,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WredEntry
     }
 }
 
-struct WgradPlan { int A, B, C, ntaps, ngroups, nsplit, nco_tiles, nci_tiles, npt, tiles_y, tiles_x, dma; size_t smem; long long slab_bytes; };
+struct WgradPlan { int A, B, C, ntaps, ngroups, nsplit, nco_tiles, nci_tiles, npt, tiles_y, tiles_x, dma, cf_off; size_t smem; long long slab_bytes; };
 
-int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, WgradPlan* pl) {
+int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, WgradPlan* pl, bool pre = false) {
     if (KH == 1 && KW == 1) dil = 1;
     if (dil == 1) {
         if (KH == 3 && KW == 3) { pl->ntaps = 9; pl->ngroups = 1; }
@@ -480,27 +557,34 @@ int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW
     static const int dma_off = getenv("EGM_WGRAD_NO_DMA") != nullptr;
     // (measured: 9 % faster on the 2 x 2-block layers, i.e. Cin, Cout > 32; slower on the narrow and the dilated ones, which keep
     //  the register-staged pipeline)
-    pl->dma = (dtype == EGM_BF16 && !dma_off && A * B == 4 && pl->ntaps == 9 && 2 * pl->smem <= 156 * 1024) ? 1 : 0;
+    pl->dma = (dtype == EGM_BF16 && !dma_off && !pre && A * B == 4 && pl->ntaps == 9 && 2 * pl->smem <= 156 * 1024) ? 1 : 0;
     if (pl->dma) pl->smem *= 2;
+    pl->cf_off = (int)pl->smem;
+    if (pre) pl->smem += (size_t)(4 * 32 * A + 2 * 32 * B) * sizeof(float);     // prologue coefficient rows behind the images
     const size_t red_bytes = pl->C > 1 ? (size_t)A * B * pl->ntaps * 16 * 64 * sizeof(float) : 0;   // cross-wave reduction buffer
     if (pl->smem < red_bytes) pl->smem = red_bytes;
     pl->slab_bytes = (long long)nsplit * KH * KW * Cout * Cin * (long long)sizeof(float);
     return EGM_OK;
 }
 
-template <typename T, int NTAPS>
-int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
+template <typename T, int NTAPS, bool PRE>
+int launch_wgrad_pre(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<T, NTAPS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<T, NTAPS, PRE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     dim3 grid(pl.nsplit, pl.nco_tiles * pl.nci_tiles, pl.ngroups);
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, NTAPS>), grid, dim3(256), pl.smem, st, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, NTAPS, PRE>), grid, dim3(256), pl.smem, st, p);
     EGM_CHECK_LAUNCH("conv_wgrad");
     return EGM_OK;
+}
+template <typename T, int NTAPS>
+int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
+    if (p.prex.mode != EGM_PRE_NONE || p.predy.mode != EGM_PRE_NONE) return launch_wgrad_pre<T, NTAPS, true>(p, pl, st);
+    return launch_wgrad_pre<T, NTAPS, false>(p, pl, st);
 }
 
 template <typename T>
@@ -549,7 +633,22 @@ extern "C" int egm_wgrad_reduce_multi(const void* table_dev, int n, long long to
 extern "C" int egm_conv_wgrad(int dtype, const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace, int N,
                               int H, int W, int Cin, int Cout, int CinR, int CoutR, int KH, int KW, int dil, int groups,
                               int accumulate, egm_stream_t s) {
+    return egm_conv_wgrad_pre(dtype, x, ldx, EGM_PRE_NONE, 0, nullptr, dy, lddy, EGM_PRE_NONE, 0, nullptr, nullptr, 0, nullptr, 0, dw, workspace,
+                              N, H, W, Cin, Cout, CinR, CoutR, KH, KW, dil, groups, accumulate, s);
+}
+
+extern "C" int egm_conv_wgrad_pre(int dtype, const void* x, int ldx, int xpre_mode, int xpre_act, const float* xpre_cf, const void* dy,
+                                  int lddy, int dypre_mode, int dypre_act, const float* dypre_cf, const void* dypre_aux, int dypre_ld_aux,
+                                  void* dy_out, int ld_dy_out, float* dw, void* workspace, int N, int H, int W, int Cin, int Cout,
+                                  int CinR, int CoutR, int KH, int KW, int dil, int groups, int accumulate, egm_stream_t s) {
     EGM_REQUIRE(x && dy && workspace, "conv_wgrad: null pointer");
+    EGM_REQUIRE(xpre_mode == EGM_PRE_NONE || (xpre_mode == EGM_PRE_BN_ACT && xpre_cf), "conv_wgrad: x prologue must be NONE or BN_ACT with coefficients");
+    EGM_REQUIRE(dypre_mode == EGM_PRE_NONE || ((dypre_mode == EGM_PRE_BN_BWD || dypre_mode == EGM_PRE_BN_ACT) && dypre_cf),
+                "conv_wgrad: bad dy prologue");
+    EGM_REQUIRE(dypre_mode != EGM_PRE_BN_BWD || (dypre_aux && egm_aligned16(dypre_aux) && dypre_ld_aux >= Cout && dypre_ld_aux % 8 == 0),
+                "conv_wgrad: BN-backward prologue needs the BatchNorm input (aux) with ld >= Cout, multiple of 8");
+    EGM_REQUIRE(dy_out == nullptr || (dypre_mode != EGM_PRE_NONE && egm_aligned16(dy_out) && ld_dy_out >= Cout && ld_dy_out % 8 == 0),
+                "conv_wgrad: dy_out needs a dy prologue, 16-byte alignment and ld >= Cout, multiple of 8");
     EGM_REQUIRE(N > 0 && H > 0 && W > 0, "conv_wgrad: bad shape");
     EGM_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && Cin > 0 && Cout > 0, "conv_wgrad: padded channels must be multiples of 8");
     EGM_REQUIRE(CinR <= Cin && CoutR <= Cout && CinR > 0 && CoutR > 0 && groups > 0 && CinR % groups == 0 && CoutR % groups == 0,
@@ -559,10 +658,16 @@ extern "C" int egm_conv_wgrad(int dtype, const void* x, int ldx, const void* dy,
     EGM_REQUIRE(dil >= 1 && (KH & 1) && (KW & 1), "conv_wgrad: bad kernel");
     if (KH == 1 && KW == 1) dil = 1;
     WgradPlan pl;
-    if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl) != EGM_OK)
+    const bool pre = xpre_mode != EGM_PRE_NONE || dypre_mode != EGM_PRE_NONE;
+    if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl, pre) != EGM_OK)
         EGM_FAIL(EGM_ERR_UNSUPPORTED, "conv_wgrad: unsupported kernel %dx%d dil %d", KH, KW, dil);
     EGM_REQUIRE(pl.smem <= 160 * 1024, "conv_wgrad: LDS budget exceeded");
     WgradParams p;
+    p.prex.mode = xpre_mode; p.prex.act = xpre_act; p.prex.cf = xpre_cf; p.prex.aux = nullptr; p.prex.ld_aux = 0; p.prex.C = Cin;
+    p.predy.mode = dypre_mode; p.predy.act = dypre_act; p.predy.cf = dypre_cf; p.predy.aux = dypre_aux; p.predy.ld_aux = dypre_ld_aux;
+    p.predy.C = Cout; p.cf_off = pl.cf_off;
+    p.dy_out = dy_out; p.ld_dy_out = ld_dy_out;
+    p.out_grp = (pl.ntaps == 3 && dil > 1) ? 1 : (pl.ngroups == 9 ? 4 : 0);       // a tap group with zero row/column offset: it skips no tile
     p.x = x; p.dy = dy; p.slab = (float*)workspace; p.ldx = ldx; p.lddy = lddy; p.N = N; p.H = H; p.W = W;
     p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.dil = dil; p.tiles_y = pl.tiles_y; p.tiles_x = pl.tiles_x;
     p.npt = pl.npt; p.nsplit = pl.nsplit; p.A = pl.A; p.B = pl.B; p.C = pl.C; p.nci_tiles = pl.nci_tiles; p.ngroups = pl.ngroups;

@@ -84,9 +84,10 @@ class BasicConv(nn.Module):
         self.relu = nn.ReLU(inplace=True) if relu else None
         self._dil, self._groups = dilation, groups
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, lazy=False):
+        """x: NHWC tensor or ops.Lazy; lazy=True returns an ops.Lazy for a consuming convolution (no BatchNorm apply pass)."""
         return ops.conv_bn_act(x, self.conv, self.bn, ACT_RELU if self.relu is not None else ACT_NONE, dil=self._dil,
-                               groups=self._groups, out=out)
+                               groups=self._groups, out=out, lazy=lazy)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -190,10 +191,15 @@ class EdgeEnhancedGRFB(nn.Module):
 
     @staticmethod
     def _seq(seq, x, out):
-        """nn.Sequential of blocks whose last BasicConv writes into the concat slot `out`"""
-        for m in list(seq)[:-1]:
-            x = m(x)
-        return seq[-1](x, out=out)
+        """nn.Sequential of blocks whose last BasicConv writes into the concat slot `out`.  A BasicConv followed by another
+        BasicConv hands its result on as an ops.Lazy: that BatchNorm(+ReLU) is applied by the next conv's operand prologue."""
+        mods = list(seq)
+        for k, m in enumerate(mods[:-1]):
+            if isinstance(m, BasicConv):
+                x = m(x, lazy=isinstance(mods[k + 1], BasicConv))
+            else:
+                x = m(ops.materialize(x))
+        return mods[-1](x, out=out)
 
     def forward(self, x, out=None):
         x_e, x_e2, x_cat, x_sc = ops.fork(x, 4)
@@ -329,7 +335,8 @@ class GRFB(nn.Module):
 
     def forward(self, x):
         x_cat, x0, x1, x2, x_sc = ops.fork(x, 5)
-        cat = ops.cat_channels([x_cat, self.branch0(x0), self.branch1(x1), self.branch2(x2)])
+        seq = EdgeEnhancedGRFB._seq                       # BasicConv chains: BatchNorm(+ReLU) applied by the next conv's prologue
+        cat = ops.cat_channels([x_cat, seq(self.branch0, x0, None), seq(self.branch1, x1, None), seq(self.branch2, x2, None)])
         return ops.scale_add_relu(self.ConvLinear(cat), self.scale, self.shortcut(x_sc))     # relu(out*scale + short)
 
 
@@ -402,7 +409,7 @@ class DoubleConv1(nn.Sequential):
 
     def forward(self, x, out=None):
         o = 1 if self._mca else 0
-        x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU)
+        x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU, lazy=not self._mca)   # the MCALayer needs the tensor; a conv does not
         if self._mca:
             x = self[3](x)
         x = ops.conv_bn_act(x, self[3 + o], self[4 + o], ACT_RELU)
@@ -458,5 +465,5 @@ class GRFBUNet(_SegNetBase):
         y = self.up1(x5, x4s, bufs[3])
         y = self.up2(y, x3s, bufs[2])
         y = self.up3(y, x2s, bufs[1])
-        y = self.up4(y, x1s, bufs[0])
+        y = self.up4(y, x1s, bufs[0], lazy=True)                 # the 1x1 classifier applies up4's last BatchNorm+ReLU itself
         return self._exit(self.out_conv(y))

@@ -3,13 +3,14 @@
 Activations are NHWC tensors ``[N, H, W, C]`` (fp32 or bf16, C a multiple of 8, possibly a channel-slice view of a
 wider buffer).  torch is used for memory (torch.empty / views), streams and autograd bookkeeping only.
 """
+import os
 import struct
 import weakref
 
 import torch
 from torch.autograd import Function, Variable
 
-from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, dtype_code, lib, ptr, stream  # noqa: F401
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, PRE_BN_ACT, PRE_BN_BWD, PRE_NONE, dtype_code, lib, ptr, stream  # noqa: F401
 
 
 def pad8(c: int) -> int:
@@ -305,31 +306,133 @@ def _channel_sum(t):
     return out
 
 
-class _Conv2d(Function):
-    """nn.Conv2d (stride 1, same padding) on NHWC activations; weight stays the fp32 OIHW nn.Parameter."""
+# environment switch for A/B runs and for the bit-exactness test of the fused path against the materialised one
+_FUSE_BN = os.environ.get("EGM_FUSE_BN", "1") != "0"
+
+
+def fuse_bn(enabled=None):
+    """Get / set whether BatchNorm(+activation) is folded into consuming convolutions (Lazy tensors).  Both settings compute the same
+    arithmetic; the materialised form (False) exists for A/B timing and for the bit-exactness test."""
+    global _FUSE_BN
+    if enabled is not None:
+        _FUSE_BN = bool(enabled)
+    return _FUSE_BN
+
+
+class Lazy:
+    """A logical activation z = act(scale*y + shift) that has NOT been written to memory: `y` is the raw conv output (the autograd
+    stand-in: its gradient is, by convention, dL/dz), `coef` the fp32 [4, C] rows scale | shift | mean | rstd of the BatchNorm.
+    Convolutions consume it directly (operand prologue EGM_PRE_BN_ACT); everything else calls materialize()."""
+    __slots__ = ("y", "coef", "act")
+
+    def __init__(self, y, coef, act):
+        self.y, self.coef, self.act = y, coef, act
+
+    shape = property(lambda self: self.y.shape)
+    dtype = property(lambda self: self.y.dtype)
+    device = property(lambda self: self.y.device)
+
+    def materialize(self, out=None):
+        return _Materialize.apply(self.y, self.coef, self.act, None if out is None else [out])
+
+
+def materialize(x, out=None):
+    """Lazy -> tensor (optionally into the destination view `out`); tensors pass through (copied only if `out` is another place)."""
+    if isinstance(x, Lazy):
+        return x.materialize(out)
+    if out is not None and not (x.data_ptr() == out.data_ptr() and x.stride() == out.stride()):
+        return _axpby(x, 1.0, None, 0.0, out)
+    return x
+
+
+class _Materialize(Function):
+    """z = act(scale*y + shift) as a tensor.  The gradient of the stand-in y IS dL/dz (see Lazy), so backward is the identity:
+    the activation derivative and the BatchNorm backward both happen in the producing _ConvBN node."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, dil, groups, want_stats, bias_grad_zero=False):
+    def forward(ctx, y, coef, act, out_slot):
+        y, ldy = _nhwc(y)
+        N, H, W, CP = y.shape
+        z, ldz = _slot_or_new(out_slot, (N, H, W, CP), y.dtype, y.device)
+        lib().call("egm_bn_act_fwd", dtype_code(y.dtype), ptr(y), ldy, ptr(coef[0]), ptr(coef[1]), act, ptr(z), ldz, _npix(y), CP, stream())
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None, None
+
+
+def _unlazy(x):
+    """-> (tensor, coef or None, act): the memory operand of a conv and its prologue"""
+    if isinstance(x, Lazy):
+        return x.y, x.coef, x.act
+    return x, None, ACT_NONE
+
+
+def _conv_forward(x, ldx, x_coef, x_act, weight, bias, dil, groups, want_stats):
+    """The conv launch shared by _Conv2d and _ConvBN: y = conv(prologue(x), weight) (+bias), optional BN partial statistics."""
+    N, H, W, CinP = x.shape
+    Cout, Cin_g, KH, KW = weight.shape
+    Cin = Cin_g * groups
+    if pad8(Cin) != CinP:
+        raise RuntimeError(f"conv2d: input has {CinP} channels, weight expects {Cin} (padded {pad8(Cin)})")
+    CoutP = pad8(Cout)
+    L, dt = lib(), dtype_code(x.dtype)
+    wf, wd = _packed_weights(weight, groups, x.dtype)
+    y = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=x.device)
+    pre = PRE_BN_ACT if x_coef is not None else PRE_NONE
+    stats = None
+    if want_stats:
+        ntiles = L.query("egm_conv_stats_tiles_pre", dt, pre, N, H, W, CinP, CoutP, KH, KW, dil)
+        stats = _f32((ntiles, 2, CoutP), x.device)
+    b = bias.detach() if bias is not None else None
+    L.call("egm_conv_fwd_pre", dt, ptr(x), ldx, pre, x_act, ptr(x_coef), None, 0, ptr(wf), ptr(b), Cout if b is not None else 0, ptr(y),
+           CoutP, ptr(stats), N, H, W, CinP, CoutP, KH, KW, dil, stream())
+    return y, stats, wd
+
+
+def _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, dy_pre, dy_out, weight, dil, groups, Cin, Cout):
+    """Weight gradient of one conv (operands may be logical, see egm_conv_wgrad_pre); deferred slab reduction when that is safe.
+    dy_pre: None or (act, cf4 [4, CoutP], y, ldy) = the BatchNorm backward computed while staging; dy_out: tensor that receives the
+    logical dy as a by-product (or None)."""
+    N, H, W, CinP = x.shape
+    CoutP = gy.shape[3]
+    KH, KW = weight.shape[2], weight.shape[3]
+    L, dt, st = lib(), dtype_code(x.dtype), stream()
+    gw = torch.empty_like(weight)
+    nbytes = L.query("egm_conv_wgrad_workspace", N, H, W, CinP, CoutP, KH, KW)
+    ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=x.device)
+    # leaf parameter whose only gradient contribution this is: defer the slab reduction to one multi-conv launch
+    defer = _sole_conv_use(weight) and weight.is_leaf and weight.grad is None
+    xm = PRE_BN_ACT if x_coef is not None else PRE_NONE
+    if dy_pre is None:
+        dm, dact, dcf, daux, dld = PRE_NONE, 0, None, None, 0
+    else:
+        dm, (dact, dcf, daux, dld) = PRE_BN_BWD, dy_pre
+    L.call("egm_conv_wgrad_pre", dt, ptr(x), ldx, xm, x_act, ptr(x_coef), ptr(gy), ldg, dm, dact, ptr(dcf), ptr(daux), dld,
+           ptr(dy_out), CoutP if dy_out is not None else 0, None if defer else ptr(gw), ptr(ws), N, H, W, CinP, CoutP, Cin, Cout,
+           KH, KW, dil, groups, 0, st)
+    if defer:
+        nslab = L.query("egm_conv_wgrad_slabs", dt, N, H, W, CinP, CoutP, KH, KW, dil)
+        if not _pending_wgrad:
+            Variable._execution_engine.queue_callback(_flush_wgrads)
+        _pending_wgrad.append((ws, weight, nslab, KH * KW, CoutP, CinP, Cout, Cin, groups, weakref.ref(gw), gw.data_ptr()))
+    return gw
+
+
+class _Conv2d(Function):
+    """nn.Conv2d (stride 1, same padding) on NHWC activations; weight stays the fp32 OIHW nn.Parameter.  The input may be a logical
+    tensor (x = stand-in, x_coef / x_act = its BatchNorm + activation, applied by the kernels' operand prologue)."""
+
+    @staticmethod
+    def forward(ctx, x, x_coef, x_act, weight, bias, dil, groups, want_stats, bias_grad_zero=False):
         x, ldx = _nhwc(x)
-        N, H, W, CinP = x.shape
-        Cout, Cin_g, KH, KW = weight.shape
-        Cin = Cin_g * groups
-        if pad8(Cin) != CinP:
-            raise RuntimeError(f"conv2d: input has {CinP} channels, weight expects {Cin} (padded {pad8(Cin)})")
-        CoutP = pad8(Cout)
-        wf, wd = _packed_weights(weight, groups, x.dtype)
-        y = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=x.device)
-        stats = None
-        if want_stats:
-            ntiles = lib().query("egm_conv_stats_tiles", dtype_code(x.dtype), N, H, W, CinP, CoutP, KH, KW, dil)
-            stats = _f32((ntiles, 2, CoutP), x.device)
-        b = bias.detach() if bias is not None else None
-        lib().call("egm_conv_fwd", dtype_code(x.dtype), ptr(x), ldx, ptr(wf), ptr(b), Cout if b is not None else 0, ptr(y),
-                   CoutP, ptr(stats), N, H, W, CinP, CoutP, KH, KW, dil, stream())
-        if ctx.needs_input_grad[1]:
+        Cout, Cin_g = weight.shape[0], weight.shape[1]
+        y, stats, wd = _conv_forward(x, ldx, x_coef, x_act, weight, bias, dil, groups, want_stats)
+        if ctx.needs_input_grad[3]:
             _note_conv_use(weight)
-        ctx.save_for_backward(x, weight, wd)
-        ctx.meta = (dil, groups, bias is not None, Cin, Cout)
+        ctx.save_for_backward(x, weight, wd, x_coef)
+        ctx.meta = (dil, groups, bias is not None, Cin_g * groups, Cout, x_act)
         ctx.bias_grad_zero = bias_grad_zero
         ctx.set_materialize_grads(False)                # no zero-filled "gradient" for the non-differentiable stats output
         if want_stats:
@@ -340,9 +443,9 @@ class _Conv2d(Function):
     @staticmethod
     def backward(ctx, gy, *_):
         if gy is None:
-            return (None,) * 7
-        x, weight, wd = ctx.saved_tensors
-        dil, groups, has_bias, Cin, Cout = ctx.meta
+            return (None,) * 9
+        x, weight, wd, x_coef = ctx.saved_tensors
+        dil, groups, has_bias, Cin, Cout, x_act = ctx.meta
         gy, ldg = _nhwc(gy)
         x, ldx = _nhwc(x)
         N, H, W, CinP = x.shape
@@ -353,26 +456,89 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=x.device)
             L.call("egm_conv_fwd", dt, ptr(gy), ldg, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
-        if ctx.needs_input_grad[1]:
-            gw = torch.empty_like(weight)
-            nbytes = L.query("egm_conv_wgrad_workspace", N, H, W, CinP, CoutP, KH, KW)
-            ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=x.device)
-            # leaf parameter whose only gradient contribution this is: defer the slab reduction to one multi-conv launch
-            defer = _sole_conv_use(weight) and weight.is_leaf and weight.grad is None
-            L.call("egm_conv_wgrad", dt, ptr(x), ldx, ptr(gy), ldg, None if defer else ptr(gw), ptr(ws), N, H, W, CinP, CoutP, Cin, Cout,
-                   KH, KW, dil, groups, 0, st)
-            if defer:
-                nslab = L.query("egm_conv_wgrad_slabs", dt, N, H, W, CinP, CoutP, KH, KW, dil)
-                if not _pending_wgrad:
-                    Variable._execution_engine.queue_callback(_flush_wgrads)
-                _pending_wgrad.append((ws, weight, nslab, KH * KW, CoutP, CinP, Cout, Cin, groups, weakref.ref(gw), gw.data_ptr()))
-        if has_bias and ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[3]:
+            gw = _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, None, None, weight, dil, groups, Cin, Cout)
+        if has_bias and ctx.needs_input_grad[4]:
             gb = _f32(Cout, x.device, zero=True) if ctx.bias_grad_zero else _channel_sum(gy)[0, :Cout]
-        return gx, gw, gb, None, None, None, None
+        return gx, None, None, gw, gb, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, dil=1, groups=1, want_stats=False, bias_grad_zero=False):
-    return _Conv2d.apply(x, weight, bias, dil, groups, want_stats, bias_grad_zero)
+    """x: NHWC tensor or Lazy (consumed through the conv's operand prologue, never materialised)."""
+    xt, xc, xa = _unlazy(x)
+    return _Conv2d.apply(xt, xc, xa, weight, bias, dil, groups, want_stats, bias_grad_zero)
+
+
+class _ConvBN(Function):
+    """conv -> BatchNorm (-> act, applied by whoever consumes the result) as ONE autograd node.
+
+    forward : y = conv(prologue(x)) with the BN statistics from the conv epilogue; egm_bn_finalize -> coef.  Returns the RAW conv
+              output y as the stand-in of the logical z = act(scale*y + shift), and coef (see Lazy).
+    backward: receives dL/dz.  Partial sums (dz, y) -> egm_bn_bwd_coefs -> the weight-gradient kernel computes dy = f(dz, y) while
+              staging it (EGM_PRE_BN_BWD) and writes it out once as a by-product; the data gradient reads that.  No BatchNorm apply
+              pass in either direction."""
+
+    @staticmethod
+    def forward(ctx, x, x_coef, x_act, weight, bias, gamma, beta, running_mean, running_var, eps, momentum, act, training, dil, groups):
+        x, ldx = _nhwc(x)
+        Cout, Cin_g = weight.shape[0], weight.shape[1]
+        y, stats, wd = _conv_forward(x, ldx, x_coef, x_act, weight, bias, dil, groups, training)
+        CoutP, npix, dev = y.shape[3], _npix(y), y.device
+        L, st = lib(), stream()
+        coef = _f32((4, CoutP), dev)                    # scale, shift, save_mean, save_rstd
+        if training:
+            L.call("egm_bn_finalize", ptr(stats), stats.shape[0], npix, ptr(gamma.detach()), ptr(beta.detach()), eps, momentum,
+                   ptr(running_mean), ptr(running_var), ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), CoutP, Cout, st)
+        else:
+            L.call("egm_bn_eval_coeffs", ptr(gamma.detach()), ptr(beta.detach()), ptr(running_mean), ptr(running_var), eps,
+                   ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), CoutP, Cout, st)
+        if ctx.needs_input_grad[3]:
+            _note_conv_use(weight)
+        ctx.save_for_backward(x, weight, wd, x_coef, y, coef)
+        ctx.meta = (dil, groups, bias is not None, Cin_g * groups, Cout, x_act, act, training)
+        ctx.mark_non_differentiable(coef)
+        ctx.set_materialize_grads(False)
+        return y, coef
+
+    @staticmethod
+    def backward(ctx, gz, _):
+        if gz is None:
+            return (None,) * 15
+        x, weight, wd, x_coef, y, coef = ctx.saved_tensors
+        dil, groups, has_bias, Cin, Cout, x_act, act, training = ctx.meta
+        gz, ldg = _nhwc(gz)
+        x, ldx = _nhwc(x)
+        y, ldy = _nhwc(y)
+        N, H, W, CinP = x.shape
+        CoutP, npix, dev = y.shape[3], _npix(y), y.device
+        KH, KW = weight.shape[2], weight.shape[3]
+        L, dt, st = lib(), dtype_code(x.dtype), stream()
+        scale, shift, mean, rstd = coef[0], coef[1], coef[2], coef[3]
+        nb = L.query("egm_channel_partials_blocks", npix, CoutP)
+        part = _f32(nb * 2 * CoutP, dev)
+        L.call("egm_bn_act_bwd_reduce", dt, ptr(gz), ldg, ptr(y), ldy, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), act, ptr(part),
+               npix, CoutP, st)
+        sums, cf4 = _f32((2, CoutP), dev), _f32((4, CoutP), dev)
+        L.call("egm_bn_bwd_coefs", ptr(part), nb, npix, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), 1 if training else 0, ptr(sums),
+               ptr(cf4), CoutP, st)
+        need_gx, need_gw = ctx.needs_input_grad[0], ctx.needs_input_grad[3]
+        gx = gw = gb = dy = None
+        if need_gx:
+            dy = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev)
+        if need_gw:
+            # the weight-gradient kernel computes dy from (dz, y) while staging and leaves it in `dy` for the data gradient below
+            gw = _conv_wgrad(x, ldx, x_coef, x_act, gz, ldg, (act, cf4, y, ldy), dy, weight, dil, groups, Cin, Cout)
+        elif need_gx:
+            L.call("egm_bn_act_bwd_apply", dt, ptr(gz), ldg, ptr(y), ldy, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), act,
+                   1 if training else 0, ptr(sums), ptr(dy), CoutP, npix, CoutP, st)
+        if need_gx:
+            gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=dev)
+            L.call("egm_conv_fwd", dt, ptr(dy), CoutP, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
+        if has_bias and ctx.needs_input_grad[4]:
+            gb = _f32(Cout, dev, zero=True)             # a conv bias feeding a BatchNorm has an identically zero gradient
+        ggamma = sums[1, :Cout] if ctx.needs_input_grad[5] else None
+        gbeta = sums[0, :Cout] if ctx.needs_input_grad[6] else None
+        return gx, None, None, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -463,13 +629,21 @@ def bn_act(y, bn, act, stats=None, out=None):
                         None if out is None else [out])
 
 
-def conv_bn_act(x, conv, bn, act, dil=1, groups=1, out=None):
-    """conv -> BatchNorm -> activation with the BN statistics produced by the conv epilogue.  `out`: optional destination view."""
-    if bn.training:
-        # a conv bias feeding a train-mode BN has an identically zero gradient (the batch mean absorbs it)
-        y, stats = conv2d(x, conv.weight, conv.bias, dil, groups, want_stats=True, bias_grad_zero=True)
-        return bn_act(y, bn, act, stats, out)
-    return bn_act(conv2d(x, conv.weight, conv.bias, dil, groups), bn, act, None, out)
+def conv_bn_act(x, conv, bn, act, dil=1, groups=1, out=None, lazy=False):
+    """conv -> BatchNorm -> activation (statistics from the conv epilogue).  x: NHWC tensor or Lazy.
+    lazy=True returns the result as a Lazy (for a consumer that is a convolution: the BatchNorm apply never runs as a pass);
+    otherwise the result is materialised, into the destination view `out` when given."""
+    if bn.training and bn.num_batches_tracked is not None and not getattr(bn, "_egm_counter_managed", False):
+        bn.num_batches_tracked.add_(1)                  # bookkeeping counter (int64), as nn.BatchNorm2d does
+    training = bn.training or bn.running_mean is None
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    if not _FUSE_BN:
+        x = materialize(x)
+    xt, xc, xa = _unlazy(x)
+    y, coef = _ConvBN.apply(xt, xc, xa, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, act,
+                            training, dil, groups)
+    z = Lazy(y, coef, act)
+    return z if (lazy and out is None and _FUSE_BN) else z.materialize(out)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -615,6 +789,9 @@ class _Fork(Function):
 
 
 def fork(x, n):
+    """n autograd aliases of x whose gradients are summed in one pass; a Lazy forks into n Lazies over aliases of its stand-in."""
+    if isinstance(x, Lazy):
+        return tuple(Lazy(y, x.coef, x.act) for y in _Fork.apply(x.y, n))
     return _Fork.apply(x, n)
 
 

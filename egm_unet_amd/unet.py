@@ -26,9 +26,11 @@ class DoubleConv(nn.Sequential):
             nn.ReLU(inplace=True),
         )
 
-    def forward(self, x, out=None):  # x: NHWC; out: optional destination view (a concat slot)
-        x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU)
-        return ops.conv_bn_act(x, self[3], self[4], ACT_RELU, out=out)
+    def forward(self, x, out=None, lazy=False):
+        """x: NHWC; out: optional destination view (a concat slot); lazy: hand the result on as an ops.Lazy (the caller feeds it to a
+        convolution).  The first BatchNorm+ReLU is never a pass: the second conv applies it while staging its input."""
+        x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU, lazy=True)
+        return ops.conv_bn_act(x, self[3], self[4], ACT_RELU, out=out, lazy=lazy)
 
 
 class Down(nn.Sequential):
@@ -54,11 +56,12 @@ class Up(nn.Module):
             self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
             self.conv = DoubleConv(in_channels, out_channels)
 
-    def forward(self, x1, x2, catbuf=None):   # x1: low-res, x2: skip (both NHWC); catbuf: concat destination that already holds x2
+    def forward(self, x1, x2, catbuf=None, lazy=False):
+        """x1: low-res, x2: skip (both NHWC); catbuf: concat destination that already holds x2; lazy: see DoubleConv.forward"""
         if self.bilinear:
-            return self.conv(ops.upcat(x2, x1, catbuf))
+            return self.conv(ops.upcat(x2, x1, catbuf), lazy=lazy)
         x1 = ops.conv_transpose2x2(x1, self.up, (x2.shape[1], x2.shape[2]))
-        return self.conv(ops.cat_channels([x2, x1]))
+        return self.conv(ops.cat_channels([x2, x1]), lazy=lazy)
 
 
 class OutConv(nn.Sequential):
@@ -136,5 +139,5 @@ class UNet(_SegNetBase):
         y = self.up1(x5, x4s)
         y = self.up2(y, x3s)
         y = self.up3(y, x2s)
-        y = self.up4(y, x1s)
+        y = self.up4(y, x1s, lazy=True)                          # the 1x1 classifier applies up4's last BatchNorm+ReLU itself
         return self._exit(self.out_conv(y))
