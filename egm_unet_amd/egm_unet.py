@@ -461,7 +461,10 @@ class GRFBUNet(_SegNetBase):
         x2, x2s = ops.fork(self.down1(x1, slots[1]), 2)
         x3, x3s = ops.fork(self.down2(x2, slots[2]), 2)
         x4, x4s = ops.fork(self.down3(x3, slots[3]), 2)
-        x5 = self.attn1(self.down4(x4))
+        d4 = self.down4(x4)
+        if self.ddp_boundary is not None:                 # graph.GraphedTrainStep splits backward at the encoder -> decoder tensors
+            self.ddp_boundary.extend([x1s, x2s, x3s, x4s, d4])
+        x5 = self.attn1(d4)
         y = self.up1(x5, x4s, bufs[3])
         y = self.up2(y, x3s, bufs[2])
         y = self.up3(y, x2s, bufs[1])

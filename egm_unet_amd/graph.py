@@ -1,14 +1,29 @@
-"""Whole-step hipGraph capture of the training step (forward + criterion + backward + fused SGD).
+"""hipGraph capture of the training step (forward + criterion + backward + fused SGD).
 
-The eager step issues ~1700 kernel launches through Python autograd; on MI355X their device time (tens of ms) is close
-to the host time needed to issue them, so the step is captured once into a HIP graph (torch.cuda.CUDAGraph on ROCm is
-hipGraph) and replayed: one host call per step, static device buffers, no Python in the loop.
+The eager step issues ~1000 kernel launches through Python autograd; on MI355X their device time is close to the host time
+needed to issue them, so the step is captured once into HIP graphs (torch.cuda.CUDAGraph on ROCm is hipGraph) and replayed:
+static device buffers, no Python in the loop.
 
     step = GraphedTrainStep(model, optimizer, example_image, example_target, loss_weight, num_classes, ignore_index=255)
     loss = step(image, target)        # copies the batch into the static buffers, replays, returns the device loss
 
-With a GradAllReducer (data parallel) the graph holds forward+backward only; the bucketed RCCL all-reduce and the SGD
-update run right after each replay on the live stream.
+Single GPU: ONE graph holds forward, criterion, backward and the SGD update.
+
+Data parallel (a GradAllReducer with world > 1): the step is captured as THREE graphs so that the gradient exchange overlaps the
+encoder's backward (the reference has no DDP at all; BASELINE.json's north_star asks for exactly this overlap):
+
+    graph A   forward, criterion, backward of the decoder side (out_conv, up4..up1, attn1 = bucket 0 of parallel.py), gather of
+              bucket 0 into its flat buffer.  The backward stops at the encoder/decoder boundary tensors (the four skip
+              connections and down4's output), whose gradients it leaves in static buffers.
+    side stream: all-reduce of bucket 0 (RCCL), enqueued BEFORE graph B is launched
+    graph B   backward of the encoder (down4..down1, in_conv = bucket 1) from the boundary gradients, gather of bucket 1
+    side stream: all-reduce of bucket 1
+    graph C   fused SGD reading the reduced buckets with grad_scale = 1/world (after the main stream has joined the side stream)
+
+The learning rate is read by the SGD kernel from a device scalar (optimizer.lr_dev), refreshed from param_groups before every
+replay, so LR schedulers keep working (a captured graph bakes by-value arguments in).  The constructor's warm-up runs
+`warmup` REAL eager training steps on the example batch (allocator warm-up, lazy kernel attributes, momentum buffers); pass
+restore_after_warmup=True to get weights, BatchNorm statistics and momentum back to their values from before the warm-up.
 """
 import torch
 
@@ -18,11 +33,25 @@ from .train_utils.train_and_eval import criterion
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, example_image, example_target, loss_weight=None, num_classes=2, ignore_index=255,
-                 reducer=None, warmup=3):
+                 reducer=None, warmup=3, restore_after_warmup=False, split=None):
         self.model, self.opt, self.reducer = model, optimizer, reducer
         self.lw, self.nc, self.ign = loss_weight, num_classes, ignore_index
         self.x = example_image.clone()
         self.t = example_target.clone()
+        self.trace = []                               # host-order log of the last call (tests assert the overlap structure on it)
+        dev = self.x.device
+        # ---- learning rate in device memory; managed here unless the caller already does (train_one_epoch)
+        self._own_lr = optimizer.lr_dev is None
+        if self._own_lr:
+            optimizer.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._lr_pinned = torch.zeros(1, dtype=torch.float32).pin_memory()
+            self._lr_event = None
+            self._push_lr()
+        snapshot = None
+        if restore_after_warmup:
+            snapshot = ({k: v.clone() for k, v in model.state_dict().items()},
+                        {p: (st["momentum_buffer"].clone() if st.get("momentum_buffer") is not None else None)
+                         for p, st in optimizer.state.items()}, set(optimizer.state.keys()))
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -34,17 +63,71 @@ class GraphedTrainStep:
                 self.warmup_loss = self._eager().detach()
         cur.wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
+        if snapshot is not None:
+            with torch.no_grad():
+                sd = model.state_dict()
+                for k, v in snapshot[0].items():
+                    sd[k].copy_(v)
+                for p, st in optimizer.state.items():
+                    if p in snapshot[1] and snapshot[1][p] is not None:
+                        st["momentum_buffer"].copy_(snapshot[1][p])
+                    elif st.get("momentum_buffer") is not None:
+                        st["momentum_buffer"].zero_()  # created by the warm-up: v = 0, so the first real step gives v = g as torch does
+            ops.bump_weight_generation()
         self.opt.zero_grad(set_to_none=True)
         if self.reducer is not None:
-            self.reducer.hooks_enabled = False       # no collectives inside the captured graph
-        with self._ns, torch.cuda.graph(self.graph):
-            loss = criterion(self.model(self.x), self.t, self.lw, num_classes=self.nc, ignore_index=self.ign)
-            loss.backward()
-            if self.reducer is None:
-                self.opt.step()
-            self.loss = loss.detach()
+            self.reducer.hooks_enabled = False       # no collectives inside a captured graph
+        want_split = self.reducer is not None and (self.reducer.world > 1 if split is None else split)
+        self.split = bool(want_split and hasattr(model, "ddp_boundary") and len(self.reducer.buckets) == 2)
+        if self.split:
+            self._capture_split()
+        else:
+            self.graph = torch.cuda.CUDAGraph()
+            with self._ns, torch.cuda.graph(self.graph):
+                loss = criterion(self.model(self.x), self.t, self.lw, num_classes=self.nc, ignore_index=self.ign)
+                loss.backward()
+                if self.reducer is None:
+                    self.opt.step()
+                self.loss = loss.detach()
         ops.bump_weight_generation()
+
+    # ---- three-graph capture for the overlapped gradient exchange
+    def _capture_split(self):
+        red, model = self.reducer, self.model
+        self.side = red.side if red.side is not None else torch.cuda.Stream(device=self.x.device)
+        self.gA, self.gB, self.gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        b0, b1 = red.buckets
+        with self._ns, torch.cuda.graph(self.gA):
+            model.ddp_boundary = []                   # forward() fills it with the encoder -> decoder tensors
+            loss = criterion(model(self.x), self.t, self.lw, num_classes=self.nc, ignore_index=self.ign)
+            bnd = list(model.ddp_boundary)
+            # the decoder half of backward: stops at the boundary tensors (their gradients land in .grad) and at bucket 0's parameters
+            torch.autograd.backward(loss, inputs=list(b0) + bnd, retain_graph=True)
+            red.gather_bucket(0)
+            self.loss = loss.detach()
+            bgrads = [b.grad for b in bnd]
+        with self._ns, torch.cuda.graph(self.gB, pool=self.gA.pool()):
+            torch.autograd.backward(bnd, bgrads, inputs=list(b1))
+            red.gather_bucket(1)
+        model.ddp_boundary = None
+        for b in bnd:
+            b.grad = None
+        self.opt.grad_source = red.views
+        with self._ns, torch.cuda.graph(self.gC, pool=self.gA.pool()):
+            self.opt.step()
+
+    def _push_lr(self):
+        lr = float(self.opt.param_groups[0]["lr"])
+        if lr == getattr(self, "_lr_pushed", None):
+            return                                    # unchanged since the last upload
+        self._lr_pushed = lr
+        if self._lr_event is not None:
+            self._lr_event.synchronize()              # the previous upload has read the pinned scalar
+        self._lr_pinned[0] = lr
+        self.opt.lr_dev.copy_(self._lr_pinned, non_blocking=True)
+        if self._lr_event is None:
+            self._lr_event = torch.cuda.Event()
+        self._lr_event.record()
 
     def _eager(self):
         loss = criterion(self.model(self.x), self.t, self.lw, num_classes=self.nc, ignore_index=self.ign)
@@ -59,9 +142,21 @@ class GraphedTrainStep:
         if image is not None:
             self.x.copy_(image, non_blocking=True)
             self.t.copy_(target, non_blocking=True)
-        self.graph.replay()
-        if self.reducer is not None:
-            self.opt.grad_source = self.reducer.reduce_now()
-            self.opt.step()
+        if self._own_lr:
+            self._push_lr()
+        tr = self.trace = []
+        if self.split:
+            red, cur = self.reducer, torch.cuda.current_stream()
+            self.gA.replay(); tr.append("graph A: forward + decoder backward + gather bucket 0")
+            red.exchange_bucket(0, self.side, cur); tr.append("all-reduce bucket 0 enqueued on the side stream")
+            self.gB.replay(); tr.append("graph B: encoder backward + gather bucket 1")
+            red.exchange_bucket(1, self.side, cur); tr.append("all-reduce bucket 1 enqueued on the side stream")
+            red.join(self.side, cur); tr.append("main stream joined the side stream")
+            self.gC.replay(); tr.append("graph C: SGD on the reduced buckets")
+        else:
+            self.graph.replay(); tr.append("graph: forward + backward" + (" + SGD" if self.reducer is None else ""))
+            if self.reducer is not None:
+                self.opt.grad_source = self.reducer.reduce_now()
+                self.opt.step(); tr.append("exchange + SGD after the replay")
         ops.bump_weight_generation()                  # packed-weight caches are stale after an in-graph update
         return self.loss

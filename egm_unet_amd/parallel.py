@@ -19,22 +19,14 @@ from ._lib import lib, ptr
 BUCKET0_PREFIXES = ("out_conv", "up4", "up3", "up2", "up1", "attn1")
 
 
-_gather_tables = {}
-
-
-def _hip_gather(entries, device, stream_handle):
-    """entries: [(dst_view, src_grad)] -> one multi-tensor copy on the given stream."""
-    rows = tuple((d.data_ptr(), s.data_ptr(), s.numel()) for d, s in entries)
-    hit = _gather_tables.get(rows[0][0])
-    if hit is None or hit[0] != rows:
-        # pointers changed: a FRESH pinned staging buffer and device table per distinct pointer set (an upload still in flight from
-        # the previous buffer is never overwritten; the old pair stays alive in the caller's keep-list until finish())
-        pinned = torch.tensor(rows, dtype=torch.int64).pin_memory()
-        table = torch.empty(pinned.shape, dtype=torch.int64, device=device)
-        table.copy_(pinned, non_blocking=True)
-        _gather_tables[rows[0][0]] = hit = (rows, pinned, table)
-    lib().call("egm_copy_multi", ptr(hit[2]), len(rows), stream_handle)
-    return hit
+def _hip_gather(entries, device, stream_handle, table):
+    """entries: [(dst_view, src_grad)] -> one multi-tensor copy on the given stream.  `table`: the ops.DeviceTable that carries the
+    (dst, src, count) rows to the device -- uploaded from a pinned staging buffer only when a pointer changed, ordered behind the
+    previous upload, one set of buffers per table namespace (so a captured graph owns the bytes it re-copies on replay)."""
+    import struct
+    blob = b"".join(struct.pack("<qqq", d.data_ptr(), s.data_ptr(), s.numel()) for d, s in entries)
+    dev_table = table.get(blob, device)
+    lib().call("egm_copy_multi", ptr(dev_table), len(entries), stream_handle)
 
 
 class GradAllReducer:
@@ -68,6 +60,12 @@ class GradAllReducer:
             self.flat.append(flat)
         self.gather_fn = gather_fn
         cuda = dev.type == "cuda"
+        self._tables = None
+        if cuda and gather_fn is None:
+            from . import ops
+            self._tables = [ops.DeviceTable() for _ in self.buckets]
+            for tb in self._tables:
+                tb.reserve(dev)
         self.side = torch.cuda.Stream(device=dev) if (cuda and (use_side_stream is None or use_side_stream)) else None
         self._pending = [len(ps) for ps in self.buckets]
         self._works, self._keep = [], []
@@ -95,21 +93,44 @@ class GradAllReducer:
             ev.record(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ev)
-                self._gather(entries)
+                self._gather(entries, b)
                 if self.world > 1:
                     self._works.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
         else:
-            self._gather(entries)
+            self._gather(entries, b)
             if self.world > 1:
                 self._works.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
 
-    def _gather(self, entries):
+    def _gather(self, entries, b):
         if self.gather_fn is not None:
             self.gather_fn(entries)
         else:
             import ctypes
             h = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            self._keep.append(_hip_gather(entries, self.device, h))
+            _hip_gather(entries, self.device, h, self._tables[b])
+
+    # ---- explicit phases for a step captured as hipGraphs (graph.GraphedTrainStep): the gathers are captured inside the graphs, the
+    # collectives run between the replays on the side stream
+    def gather_bucket(self, b):
+        """Copy bucket b's parameter gradients into its flat buffer on the CURRENT stream (legal inside a hipGraph capture)."""
+        self._gather([(self.views[p], p.grad) for p in self.buckets[b]], b)
+
+    def exchange_bucket(self, b, side, cur):
+        """All-reduce flat bucket b on `side` once everything queued on `cur` so far (the graph that filled it) has finished."""
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            if self.world > 1:
+                self._works.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
+
+    def join(self, side, cur):
+        """Make the reduced buckets visible to `cur`."""
+        with torch.cuda.stream(side):
+            for w in self._works:
+                w.wait()
+        cur.wait_stream(side)
+        self._works = []
 
     def reduce_now(self):
         """Gradients already complete (e.g. after a captured fwd+bwd graph replay): exchange every bucket now."""

@@ -78,6 +78,9 @@ class _SegNetBase(nn.Module):
     """Module-boundary plumbing shared by UNet and GRFBUNet: NCHW fp32 in, {"out": NCHW fp32 logits} out."""
 
     compute_dtype = torch.float32
+    # Set to a list by graph.GraphedTrainStep while it captures a data-parallel step: forward() appends the tensors that cross from
+    # the encoder (gradient bucket 1 of parallel.py) to the decoder side (bucket 0), where the captured backward is cut in two.
+    ddp_boundary = None
 
     def set_compute_dtype(self, dtype):
         """torch.float32 (parity path) or torch.bfloat16 (throughput path) activation storage."""
@@ -136,6 +139,10 @@ class UNet(_SegNetBase):
         x3, x3s = ops.fork2(self.down2(x2))
         x4, x4s = ops.fork2(self.down3(x3))
         x5 = self.down4(x4)
+        if self.ddp_boundary is not None:
+            x5, x5d = ops.fork2(x5)                              # the decoder-side alias is the boundary tensor
+            self.ddp_boundary.extend([x1s, x2s, x3s, x4s, x5d])
+            x5 = x5d
         y = self.up1(x5, x4s)
         y = self.up2(y, x3s)
         y = self.up3(y, x2s)

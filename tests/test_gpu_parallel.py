@@ -47,6 +47,30 @@ def _worker(rank, world, port, q, graphed=False):
     torch.cuda.synchronize()
     probe = {k: v.detach().float().cpu().numpy().tolist() for k, v in m.state_dict().items() if k in ("in_conv.0.weight", "out_conv.0.bias")}
     # the averaged gradient of rank-local batches must be identical on both ranks after the all-reduce
+    if not graphed:
+        # ... and it must BE the mean: one step from the same initial weights with both ranks' batches evaluated in this process,
+        # gradients summed and scaled by 1/world, gives the weights of one distributed step (bitwise: a + b is commutative)
+        torch.manual_seed(0)
+        ref, dist_m = UNet(3, 2, base_c=8).to("cuda").train(), UNet(3, 2, base_c=8).to("cuda").train()
+        dist_m.load_state_dict(ref.state_dict())
+        red2 = GradAllReducer(dist_m, world_size=world, broadcast=False)
+        opt_d = SGD(dist_m.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4); opt_d.grad_scale = 1.0 / world
+        criterion(dist_m(x), t, lw, num_classes=2, ignore_index=255).backward()
+        opt_d.grad_source = red2.finish(); opt_d.step()
+        sums = None
+        for r in range(world):
+            gr = torch.Generator().manual_seed(50 + r)
+            xr, tr = torch.randn(2, 3, 32, 32, generator=gr).cuda(), torch.randint(0, 2, (2, 32, 32), generator=gr).cuda()
+            probe_m = UNet(3, 2, base_c=8).to("cuda").train()
+            probe_m.load_state_dict(ref.state_dict())
+            criterion(probe_m(xr), tr, lw, num_classes=2, ignore_index=255).backward()
+            gs = [p.grad.clone() for p in probe_m.parameters()]
+            sums = gs if sums is None else [a + b for a, b in zip(sums, gs)]
+        opt_r = SGD(ref.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4); opt_r.grad_scale = 1.0 / world
+        opt_r.grad_source = dict(zip(ref.parameters(), sums)); opt_r.step()
+        torch.cuda.synchronize()
+        mism = [n for (n, a), b in zip(ref.named_parameters(), dist_m.parameters()) if not torch.equal(a, b)]
+        probe["mean_mismatch"] = mism[:4]
     q.put((rank, probe))
     dist.barrier()
     dist.destroy_process_group()
@@ -65,6 +89,9 @@ def test_two_ranks_stay_in_sync(graphed):
         p.join(timeout=120)
         assert p.exitcode == 0
     for k in res[0]:
+        if k == "mean_mismatch":
+            assert res[0][k] == [] and res[1][k] == [], ("the exchanged gradient is not the mean of the ranks' gradients", res[0][k])
+            continue
         a, b = torch.tensor(res[0][k]), torch.tensor(res[1][k])
         assert torch.allclose(a, b, rtol=0, atol=0), k          # bitwise: same reduced gradients, same update
 
@@ -138,9 +165,17 @@ def test_reducer_paths_match_plain_training_bitwise():
         m.load_state_dict(sd0)
         opt = SGD(m.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
         red = GradAllReducer(m, world_size=1) if mode != "plain" else None
-        if mode == "graph":
-            step = GraphedTrainStep(m, opt, x, t, lw, num_classes=2, ignore_index=255, reducer=red, warmup=1)   # warm-up = step 1
+        if mode in ("graph", "split"):
+            step = GraphedTrainStep(m, opt, x, t, lw, num_classes=2, ignore_index=255, reducer=red, warmup=1,   # warm-up = step 1
+                                    split=(mode == "split"))
+            assert step.split == (mode == "split")
             step()
+            if mode == "split":
+                # the overlap structure of the data-parallel step: bucket 0's collective is enqueued (side stream) BEFORE the
+                # encoder-backward graph is launched, SGD runs as its own graph after the join
+                order = [s.split(":")[0] for s in step.trace]
+                assert order == ["graph A", "all-reduce bucket 0 enqueued on the side stream", "graph B",
+                                 "all-reduce bucket 1 enqueued on the side stream", "main stream joined the side stream", "graph C"], step.trace
         else:
             for _ in range(2):
                 loss = criterion(m(x), t, lw, num_classes=2, ignore_index=255)
@@ -154,8 +189,10 @@ def test_reducer_paths_match_plain_training_bitwise():
             red.remove()
         return {k: v.detach().clone() for k, v in m.state_dict().items()}
 
-    plain, eager, graph = run("plain"), run("eager"), run("graph")
+    plain, eager, graph, split = run("plain"), run("eager"), run("graph"), run("split")
     bad_e = [k for k in plain if not torch.equal(plain[k], eager[k])]
     bad_g = [k for k in plain if not torch.equal(plain[k], graph[k])]
+    bad_s = [k for k in plain if not torch.equal(plain[k], split[k])]
     assert not bad_e, ("eager reducer", bad_e[:6])
     assert not bad_g, ("graphed reducer", bad_g[:6])
+    assert not bad_s, ("three-graph step with the exchange between the graphs", bad_s[:6])
