@@ -433,6 +433,279 @@ __global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2 && !PRE) ? 2 : 1
 #endif
 }
 
+// -------------------------------------------------------------------------------------------------
+// Wave-specialised bf16 kernel (the throughput path): 8 waves per workgroup, one workgroup per CU.
+//   * waves 0-3 (one per SIMD) are CONSUMERS: A x B x C split as above, NTAPS accumulators each, nothing but transposing LDS reads
+//     and MFMAs in their loop -- no staging registers, no global memory instruction, no VALU work besides addressing;
+//   * waves 4-7 are PRODUCERS: they load the next tile's dy / x vectors into registers, apply the operand prologues (prologue.h:
+//     x = act(bn(y_prev)), dy = BatchNorm backward of (dz, y)), write the result into the OTHER LDS image pair, store dy once to
+//     memory for the data-gradient kernel (by-product) and immediately re-issue the loads of the tile after next into the freed
+//     registers, so a whole tile period hides the global latency.
+//   A consumer and a producer wave share each SIMD: the producers' VALU work (50-55 instructions per 16-byte vector for the
+//   BatchNorm backward) runs beside the consumers' MFMAs instead of in front of them -- in the one-wave-per-SIMD kernel above the
+//   same prologue work is serialised with the matrix work and doubles the kernel.  One barrier per tile.
+template <int NTAPS, bool PRE>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using M = WMma<bf16_t>;
+    constexpr int WH = Window<NTAPS>::WH, WW = Window<NTAPS>::WW;
+    constexpr bool DROW = (NTAPS == 3);
+    constexpr int PH = TH + WH - 1;
+    constexpr int PWC = DROW ? TW + 2 * kMaxRowDil : TW + WW - 1;
+    const int PW = DROW ? TW + 2 * p.dil : TW + WW - 1;
+    constexpr int RB = 64, VPR = 4;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wv >= 4;
+    const int cw = wv & 3;                                             // consumer index (producers: unused role split)
+    const int wa = cw % p.A, wb = (cw / p.A) % p.B, wc = cw / (p.A * p.B);
+    const int ptid = tid & 255;                                        // producer thread index
+    const int split = blockIdx.x;
+    const int cot = blockIdx.y / p.nci_tiles, cit = blockIdx.y % p.nci_tiles;
+    const int grp = blockIdx.z;
+    const int co_base = cot * 32 * p.A, ci_base = cit * 32 * p.B;
+
+    int offy, offx, tap0;
+    if (DROW) { offy = (grp - 1) * p.dil; offx = -p.dil; tap0 = grp * 3; }
+    else if (p.dil == 1) {
+        if (NTAPS == 9 || NTAPS == 1) { offy = -(p.KH / 2); offx = -(p.KW / 2); tap0 = 0; }
+        else { offy = grp - p.KH / 2; offx = -(p.KW / 2); tap0 = grp * p.KW; }
+    } else { offy = (grp / p.KW - p.KH / 2) * p.dil; offx = (grp % p.KW - p.KW / 2) * p.dil; tap0 = grp; }
+
+    const int ndy = p.A * TH * TW * VPR, nx = p.B * PH * PW * VPR;
+    const int img_bytes = (p.A * TH * TW + p.B * PH * PW) * RB;           // one dy + x image pair; two of them, then the coefficients
+    const bf16_t* __restrict__ xg = reinterpret_cast<const bf16_t*>(p.x);
+    const bf16_t* __restrict__ dyg = reinterpret_cast<const bf16_t*>(p.dy);
+    const bf16_t* __restrict__ yg = reinterpret_cast<const bf16_t*>(p.predy.aux);
+    bf16_t* __restrict__ og = reinterpret_cast<bf16_t*>(p.dy_out);
+    float* cf_dy = reinterpret_cast<float*>(smem + p.cf_off);
+    float* cf_x = cf_dy + 4 * 32 * p.A;
+    const int cs_dy = 32 * p.A, cs_x = 32 * p.B;
+    if (PRE) {
+        for (int i = tid; i < 4 * cs_dy; i += 512) {
+            const int r = i / cs_dy, c = co_base + (i - r * cs_dy);
+            cf_dy[i] = (p.predy.mode != EGM_PRE_NONE && c < p.Cout && (r < 2 || p.predy.mode == EGM_PRE_BN_BWD)) ? p.predy.cf[r * p.predy.C + c] : 0.f;
+        }
+        for (int i = tid; i < 2 * cs_x; i += 512) {
+            const int r = i / cs_x, c = ci_base + (i - r * cs_x);
+            cf_x[i] = (p.prex.mode != EGM_PRE_NONE && c < p.Cin) ? p.prex.cf[r * p.prex.C + c] : 0.f;
+        }
+    }
+
+    const int tpi = p.tiles_y * p.tiles_x;
+    auto tile_ok = [&](int pt, int& n, int& oy0, int& ox0) __attribute__((always_inline)) {
+        n = pt / tpi; const int trem = pt - n * tpi;
+        oy0 = (trem / p.tiles_x) * TH; ox0 = (trem % p.tiles_x) * TW;
+        return !(p.dil > 1 && (oy0 + offy >= p.H || oy0 + offy + TH <= 0 || ox0 + offx >= p.W || ox0 + offx + (DROW ? PW : TW) <= 0));
+    };
+    auto next_tile = [&](int pt, int& n, int& oy0, int& ox0) __attribute__((always_inline)) {
+        while (pt < p.npt && !tile_ok(pt, n, oy0, ox0)) pt += p.nsplit;
+        return pt;
+    };
+
+    // The two roles are two disjoint programs (the producers leave through their own branch): the accumulators are never live in a
+    // producer wave and the staging registers never in a consumer wave, so the kernel's register count is the larger of the two
+    // roles', not their sum.  Both walk the same tile sequence and execute the same number of barriers.
+    int n0 = 0, oy0 = 0, ox0 = 0, n1 = 0, oy1 = 0, ox1 = 0;
+    int pt0 = next_tile(split, n0, oy0, ox0);                           // tile whose image pair is (about to be) complete
+    int pt1 = pt0 < p.npt ? next_tile(pt0 + p.nsplit, n1, oy1, ox1) : p.npt;
+
+    if (producer) {
+        // ---- producer state: 16-byte vector i = ptid + 256 k of the dy image / the x image (block-major [32-ch block][pixel][4 vectors])
+        constexpr int DYVEC = ((DROW ? 1 : 2) * TH * TW * VPR + 255) / 256;
+        constexpr int XVEC = ((DROW ? 1 : 2) * PH * PWC * VPR + 255) / 256;
+        uint4 rdy[DYVEC], rya[PRE ? DYVEC : 1], rx[XVEC];
+        const bool dy_writer = PRE && og != nullptr && cit == 0 && grp == p.out_grp;
+        const bool dy_bwd = PRE && p.predy.mode == EGM_PRE_BN_BWD, x_act = PRE && p.prex.mode != EGM_PRE_NONE;
+        const int v4 = ptid & 3;                                        // the thread's vector inside a 32-channel row (same for all its slots)
+        // slot geometry -> (inside the tensor?, pixel offset from the tile's / patch's first pixel, channel offset inside the block set)
+        auto dy_geom = [&](int k, int oy_, int ox_, int& rel, int& cl) __attribute__((always_inline)) {
+            const int i = ptid + k * 256, pix = (i >> 2) & (TH * TW - 1), blk = i >> 10;    // TH*TW*VPR = 1024
+            const int py = pix >> 5, px = pix & 31;
+            cl = blk * 32 + v4 * 8;
+            rel = py * p.W + px;
+            return i < ndy && oy_ + py < p.H && ox_ + px < p.W && co_base + cl < p.Cout;
+        };
+        // x slots: (block, patch row, patch column) packed once per thread (the patch width is a run-time value for dilated rows, and
+        // integer division has no instruction on this machine: ~25 per quotient, per slot, per tile otherwise)
+        int xpk[XVEC];
+#pragma unroll
+        for (int k = 0; k < XVEC; ++k) {
+            const int i = ptid + k * 256, q = i >> 2, npp = PH * PW;
+            const int blk = q / npp, pix = q - blk * npp, py = pix / PW, px = pix - py * PW;
+            xpk[k] = (i < nx && ci_base + blk * 32 + v4 * 8 < p.Cin) ? (blk << 20) | (py << 10) | px : -1;
+        }
+        auto x_geom = [&](int k, int iy0, int ix0, int& rel, int& cl) __attribute__((always_inline)) {
+            const int pk = xpk[k], blk = pk >> 20, py = (pk >> 10) & 1023, px = pk & 1023;
+            cl = blk * 32 + v4 * 8;
+            rel = py * p.W + px;
+            const int iy = iy0 + py, ix = ix0 + px;
+            return pk >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        };
+        auto issue_tile = [&](int n, int oy_, int ox_) __attribute__((always_inline)) {
+            const long long o_dy = (long long)(n * p.H + oy_) * p.W + ox_;                // first pixel of the dy tile (inside the image)
+            const long long o_x = (long long)(n * p.H + oy_ + offy) * p.W + ox_ + offx;   // first pixel of the x patch (may be outside)
+            const bf16_t* dbase = dyg + o_dy * p.lddy + co_base;
+            const bf16_t* ybase = dy_bwd ? yg + o_dy * p.predy.ld_aux + co_base : nullptr;
+            const bf16_t* xbase = xg + o_x * p.ldx + ci_base;
+#pragma unroll
+            for (int k = 0; k < DYVEC; ++k) {
+                int rel, cl;
+                const bool ok = dy_geom(k, oy_, ox_, rel, cl);
+                rdy[k] = make_uint4(0, 0, 0, 0);
+                if (ok) rdy[k] = *reinterpret_cast<const uint4*>(dbase + rel * p.lddy + cl);
+                if (PRE) { rya[k] = make_uint4(0, 0, 0, 0); if (ok && dy_bwd) rya[k] = *reinterpret_cast<const uint4*>(ybase + rel * p.predy.ld_aux + cl); }
+            }
+#pragma unroll
+            for (int k = 0; k < XVEC; ++k) {
+                int rel, cl;
+                const bool ok = x_geom(k, oy_ + offy, ox_ + offx, rel, cl);
+                rx[k] = make_uint4(0, 0, 0, 0);
+                if (ok) rx[k] = *reinterpret_cast<const uint4*>(xbase + rel * p.ldx + cl);
+            }
+        };
+        // transform + LDS write of the tile held in registers (tile coordinates n, oy_, ox_) into image pair `buf`
+        auto write_tile = [&](int buf, int n, int oy_, int ox_) __attribute__((always_inline)) {
+            unsigned char* dyb = smem + buf * img_bytes;
+            unsigned char* xb = dyb + p.A * (TH * TW) * RB;
+            bf16_t* obase = dy_writer ? og + ((long long)(n * p.H + oy_) * p.W + ox_) * p.ld_dy_out + co_base : nullptr;
+#pragma unroll
+            for (int k = 0; k < DYVEC; ++k) {
+                const int i = ptid + k * 256;
+                if (i < ndy) {
+                    uint4 v = rdy[k];
+                    if (PRE && p.predy.mode != EGM_PRE_NONE) {
+                        int rel, cl;
+                        const bool ok = dy_geom(k, oy_, ox_, rel, cl);
+                        // (activations: ReLU or none -- the host entry routes the smooth ones to the 4-wave kernel; three variants
+                        //  of every slot's code would not fit the instruction cache)
+                        if (p.predy.act == EGM_ACT_RELU) v = pre_apply_rt<EGM_ACT_RELU>(bf16_t(), v, rya[k], cf_dy + cl, cs_dy, p.predy.mode, 0);
+                        else v = pre_apply_rt<EGM_ACT_NONE>(bf16_t(), v, rya[k], cf_dy + cl, cs_dy, p.predy.mode, 0);
+                        if (!ok) v = make_uint4(0, 0, 0, 0);
+                        else if (dy_writer) *reinterpret_cast<uint4*>(obase + rel * p.ld_dy_out + cl) = v;
+                    }
+                    *reinterpret_cast<uint4*>(dyb + i * 16) = v;
+                }
+                if (PRE) __builtin_amdgcn_sched_barrier(0);              // one vector at a time: interleaving the slots only costs registers
+            }
+#pragma unroll
+            for (int k = 0; k < XVEC; ++k) {
+                const int i = ptid + k * 256;
+                if (i < nx) {
+                    uint4 v = rx[k];
+                    if (x_act) {
+                        int rel, cl;
+                        const bool ok = x_geom(k, oy_ + offy, ox_ + offx, rel, cl);
+                        if (p.prex.act == EGM_ACT_RELU) v = pre_apply_rt<EGM_ACT_RELU>(bf16_t(), v, v, cf_x + cl, cs_x, EGM_PRE_BN_ACT, 0);
+                        else v = pre_apply_rt<EGM_ACT_NONE>(bf16_t(), v, v, cf_x + cl, cs_x, EGM_PRE_BN_ACT, 0);
+                        if (!ok) v = make_uint4(0, 0, 0, 0);
+                    }
+                    *reinterpret_cast<uint4*>(xb + i * 16) = v;
+                }
+                if (PRE) __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // Producers run one tile ahead in LDS and two ahead in registers.
+        if (pt0 < p.npt) issue_tile(n0, oy0, ox0);
+        __syncthreads();                                                // coefficient rows visible
+        if (pt0 < p.npt) {
+            write_tile(0, n0, oy0, ox0);
+            if (pt1 < p.npt) issue_tile(n1, oy1, ox1);
+        }
+        __syncthreads();
+        int buf = 0;
+        while (pt0 < p.npt) {
+            int n2 = 0, oy2 = 0, ox2 = 0;
+            const int pt2 = pt1 < p.npt ? next_tile(pt1 + p.nsplit, n2, oy2, ox2) : p.npt;
+            if (pt1 < p.npt) {
+                write_tile(buf ^ 1, n1, oy1, ox1);                      // registers -> the image pair the consumers are NOT reading
+                if (pt2 < p.npt) issue_tile(n2, oy2, ox2);              // the freed registers take the tile after next
+            }
+            __syncthreads();
+            buf ^= 1;
+            pt0 = pt1; pt1 = pt2; n1 = n2; oy1 = oy2; ox1 = ox2;
+        }
+        for (int r = 1; r < p.C; ++r) { __syncthreads(); __syncthreads(); }   // the consumers' cross-wave reduction
+        return;
+    }
+
+    // ---- consumers
+    f32x16_t acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    // MFMAs over one staged tile; rows wc, wc + C, ...; two fragment sets in flight
+    auto mfma_tile = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char* dyb = smem + buf * img_bytes;
+        const unsigned char* ablk = dyb + wa * (TH * TW) * RB;
+        const unsigned char* bblk = dyb + p.A * (TH * TW) * RB + wb * (PH * PW) * RB;
+        auto load_step = [&](int ry, int k0, M::Frag& fa, M::Frag (&fb)[NTAPS]) __attribute__((always_inline)) {
+            fa = M::load(ablk, ry * TW + k0, lane);
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) fb[t] = M::load(bblk, DROW ? ry * PW + k0 + t * p.dil : (ry + t / WW) * PW + k0 + t % WW, lane);
+        };
+        auto mma_step = [&](const M::Frag& fa, const M::Frag (&fb)[NTAPS]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) acc[t] = M::mma(fa, fb[t], acc[t]);
+        };
+        M::Frag fa0, fa1, fb0[NTAPS], fb1[NTAPS];
+        if (wc < TH) load_step(wc, 0, fa0, fb0);
+        for (int ry = wc; ry < TH; ry += p.C) {
+            load_step(ry, M::kStep, fa1, fb1);
+            mma_step(fa0, fb0);
+            if (ry + p.C < TH) load_step(ry + p.C, 0, fa0, fb0);
+            mma_step(fa1, fb1);
+        }
+    };
+    __syncthreads();
+    __syncthreads();
+    {
+        int buf = 0;
+        while (pt0 < p.npt) {
+            int n2 = 0, oy2 = 0, ox2 = 0;
+            const int pt2 = pt1 < p.npt ? next_tile(pt1 + p.nsplit, n2, oy2, ox2) : p.npt;
+            mfma_tile(buf);
+            __syncthreads();
+            buf ^= 1;
+            pt0 = pt1; pt1 = pt2;
+        }
+    }
+    // ---- reduce the C pixel-row waves of each (wa, wb) pair through LDS (fixed order), then one slab per workgroup
+    for (int r = 1; r < p.C; ++r) {
+        __syncthreads();
+        float* rb = reinterpret_cast<float*>(smem) + (wb * p.A + wa) * (NTAPS * 16 * 64);
+        if (wc == r) {
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) rb[(t * 16 + i) * 64 + lane] = acc[t][i];
+        }
+        __syncthreads();
+        if (wc == 0) {
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] += rb[(t * 16 + i) * 64 + lane];
+        }
+    }
+    const int h = lane >> 5, r31 = lane & 31;
+    const int ci = ci_base + wb * 32 + r31;
+    const long long taps = (long long)p.KH * p.KW;
+    float* slab = p.slab + ((long long)split * taps) * p.Cout * p.Cin;
+    if (wc == 0 && ci < p.Cin) {
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int co = co_base + wa * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (co < p.Cout) slab[((long long)(tap0 + t) * p.Cout + co) * p.Cin + ci] = acc[t][i];
+            }
+        }
+    }
+}
+
 // sum slabs in fixed order and scatter to fp32 OIHW (real, possibly grouped, shape).
 // block = 64 consecutive packed elements (tap, co, ci) x 4 slab lanes: every slab row read is a 256-byte segment.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslab, int taps,
@@ -516,9 +789,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WredEntry
     }
 }
 
-struct WgradPlan { int A, B, C, ntaps, ngroups, nsplit, nco_tiles, nci_tiles, npt, tiles_y, tiles_x, dma, cf_off; size_t smem; long long slab_bytes; };
+struct WgradPlan { int A, B, C, ntaps, ngroups, nsplit, nco_tiles, nci_tiles, npt, tiles_y, tiles_x, dma, ws, cf_off; size_t smem; long long slab_bytes; };
 
-int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, WgradPlan* pl, bool pre = false) {
+// smooth: a prologue with a sigmoid / SiLU activation (rare: the 4-wave kernel takes it; the slab count does not depend on it)
+int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, WgradPlan* pl, bool pre = false, bool smooth = false) {
     if (KH == 1 && KW == 1) dil = 1;
     if (dil == 1) {
         if (KH == 3 && KW == 3) { pl->ntaps = 9; pl->ngroups = 1; }
@@ -544,7 +818,11 @@ int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW
     // ~one workgroup per CU; the 1- and 3-tap kernels are light on registers and stage-latency bound (a stage is two barriers around
     // a handful of MFMAs), so they get as many co-resident workgroups per CU as EGM_WGRAD_PER_CU says (default 2)
     static const int per_cu_small = getenv("EGM_WGRAD_PER_CU") ? atoi(getenv("EGM_WGRAD_PER_CU")) : 2;
-    const int per_cu = (pl->ntaps <= 3 && dtype == EGM_BF16) ? per_cu_small : 1;
+    // bf16: the wave-specialised kernel (8 waves, two image pairs, one workgroup per CU); EGM_WGRAD_WS=0 keeps the 4-wave pipelines
+    static const int ws_on = getenv("EGM_WGRAD_WS") ? atoi(getenv("EGM_WGRAD_WS")) : 1;
+    const bool ws_family = dtype == EGM_BF16 && ws_on;
+    pl->ws = (ws_family && !smooth) ? 1 : 0;
+    const int per_cu = ws_family ? 1 : ((pl->ntaps <= 3 && dtype == EGM_BF16) ? per_cu_small : 1);
     int nsplit = 256 * per_cu / blocks_per_split;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > pl->npt) nsplit = pl->npt;
@@ -557,10 +835,10 @@ int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW
     static const int dma_off = getenv("EGM_WGRAD_NO_DMA") != nullptr;
     // (measured: 9 % faster on the 2 x 2-block layers, i.e. Cin, Cout > 32; slower on the narrow and the dilated ones, which keep
     //  the register-staged pipeline)
-    pl->dma = (dtype == EGM_BF16 && !dma_off && !pre && A * B == 4 && pl->ntaps == 9 && 2 * pl->smem <= 156 * 1024) ? 1 : 0;
-    if (pl->dma) pl->smem *= 2;
+    pl->dma = (dtype == EGM_BF16 && !pl->ws && !dma_off && !pre && A * B == 4 && pl->ntaps == 9 && 2 * pl->smem <= 156 * 1024) ? 1 : 0;
+    if (pl->dma || pl->ws) pl->smem *= 2;
     pl->cf_off = (int)pl->smem;
-    if (pre) pl->smem += (size_t)(4 * 32 * A + 2 * 32 * B) * sizeof(float);     // prologue coefficient rows behind the images
+    if (pre || pl->ws) pl->smem += (size_t)(4 * 32 * A + 2 * 32 * B) * sizeof(float);     // prologue coefficient rows behind the images
     const size_t red_bytes = pl->C > 1 ? (size_t)A * B * pl->ntaps * 16 * 64 * sizeof(float) : 0;   // cross-wave reduction buffer
     if (pl->smem < red_bytes) pl->smem = red_bytes;
     pl->slab_bytes = (long long)nsplit * KH * KW * Cout * Cin * (long long)sizeof(float);
@@ -581,9 +859,27 @@ int launch_wgrad_pre(const WgradParams& p, const WgradPlan& pl, hipStream_t st) 
     EGM_CHECK_LAUNCH("conv_wgrad");
     return EGM_OK;
 }
+template <int NTAPS, bool PRE>
+int launch_wgrad_ws(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ws_kernel<NTAPS, PRE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_wgrad_ws: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    dim3 grid(pl.nsplit, pl.nco_tiles * pl.nci_tiles, pl.ngroups);
+    hipLaunchKernelGGL((conv_wgrad_ws_kernel<NTAPS, PRE>), grid, dim3(512), pl.smem, st, p);
+    EGM_CHECK_LAUNCH("conv_wgrad_ws");
+    return EGM_OK;
+}
 template <typename T, int NTAPS>
 int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
-    if (p.prex.mode != EGM_PRE_NONE || p.predy.mode != EGM_PRE_NONE) return launch_wgrad_pre<T, NTAPS, true>(p, pl, st);
+    const bool pre = p.prex.mode != EGM_PRE_NONE || p.predy.mode != EGM_PRE_NONE;
+    if constexpr (sizeof(T) == 2) {
+        if (pl.ws) return pre ? launch_wgrad_ws<NTAPS, true>(p, pl, st) : launch_wgrad_ws<NTAPS, false>(p, pl, st);
+    }
+    if (pre) return launch_wgrad_pre<T, NTAPS, true>(p, pl, st);
     return launch_wgrad_pre<T, NTAPS, false>(p, pl, st);
 }
 
@@ -659,7 +955,9 @@ extern "C" int egm_conv_wgrad_pre(int dtype, const void* x, int ldx, int xpre_mo
     if (KH == 1 && KW == 1) dil = 1;
     WgradPlan pl;
     const bool pre = xpre_mode != EGM_PRE_NONE || dypre_mode != EGM_PRE_NONE;
-    if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl, pre) != EGM_OK)
+    const bool smooth = (xpre_mode != EGM_PRE_NONE && xpre_act != EGM_ACT_RELU && xpre_act != EGM_ACT_NONE) ||
+                        (dypre_mode != EGM_PRE_NONE && dypre_act != EGM_ACT_RELU && dypre_act != EGM_ACT_NONE);
+    if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl, pre, smooth) != EGM_OK)
         EGM_FAIL(EGM_ERR_UNSUPPORTED, "conv_wgrad: unsupported kernel %dx%d dil %d", KH, KW, dil);
     EGM_REQUIRE(pl.smem <= 160 * 1024, "conv_wgrad: LDS budget exceeded");
     WgradParams p;

@@ -201,15 +201,25 @@ class EdgeEnhancedGRFB(nn.Module):
                 x = m(ops.materialize(x))
         return mods[-1](x, out=out)
 
-    def forward(self, x, out=None):
+    def cat_buffer(self, N, H, W, dtype, device):
+        """The concat destination [x | dir | edge | ctx] of this block and its four channel-slice views, or None when the channel
+        counts do not allow in-place slots.  A producer that writes the block's INPUT straight into view 0 (DoubleConv1 does) saves
+        the copy of x into the concatenation; pass the pair to forward(cat=...)."""
+        C, i2 = self.shortcut.conv.in_channels, 2 * self.inter_planes
+        if i2 % 8 or C % 8:
+            return None
+        return ops.cat_slots(N, H, W, [C, i2, i2, i2], dtype, device)
+
+    def forward(self, x, out=None, cat=None):
         x_e, x_e2, x_cat, x_sc = ops.fork(x, 4)
         xe = self.edge_enhancer(x_e, x_e2)
         xe_d, xe_e, xe_c = ops.fork(xe, 3)
         # the three branch tails write straight into their slots of the concat destination (no copy, one tensor write less each)
         N, H, W, C = x.shape
-        i2 = ops.pad8(2 * self.inter_planes)
-        if i2 == 2 * self.inter_planes and C == self.shortcut.conv.in_channels:
-            buf, (_, sd, se, sc) = ops.cat_slots(N, H, W, [C, i2, i2, i2], x.dtype, x.device)
+        if cat is None:
+            cat = self.cat_buffer(N, H, W, x.dtype, x.device) if C == self.shortcut.conv.in_channels else None
+        if cat is not None:
+            buf, (_, sd, se, sc) = cat
         else:
             buf, sd, se, sc = None, None, None, None
         d = self._seq(self.branch_dir, xe_d, sd)
@@ -412,8 +422,12 @@ class DoubleConv1(nn.Sequential):
         x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU, lazy=not self._mca)   # the MCALayer needs the tensor; a conv does not
         if self._mca:
             x = self[3](x)
-        x = ops.conv_bn_act(x, self[3 + o], self[4 + o], ACT_RELU)
-        return self[6 + o](x, out)
+        # the second conv's BatchNorm+ReLU writes the GRFB's input straight into slot 0 of the GRFB's concat buffer
+        grfb = self[6 + o]
+        N, H, W = x.shape[0], x.shape[1], x.shape[2]
+        cat = grfb.cat_buffer(N, H, W, x.dtype, x.device) if self[3 + o].out_channels == grfb.shortcut.conv.in_channels else None
+        x = ops.conv_bn_act(x, self[3 + o], self[4 + o], ACT_RELU, out=None if cat is None else cat[1][0])
+        return grfb(x, out, cat)
 
 
 class Down(nn.Sequential):
