@@ -820,7 +820,9 @@ int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW
     static const int per_cu_small = getenv("EGM_WGRAD_PER_CU") ? atoi(getenv("EGM_WGRAD_PER_CU")) : 2;
     // bf16: the wave-specialised kernel (8 waves, two image pairs, one workgroup per CU); EGM_WGRAD_WS=0 keeps the 4-wave pipelines
     static const int ws_on = getenv("EGM_WGRAD_WS") ? atoi(getenv("EGM_WGRAD_WS")) : 1;
-    const bool ws_family = dtype == EGM_BF16 && ws_on;
+    // (measured, profiles/r02_*: the 5-, 7- and 9-tap layers run 10-20 % faster wave-specialised; the 1- and 3-tap ones are
+    //  stage-latency bound and keep the 4-wave kernel with two workgroups per CU)
+    const bool ws_family = dtype == EGM_BF16 && ws_on && pl->ntaps >= 5;
     pl->ws = (ws_family && !smooth) ? 1 : 0;
     const int per_cu = ws_family ? 1 : ((pl->ntaps <= 3 && dtype == EGM_BF16) ? per_cu_small : 1);
     int nsplit = 256 * per_cu / blocks_per_split;

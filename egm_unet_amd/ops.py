@@ -307,7 +307,10 @@ def _channel_sum(t):
 
 
 # environment switch for A/B runs and for the bit-exactness test of the fused path against the materialised one
-_FUSE_BN = os.environ.get("EGM_FUSE_BN", "1") != "0"
+_FUSE_BN = os.environ.get("EGM_FUSE_BN", "0") != "0"
+# BatchNorm backward: 1 = dy computed inside the weight-gradient kernel's staging (by-product for the data gradient),
+# 0 = stand-alone egm_bn_act_bwd_apply pass
+_FUSE_BN_BWD = os.environ.get("EGM_FUSE_BN_BWD", "0") != "0"
 
 
 def fuse_bn(enabled=None):
@@ -525,12 +528,16 @@ class _ConvBN(Function):
         gx = gw = gb = dy = None
         if need_gx:
             dy = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev)
-        if need_gw:
+        if need_gw and _FUSE_BN_BWD:
             # the weight-gradient kernel computes dy from (dz, y) while staging and leaves it in `dy` for the data gradient below
             gw = _conv_wgrad(x, ldx, x_coef, x_act, gz, ldg, (act, cf4, y, ldy), dy, weight, dil, groups, Cin, Cout)
-        elif need_gx:
+        else:
+            if dy is None:
+                dy = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev)
             L.call("egm_bn_act_bwd_apply", dt, ptr(gz), ldg, ptr(y), ldy, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), act,
                    1 if training else 0, ptr(sums), ptr(dy), CoutP, npix, CoutP, st)
+            if need_gw:
+                gw = _conv_wgrad(x, ldx, x_coef, x_act, dy, CoutP, None, None, weight, dil, groups, Cin, Cout)
         if need_gx:
             gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=dev)
             L.call("egm_conv_fwd", dt, ptr(dy), CoutP, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)

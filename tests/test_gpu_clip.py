@@ -178,3 +178,25 @@ def test_ensemble_fuse_and_alpha_search_vs_torch():
         ref_m.append(float(iu.mean()))
     assert np.allclose(mious, np.array(ref_m), atol=2e-4), float(np.abs(mious - np.array(ref_m)).max())
     assert abs(best_miou - max(ref_m)) < 2e-4
+
+
+def test_ensemble_matches_reference_fixture():
+    """N2 pinned by the reference itself: tests/golden/ensemble_alpha.npz holds what /root/reference/eval_CLIPseg.py's own
+    search_best_alpha + ConfusionMatrix (:656-749) and its fusion lines (:884-910) computed on seeded logits
+    (tools/make_golden_ensemble.py): bilinear resize of the CLIPSeg logits, per-alpha global mIoU over the validation set, the best
+    alpha (first maximum), and argmax(clip + alpha * unet)."""
+    from helpers import load_fixture
+    from egm_unet_amd.ensemble import fuse_predict, search_best_alpha
+    fx = load_fixture("ensemble_alpha")
+    clips = [torch.from_numpy(c).to(DEV) for c in fx["clip"]]
+    unets = [torch.from_numpy(u).to(DEV) for u in fx["unet"]]
+    labels = [lab for lab in fx["labels"]]
+    best, best_miou, mious = search_best_alpha(clips, unets, labels, search_scale=(0.1, 10.0), search_step=100)
+    assert np.allclose(mious, fx["mious"], atol=1e-5), float(np.abs(mious - fx["mious"]).max())
+    assert abs(best - float(fx["best_alpha"])) < 1e-9, (best, float(fx["best_alpha"]))
+    for i in range(len(clips)):
+        pred, fused = fuse_predict(clips[i], unets[i], best, return_fused=True)
+        ref_fused = torch.from_numpy(fx["resized"][i]) + float(np.float32(best)) * torch.from_numpy(fx["unet"][i])
+        assert_close(fused.cpu(), ref_fused, rtol=1e-5, atol=1e-5, what="fused logits")
+        agree = float((pred.cpu()[0] == torch.from_numpy(fx["pred"][i].astype(np.int64))).float().mean())
+        assert agree > 0.9995, agree          # argmax of logits that differ in the last fp32 bit may flip on exact near-ties only

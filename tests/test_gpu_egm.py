@@ -281,25 +281,39 @@ def _blob_dataset(n, size, seed):
 
 
 def test_training_run_val_miou_matches_oracle():
-    """SURVEY 8d mIoU check (ii): train the HIP build and the CPU oracle from the same seeded init on the same synthetic batches with
-    the reference's recipe (SGD 0.9 / 1e-4, warm-up + poly LR stepped per iteration, 5-term criterion, weights [1, 2]).
-    Per-step losses must agree to 1e-3 relative (measured: 4e-5 .. 8e-5).  The held-out mIoU after training is evaluated with the
-    running BatchNorm statistics (momentum 0.01 in BasicConv: barely warmed up after 48 steps), which makes it chaotic at the level
-    of fp32 summation order: the oracle run with 128, 8 and 4 CPU threads -- the same arithmetic, another reduction order -- gives
-    93.44, 92.67 and 92.85, i.e. it differs from ITSELF by up to 0.8 points, and the HIP build lands in the same range (93.4-93.5).
-    north_star's +-0.1 bar is met where it is well defined -- the same weights evaluated by both (test_gpu_fullsize: identical
-    confusion matrix on the fp32 path, bf16 within 0.1) -- and here the bar is the reference's own spread: within 0.75 points of the
-    band spanned by two oracle runs."""
+    """SURVEY 8d mIoU check (ii): 200 training steps of the HIP build and of the CPU oracle from the same seeded init on the same
+    synthetic batches with the reference's recipe (SGD 0.9 / 1e-4, warm-up + poly LR stepped per iteration, 5-term criterion,
+    weights [1, 2]); held-out set = 64 seeded images.
+
+    What is asserted, and why in this form.  Training with this criterion is chaotic at the level of fp32 summation order (its
+    Laplace / Sobel terms are L1 norms: a gradient sign flips when a near-zero response changes sign).  Measured on the oracle
+    ALONE: the same 200 steps with 8 and with 4 CPU threads -- identical arithmetic, another reduction order -- end with weights that
+    differ by up to 5 % (relative L2 per tensor), running variances by 14 %, and held-out mIoU 97.44 vs 97.74; giving one run the
+    other's BatchNorm statistics makes it worse (98.11 / 96.50), so "copy the statistics" does not make the comparison well posed,
+    and neither does training longer.  The reference therefore does not agree with ITSELF to +-0.1 after training, and no
+    implementation can.  The well-posed statements are:
+      (a) step for step, while the trajectories still coincide, the losses agree: <= 1e-3 relative over the first 48 steps
+          (measured 4e-5 .. 8e-5);
+      (b) the TRAINED model is the same function in both implementations: the weights and running statistics the HIP build ends
+          with, evaluated on the 64 held-out images by the oracle and by the build, give mIoU within +-0.1 (fp32 path: identical
+          confusion matrix; bf16 path: within 0.1) -- north_star's bar, on a trained model;
+      (c) the build's own training result lies in the band the oracle's runs span (+-0.75, the oracle's measured self-spread)."""
     from egm_unet_amd import GRFBUNet
     from egm_unet_amd.optim import SGD
     from egm_unet_amd.train_utils import create_lr_scheduler, criterion
     from egm_unet_amd.train_utils.distributed_utils import ConfusionMatrix
     from oracle import egm_ref as R, loss_ref as L
-    size, bs, nb, epochs, lr0 = 64, 4, 6, 8, 0.02
+    size, bs, nb, epochs, lr0, ncmp = 64, 4, 8, 25, 0.02, 48
     xs, ts = _blob_dataset(bs * nb, size, 31)
-    xv, tv = _blob_dataset(16, size, 32)
+    xv, tv = _blob_dataset(64, size, 32)
     st = R.make_egm_unet_state(3, 2, 8, seed=9)
     lw = torch.tensor([1.0, 2.0])
+
+    def oracle_eval(work):
+        with torch.no_grad():
+            pred = R.egm_unet_forward(work, xv, False)["out"].argmax(1)
+        mat = L.confusion_matrix(tv.flatten(), pred.flatten(), 2)
+        return mat, float(L.confusion_metrics(mat)[2].mean()) * 100
 
     def oracle_run(threads):
         torch.set_num_threads(threads)
@@ -317,10 +331,7 @@ def test_training_run_val_miou_matches_oracle():
             losses.append(float(loss.detach()))
         for k in params:
             work[k] = params[k].detach()
-        with torch.no_grad():
-            pred = R.egm_unet_forward(work, xv, False)["out"].argmax(1)
-        mat = L.confusion_matrix(tv.flatten(), pred.flatten(), 2)
-        return losses, float(L.confusion_metrics(mat)[2].mean()) * 100
+        return losses, oracle_eval(work)[1]
 
     nthreads = torch.get_num_threads()
     try:
@@ -341,18 +352,32 @@ def test_training_run_val_miou_matches_oracle():
         opt.zero_grad(); loss.backward(); opt.step(); sched.step()
         losses.append(float(loss.detach()))
     m.eval()
-    cm = ConfusionMatrix(2)
-    with torch.no_grad():
-        cm.update_from_logits(tv.to(DEV), m(xv.to(DEV))["out"])
-    miou = float(cm.compute()[2].mean()) * 100
-    worst = max(abs(a - b) / abs(b) for a, b in zip(losses, ref_losses))
-    self_worst = max(abs(a - b) / abs(b) for a, b in zip(ref_losses_b, ref_losses))
-    print(f"val mIoU hip {miou:.3f} oracle {miou_a:.3f} / {miou_b:.3f}; loss first/last hip {losses[0]:.4f}/{losses[-1]:.4f} oracle "
-          f"{ref_losses[0]:.4f}/{ref_losses[-1]:.4f}; worst step rel hip-oracle {worst:.2e}, oracle-oracle {self_worst:.2e}")
+
+    def hip_eval():
+        cm = ConfusionMatrix(2)
+        with torch.no_grad():
+            for i in range(0, xv.shape[0], 16):
+                cm.update_from_logits(tv[i:i + 16].to(DEV), m(xv[i:i + 16].to(DEV))["out"])
+        return cm.mat.cpu(), float(cm.compute()[2].mean()) * 100
+
+    mat_hip, miou = hip_eval()
+    trained = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    mat_ref, miou_same_weights = oracle_eval(trained)                  # the reference's algorithm on the build's trained model
+    m.set_compute_dtype(torch.bfloat16)
+    _, miou_bf16 = hip_eval()
+    worst = max(abs(a - b) / abs(b) for a, b in zip(losses[:ncmp], ref_losses[:ncmp]))
+    self_worst = max(abs(a - b) / abs(b) for a, b in zip(ref_losses_b[:ncmp], ref_losses[:ncmp]))
+    print(f"val mIoU (64 images): build-trained model by build {miou:.3f} (bf16 {miou_bf16:.3f}) / by oracle {miou_same_weights:.3f}; "
+          f"oracle-trained {miou_a:.3f} / {miou_b:.3f}; loss first/last hip {losses[0]:.4f}/{losses[-1]:.4f} oracle "
+          f"{ref_losses[0]:.4f}/{ref_losses[-1]:.4f}; first {ncmp} steps worst rel hip-oracle {worst:.2e}, oracle-oracle {self_worst:.2e}")
     assert ref_losses[-1] < 0.9 * ref_losses[0], "the synthetic task must be learnable for the comparison to mean anything"
-    assert worst < 1e-3, worst
+    assert worst < 1e-3, worst                                                          # (a)
+    assert abs(miou - miou_same_weights) <= 0.1, (miou, miou_same_weights)             # (b) fp32: +-0.1 (same confusion matrix up to logit ties)
+    moved = int((mat_hip.to(torch.int64) - mat_ref.to(torch.int64)).abs().sum()) // 2   # pixels the two evaluations classify differently
+    assert moved <= 1e-4 * int(mat_ref.sum()), (mat_hip, mat_ref)
+    assert abs(miou_bf16 - miou_same_weights) <= 0.1, (miou_bf16, miou_same_weights)   # (b) bf16
     lo, hi = min(miou_a, miou_b), max(miou_a, miou_b)
-    assert lo - 0.75 <= miou <= hi + 0.75, (miou, miou_a, miou_b)
+    assert lo - 0.75 <= miou <= hi + 0.75, (miou, miou_a, miou_b)                      # (c)
 
 
 def test_train_one_epoch_graph_replay_equals_eager_loop(monkeypatch):

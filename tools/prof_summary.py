@@ -36,7 +36,7 @@ def main():
     out = [f"# rocprofv3 kernel-trace summary ({path.split('/')[-1]}; {steps} steps in trace)", "",
            f"total kernel time {tot / steps / 1e6:.3f} ms/step over {len(rows) / steps:.0f} launches/step", "",
            "| kernel | launches/step | avg us | ms/step | % |", "|---|---|---|---|---|"]
-    for k, v in sorted(per_k.items(), key=lambda kv: -kv[1][1])[:40]:
+    for k, v in sorted(per_k.items(), key=lambda kv: -kv[1][1])[:int(__import__('os').environ.get('PROF_TOP', 40))]:
         out.append(f"| {k} | {v[0] / steps:.1f} | {v[1] / v[0] / 1e3:.1f} | {v[1] / steps / 1e6:.3f} | {100 * v[1] / tot:.1f} |")
     out += ["", "## heaviest (kernel, grid-in-workgroups) shapes", "", "| kernel | grid | launches/step | avg us | ms/step |", "|---|---|---|---|---|"]
     for (k, g), v in sorted(per_s.items(), key=lambda kv: -kv[1][1])[:40]:
