@@ -82,7 +82,7 @@ __global__ void scale_add_relu_fwd_kernel(const T* __restrict__ a, int lda, floa
         float u[8], v[8];
         load8(a + p * lda + cv * 8, u); load8(b + p * ldb + cv * 8, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) u[j] = fmaxf(alpha * u[j] + v[j], 0.f);
+        for (int j = 0; j < 8; ++j) u[j] = fmaxf(fmaf(alpha, u[j], v[j]), 0.f);
         store8(out + p * ldo + cv * 8, u);
     }
 }

@@ -65,8 +65,8 @@ class EdgeAwareFeatureEnhancer(nn.Module):
         """x_alias: a second autograd alias of x supplied by the caller (so the caller can sum all of x's gradients in one pass)."""
         xa, xb = (x, x_alias) if x_alias is not None else ops.fork(x, 2)
         e = ops.highpass3(xa)                                                   # x - avgpool3(x)
-        w = ops.conv_bn_act(e, self.weight_generator[0], self.weight_generator[1], ACT_SIGMOID)
-        return ops.gate_mul(xb, w)                                              # w*x + x
+        # x * (1 + sigmoid(BN(conv1x1(e)))): the BatchNorm apply and the gate are one pass (csrc/bn_fused.hip)
+        return ops.conv_bn_ew(e, self.weight_generator[0], self.weight_generator[1], ACT_SIGMOID, xb, ops.EW_GATE)
 
 
 class BasicConv(nn.Module):
@@ -227,7 +227,9 @@ class EdgeEnhancedGRFB(nn.Module):
         c = self._seq(self.branch_ctx, xe_c, sc)
         cat = ops.cat_channels([x_cat, d, e, c], buf)
         out_f = self.fusion_conv(cat)
-        out_f = ops.scale_add_relu(out_f, self.scale, self.shortcut(x_sc))      # relu(out*scale + short)
+        # relu(out*scale + BN(conv1x1(x))): the shortcut's BatchNorm apply and the residual ReLU are one pass (csrc/bn_fused.hip)
+        sc = self.shortcut
+        out_f = ops.conv_bn_ew(x_sc, sc.conv, sc.bn, ACT_NONE, out_f, ops.EW_SAR, alpha=self.scale)
         o_a, o_b = ops.fork(out_f, 2)
         t = ops.conv2d(o_a, self.target_enhancer[0].weight, self.target_enhancer[0].bias)
         return ops.gate3(o_b, t, out)                                           # out*(1 + mean_c sigmoid(t))

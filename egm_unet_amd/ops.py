@@ -602,6 +602,105 @@ class _BnAct(Function):
         return gy, None, ggamma, gbeta, None, None, None, None, None, None, None
 
 
+EW_GATE, EW_SAR = 0, 1                     # enum egm_ew_mode
+_FUSE_BN_EW = os.environ.get("EGM_FUSE_BN_EW", "1") != "0"
+
+
+def fuse_bn_ew(enabled=None):
+    """Get / set whether BatchNorm + the element-wise op behind it run as the fused kernels of csrc/bn_fused.hip."""
+    global _FUSE_BN_EW
+    if enabled is not None:
+        _FUSE_BN_EW = bool(enabled)
+    return _FUSE_BN_EW
+
+
+class _ConvBNEw(Function):
+    """conv -> BatchNorm(+act) -> element-wise consumer as ONE autograd node (csrc/bn_fused.hip):
+         EW_GATE  out = p*(1 + sigmoid(BN(conv(e))))       EdgeAwareFeatureEnhancer   (src/EGM-UNet.py:872-886)
+         EW_SAR   out = relu(alpha*p + BN(conv(x_sc)))     EdgeEnhancedGRFB tail      (:1315-1317)
+    The BatchNorm output z and its gradient dz never exist in memory: forward reads (y, p) and writes out; backward computes the
+    BatchNorm partial sums from (g, p|out, y), then dy and dp in one pass, then the conv's weight and data gradients."""
+
+    @staticmethod
+    def forward(ctx, x, p, weight, bias, gamma, beta, running_mean, running_var, eps, momentum, act, training, mode, alpha, out_slot):
+        x, ldx = _nhwc(x)
+        p, ldp = _nhwc(p)
+        Cout, Cin_g = weight.shape[0], weight.shape[1]
+        y, stats, wd = _conv_forward(x, ldx, None, ACT_NONE, weight, bias, 1, 1, training)
+        CoutP, npix, dev = y.shape[3], _npix(y), y.device
+        if tuple(p.shape) != tuple(y.shape):
+            raise RuntimeError(f"conv_bn_ew: element-wise operand {tuple(p.shape)} does not match the conv output {tuple(y.shape)}")
+        L, dt, st = lib(), dtype_code(y.dtype), stream()
+        coef = _f32((4, CoutP), dev)
+        if training:
+            L.call("egm_bn_finalize", ptr(stats), stats.shape[0], npix, ptr(gamma.detach()), ptr(beta.detach()), eps, momentum,
+                   ptr(running_mean), ptr(running_var), ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), CoutP, Cout, st)
+        else:
+            L.call("egm_bn_eval_coeffs", ptr(gamma.detach()), ptr(beta.detach()), ptr(running_mean), ptr(running_var), eps,
+                   ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), CoutP, Cout, st)
+        out, ldo = _slot_or_new(out_slot, tuple(y.shape), y.dtype, dev)
+        L.call("egm_bn_ew_fwd", dt, mode, ptr(y), CoutP, ptr(coef[0]), ptr(coef[1]), act, ptr(p), ldp, float(alpha), ptr(out), ldo, npix,
+               CoutP, st)
+        if ctx.needs_input_grad[2]:
+            _note_conv_use(weight)
+        # GATE needs p for its backward, SAR the output (ReLU mask)
+        ctx.save_for_backward(x, weight, wd, y, coef, p if mode == EW_GATE else out)
+        ctx.meta = (bias is not None, Cin_g, Cout, act, training, mode, float(alpha))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, wd, y, coef, q = ctx.saved_tensors
+        has_bias, Cin, Cout, act, training, mode, alpha = ctx.meta
+        g, ldg = _nhwc(g)
+        x, ldx = _nhwc(x)
+        q, ldq = _nhwc(q)
+        N, H, W, CinP = x.shape
+        CoutP, npix, dev = y.shape[3], _npix(y), y.device
+        KH, KW = weight.shape[2], weight.shape[3]
+        L, dt, st = lib(), dtype_code(x.dtype), stream()
+        nb = L.query("egm_channel_partials_blocks", npix, CoutP)
+        part = _f32(nb * 2 * CoutP, dev)
+        L.call("egm_bn_ew_bwd_reduce", dt, mode, ptr(g), ldg, ptr(q), ldq, ptr(y), CoutP, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]),
+               ptr(coef[3]), act, alpha, ptr(part), npix, CoutP, st)
+        sums, cf4 = _f32((2, CoutP), dev), _f32((4, CoutP), dev)
+        L.call("egm_bn_bwd_coefs", ptr(part), nb, npix, ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), 1 if training else 0,
+               ptr(sums), ptr(cf4), CoutP, st)
+        dy = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev)
+        dp = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev)
+        L.call("egm_bn_ew_bwd_apply", dt, mode, ptr(g), ldg, ptr(q), ldq, ptr(y), CoutP, ptr(cf4), act, alpha, ptr(dy), CoutP, ptr(dp),
+               CoutP, npix, CoutP, st)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=dev)
+            L.call("egm_conv_fwd", dt, ptr(dy), CoutP, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, 1, st)
+        if ctx.needs_input_grad[2]:
+            gw = _conv_wgrad(x, ldx, None, ACT_NONE, dy, CoutP, None, None, weight, 1, 1, Cin, Cout)
+        if has_bias and ctx.needs_input_grad[3]:
+            gb = _f32(Cout, dev, zero=True)             # a conv bias feeding a BatchNorm has an identically zero gradient
+        ggamma = sums[1, :Cout] if ctx.needs_input_grad[4] else None
+        gbeta = sums[0, :Cout] if ctx.needs_input_grad[5] else None
+        return gx, dp if ctx.needs_input_grad[1] else None, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None, None
+
+
+def conv_bn_ew(x, conv, bn, act, p, mode, alpha=1.0, out=None):
+    """F(p, act(BN(conv(x)))) with F = EW_GATE: p*(1+z) or EW_SAR: relu(alpha*p + z); 1x1 convs (the two users in EdgeEnhancedGRFB)."""
+    if conv.weight.shape[2] != 1 or conv.weight.shape[3] != 1 or conv.groups != 1:
+        raise RuntimeError("conv_bn_ew: 1x1 ungrouped convolutions only")
+    if not _FUSE_BN_EW:
+        z = conv_bn_act(x, conv, bn, act)
+        if mode == EW_GATE:
+            return gate_mul(p, z) if out is None else materialize(gate_mul(p, z), out)
+        r = scale_add_relu(p, alpha, z)
+        return r if out is None else materialize(r, out)
+    if bn.training and bn.num_batches_tracked is not None and not getattr(bn, "_egm_counter_managed", False):
+        bn.num_batches_tracked.add_(1)
+    training = bn.training or bn.running_mean is None
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _ConvBNEw.apply(materialize(x), materialize(p), conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                           momentum, act, training, mode, alpha, None if out is None else [out])
+
+
 def _slot_or_new(out_slot, shape, dtype, device):
     """Output placement: `out_slot` is None or a one-element list holding a kernel-addressable NHWC view (a channel slice of a wider
     buffer, e.g. of a concat destination) the result is written into -- the concat copy and its extra tensor write disappear.  The

@@ -156,6 +156,23 @@ int egm_bn_bwd_coefs(const float* partials, int ntiles, long long count, const f
                      const float* save_mean, const float* save_rstd, int train, float* sums_2xC, float* cf_4xC, int C,
                      egm_stream_t s);
 
+/* BatchNorm(+act) fused with the element-wise op behind it (z and dz never reach memory; same rounding points as the unfused
+ * chain, so results agree bit for bit):
+ *   EGM_EW_GATE  out = p*(1 + z)          EdgeAwareFeatureEnhancer, src/EGM-UNet.py:884-886 (z = sigmoid(BN(y)))
+ *   EGM_EW_SAR   out = relu(alpha*p + z)  EdgeEnhancedGRFB residual tail, :1315-1317 (z = BN(y) of the shortcut, p = fusion output)
+ * fwd: reads y, p, writes out.  bwd_reduce: partial tiles [egm_channel_partials_blocks][2][C] of the BatchNorm backward sums, from
+ * g (= dL/dout), q (GATE: p; SAR: out, for the ReLU mask) and y.  bwd_apply (cf from egm_bn_bwd_coefs): writes dy (gradient of the
+ * BatchNorm input) and dp. */
+enum egm_ew_mode { EGM_EW_GATE = 0, EGM_EW_SAR = 1 };
+int egm_bn_ew_fwd(int dtype, int mode, const void* y, int ldy, const float* scale, const float* shift, int act, const void* p,
+                  int ldp, float alpha, void* out, int ldo, long long npix, int C, egm_stream_t s);
+int egm_bn_ew_bwd_reduce(int dtype, int mode, const void* g, int ldg, const void* q, int ldq, const void* y, int ldy,
+                         const float* scale, const float* shift, const float* save_mean, const float* save_rstd, int act,
+                         float alpha, float* partials, long long npix, int C, egm_stream_t s);
+int egm_bn_ew_bwd_apply(int dtype, int mode, const void* g, int ldg, const void* q, int ldq, const void* y, int ldy,
+                        const float* cf_4xC, int act, float alpha, void* dy, int lddy, void* dp, int lddp, long long npix, int C,
+                        egm_stream_t s);
+
 /* ---- pooling / resampling --------------------------------------------------------------------- */
 /* nn.MaxPool2d(2,2) (src/EGM-UNet.py:908); H, W are the INPUT sizes (even). */
 int egm_maxpool2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, egm_stream_t s);

@@ -154,6 +154,7 @@ class _Chain(nn.Module):
 def _run_chain_hip(m, x_nchw, dtype, fuse):
     from egm_unet_amd import ops
     from egm_unet_amd._lib import ACT_NONE, ACT_RELU
+    default = ops.fuse_bn()
     ops.fuse_bn(fuse)
     try:
         for p in m.parameters():
@@ -171,7 +172,7 @@ def _run_chain_hip(m, x_nchw, dtype, fuse):
         stats = {n: b.clone() for n, b in m.named_buffers() if "running" in n}
         return out.detach().clone(), x.grad.clone(), grads, stats
     finally:
-        ops.fuse_bn(True)
+        ops.fuse_bn(default)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -214,10 +215,14 @@ def test_chain_fused_equals_materialised_and_torch(dtype):
             close(st_f[n], b, n)
 
 
+@pytest.mark.parametrize("which", ["prologue", "elementwise"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_model_fused_equals_materialised(dtype):
-    """EGM-UNet train step: logits, loss and all 333 parameter gradients identical with and without the Lazy/prologue path."""
+def test_model_fused_equals_materialised(dtype, which):
+    """EGM-UNet train step: logits, loss and all 333 parameter gradients identical with and without (a) the Lazy / operand-prologue
+    path and (b) the BatchNorm + element-wise fusions of csrc/bn_fused.hip (EdgeAwareFeatureEnhancer gate, GRFB residual tail)."""
     from egm_unet_amd import GRFBUNet, ops
+    toggle = ops.fuse_bn if which == "prologue" else ops.fuse_bn_ew
+    default = toggle()
     from egm_unet_amd.train_utils import criterion
     torch.manual_seed(11)
     m = GRFBUNet(3, 2, base_c=16).to(DEV).train()
@@ -230,7 +235,7 @@ def test_model_fused_equals_materialised(dtype):
     lw = torch.tensor([1.0, 2.0], device=DEV)
     res = []
     for fuse in (True, False):
-        ops.fuse_bn(fuse)
+        toggle(fuse)
         try:
             m.load_state_dict(state0)
             for p in m.parameters():
@@ -242,7 +247,7 @@ def test_model_fused_equals_materialised(dtype):
             res.append((out.detach().clone(), loss.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters()},
                         {n: b.clone() for n, b in m.named_buffers()}))
         finally:
-            ops.fuse_bn(True)
+            toggle(default)
     (o1, l1, g1, b1), (o2, l2, g2, b2) = res
     assert torch.equal(o1, o2) and torch.equal(l1, l2)
     bad = [n for n in g1 if not torch.equal(g1[n], g2[n])]
