@@ -32,11 +32,45 @@ __device__ __forceinline__ void ew_bwd(float g, float q, float z, float alpha, f
     else { const float gm = q > 0.f ? g : 0.f; dz = gm; dp = alpha * gm; }           // q = out (mask)
 }
 
+// Streaming kernels: when C/8 divides 256 a thread keeps the same 8 channels for its whole grid-stride loop, so the per-channel
+// coefficients are staged once per block through LDS (every thread of every block reading the same few global lines serialises on one
+// L2 channel) and then live in registers; the loop body is 16-byte loads / stores with two pixels in flight.
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_ew_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, int act, const T* __restrict__ p, int ldp,
                                                         float alpha, T* __restrict__ out, int ldo, long long npix, int C) {
     const int ncv = C >> 3;
+    if (256 % ncv == 0) {
+        __shared__ float cfl[2 * 2048];
+        for (int c = threadIdx.x; c < C; c += 256) { cfl[c] = scale[c]; cfl[C + c] = shift[c]; }
+        __syncthreads();
+        const int cv = threadIdx.x % ncv, ppb = 256 / ncv;
+        float sc[8], sh[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = cfl[cv * 8 + j]; sh[j] = cfl[C + cv * 8 + j]; }
+        const long long stride = (long long)gridDim.x * ppb;
+        long long px = (long long)blockIdx.x * ppb + threadIdx.x / ncv;
+        for (; px + stride < npix; px += 2 * stride) {
+            float y0[8], p0[8], y1[8], p1[8];
+            load8(y + px * ldy + cv * 8, y0); load8(p + px * ldp + cv * 8, p0);
+            load8(y + (px + stride) * ldy + cv * 8, y1); load8(p + (px + stride) * ldp + cv * 8, p1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                p0[j] = ew_fwd<T, MODE>(p0[j], rnd<T>(bn_fwd_elem(y0[j], sc[j], sh[j], act)), alpha);
+                p1[j] = ew_fwd<T, MODE>(p1[j], rnd<T>(bn_fwd_elem(y1[j], sc[j], sh[j], act)), alpha);
+            }
+            store8(out + px * ldo + cv * 8, p0);
+            store8(out + (px + stride) * ldo + cv * 8, p1);
+        }
+        if (px < npix) {
+            float y0[8], p0[8];
+            load8(y + px * ldy + cv * 8, y0); load8(p + px * ldp + cv * 8, p0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p0[j] = ew_fwd<T, MODE>(p0[j], rnd<T>(bn_fwd_elem(y0[j], sc[j], sh[j], act)), alpha);
+            store8(out + px * ldo + cv * 8, p0);
+        }
+        return;
+    }
     const long long total = npix * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long px = i / ncv; const int cv = (int)(i - px * ncv);
@@ -64,8 +98,11 @@ __global__ __launch_bounds__(256) void bn_ew_bwd_reduce_kernel(const T* __restri
     const int tid = threadIdx.x, cv = tid % ncv, row = tid / ncv;
     float s[8], t[8], sc[8], sh[8], mu[8], rs[8];
     zero8(s); zero8(t);
+    for (int c = tid; c < C; c += 256) { red[c] = scale[c]; red[C + c] = shift[c]; red[2 * C + c] = mean[c]; red[3 * C + c] = rstd[c]; }
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const int c = cv * 8 + j; sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; rs[j] = rstd[c]; }
+    for (int j = 0; j < 8; ++j) { const int c = cv * 8 + j; sc[j] = red[c]; sh[j] = red[C + c]; mu[j] = red[2 * C + c]; rs[j] = red[3 * C + c]; }
+    __syncthreads();                                           // red[] is reused for the reduction below
     if (row < rows) {
         for (long long px = (long long)blockIdx.x * rows + row; px < npix; px += (long long)gridDim.x * rows) {
             float gv[8], qv[8], yv[8];
@@ -93,27 +130,61 @@ __global__ __launch_bounds__(256) void bn_ew_bwd_reduce_kernel(const T* __restri
 }
 
 template <typename T, int MODE>
+__device__ __forceinline__ void ew_apply8(const float (&gv)[8], const float (&qv)[8], const float (&yv)[8], const float (&sc)[8],
+                                          const float (&sh)[8], const float (&cb)[8], const float (&cc)[8], int act, float alpha,
+                                          float (&o1)[8], float (&o2)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float z = MODE == EGM_EW_GATE ? rnd<T>(bn_fwd_elem(yv[j], sc[j], sh[j], act)) : 0.f;
+        float dz;
+        ew_bwd<T, MODE>(gv[j], qv[j], z, alpha, dz, o2[j]);
+        o1[j] = bn_bwd_elem(dz, yv[j], sc[j], sh[j], cb[j], cc[j], act);
+    }
+}
+
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_ew_bwd_apply_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ q, int ldq,
                                                               const T* __restrict__ y, int ldy, const float* __restrict__ cf, int act,
                                                               float alpha, T* __restrict__ dy, int lddy, T* __restrict__ dp, int lddp,
                                                               long long npix, int C) {
     const int ncv = C >> 3;
+    if (256 % ncv == 0) {
+        __shared__ float cfl[4 * 2048];
+        for (int c = threadIdx.x; c < 4 * C; c += 256) cfl[c] = cf[c];
+        __syncthreads();
+        const int cv = threadIdx.x % ncv, ppb = 256 / ncv;
+        float sc[8], sh[8], cb[8], cc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int c = cv * 8 + j; sc[j] = cfl[c]; sh[j] = cfl[C + c]; cb[j] = cfl[2 * C + c]; cc[j] = cfl[3 * C + c]; }
+        const long long stride = (long long)gridDim.x * ppb;
+        long long px = (long long)blockIdx.x * ppb + threadIdx.x / ncv;
+        for (; px + stride < npix; px += 2 * stride) {
+            float g0[8], q0[8], y0[8], g1[8], q1[8], y1[8], a0[8], b0[8], a1[8], b1[8];
+            load8(g + px * ldg + cv * 8, g0); load8(q + px * ldq + cv * 8, q0); load8(y + px * ldy + cv * 8, y0);
+            load8(g + (px + stride) * ldg + cv * 8, g1); load8(q + (px + stride) * ldq + cv * 8, q1); load8(y + (px + stride) * ldy + cv * 8, y1);
+            ew_apply8<T, MODE>(g0, q0, y0, sc, sh, cb, cc, act, alpha, a0, b0);
+            ew_apply8<T, MODE>(g1, q1, y1, sc, sh, cb, cc, act, alpha, a1, b1);
+            store8(dy + px * lddy + cv * 8, a0); store8(dp + px * lddp + cv * 8, b0);
+            store8(dy + (px + stride) * lddy + cv * 8, a1); store8(dp + (px + stride) * lddp + cv * 8, b1);
+        }
+        if (px < npix) {
+            float g0[8], q0[8], y0[8], a0[8], b0[8];
+            load8(g + px * ldg + cv * 8, g0); load8(q + px * ldq + cv * 8, q0); load8(y + px * ldy + cv * 8, y0);
+            ew_apply8<T, MODE>(g0, q0, y0, sc, sh, cb, cc, act, alpha, a0, b0);
+            store8(dy + px * lddy + cv * 8, a0); store8(dp + px * lddp + cv * 8, b0);
+        }
+        return;
+    }
     const long long total = npix * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long px = i / ncv; const int cv = (int)(i - px * ncv);
-        float gv[8], qv[8], yv[8], o1[8], o2[8];
+        float gv[8], qv[8], yv[8], o1[8], o2[8], sc[8], sh[8], cb[8], cc[8];
         load8(g + px * ldg + cv * 8, gv);
         load8(q + px * ldq + cv * 8, qv);
         load8(y + px * ldy + cv * 8, yv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = cv * 8 + j;
-            const float sc = cf[c], sh = cf[C + c];
-            const float z = MODE == EGM_EW_GATE ? rnd<T>(bn_fwd_elem(yv[j], sc, sh, act)) : 0.f;
-            float dz;
-            ew_bwd<T, MODE>(gv[j], qv[j], z, alpha, dz, o2[j]);
-            o1[j] = bn_bwd_elem(dz, yv[j], sc, sh, cf[2 * C + c], cf[3 * C + c], act);
-        }
+        for (int j = 0; j < 8; ++j) { const int c = cv * 8 + j; sc[j] = cf[c]; sh[j] = cf[C + c]; cb[j] = cf[2 * C + c]; cc[j] = cf[3 * C + c]; }
+        ew_apply8<T, MODE>(gv, qv, yv, sc, sh, cb, cc, act, alpha, o1, o2);
         store8(dy + px * lddy + cv * 8, o1);
         store8(dp + px * lddp + cv * 8, o2);
     }
@@ -146,7 +217,7 @@ inline int partial_blocks(long long npix, int C) {
 extern "C" int egm_bn_ew_fwd(int dtype, int mode, const void* y, int ldy, const float* scale, const float* shift, int act, const void* p,
                              int ldp, float alpha, void* out, int ldo, long long npix, int C, egm_stream_t s) {
     EGM_REQ_VEC("bn_ew_fwd", y, ldy, C); EGM_REQ_VEC("bn_ew_fwd", p, ldp, C); EGM_REQ_VEC("bn_ew_fwd", out, ldo, C);
-    EGM_REQUIRE(scale && shift && npix > 0, "bn_ew_fwd: bad args");
+    EGM_REQUIRE(scale && shift && npix > 0 && C <= 2048, "bn_ew_fwd: bad args (C <= 2048)");
     EGM_EW_DISPATCH(mode, hipLaunchKernelGGL((bn_ew_fwd_kernel<T, MODE>), dim3(stream_grid(npix * (C >> 3))), dim3(256), 0, (hipStream_t)s,
                                              (const T*)y, ldy, scale, shift, act, (const T*)p, ldp, alpha, (T*)out, ldo, npix, C));
     EGM_CHECK_LAUNCH("bn_ew_fwd");
@@ -157,7 +228,7 @@ extern "C" int egm_bn_ew_bwd_reduce(int dtype, int mode, const void* g, int ldg,
                                     const float* scale, const float* shift, const float* save_mean, const float* save_rstd, int act,
                                     float alpha, float* partials, long long npix, int C, egm_stream_t s) {
     EGM_REQ_VEC("bn_ew_bwd_reduce", g, ldg, C); EGM_REQ_VEC("bn_ew_bwd_reduce", q, ldq, C); EGM_REQ_VEC("bn_ew_bwd_reduce", y, ldy, C);
-    EGM_REQUIRE(scale && shift && save_mean && save_rstd && partials && npix > 0 && C <= 2048, "bn_ew_bwd_reduce: bad args");
+    EGM_REQUIRE(scale && shift && save_mean && save_rstd && partials && npix > 0 && C <= 1024, "bn_ew_bwd_reduce: bad args (C <= 1024)");
     const int nb = partial_blocks(npix, C);
     EGM_EW_DISPATCH(mode, hipLaunchKernelGGL((bn_ew_bwd_reduce_kernel<T, MODE>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const T*)g, ldg,
                                              (const T*)q, ldq, (const T*)y, ldy, scale, shift, save_mean, save_rstd, act, alpha, npix, C,
@@ -171,7 +242,7 @@ extern "C" int egm_bn_ew_bwd_apply(int dtype, int mode, const void* g, int ldg, 
                                    int C, egm_stream_t s) {
     EGM_REQ_VEC("bn_ew_bwd_apply", g, ldg, C); EGM_REQ_VEC("bn_ew_bwd_apply", q, ldq, C); EGM_REQ_VEC("bn_ew_bwd_apply", y, ldy, C);
     EGM_REQ_VEC("bn_ew_bwd_apply", dy, lddy, C); EGM_REQ_VEC("bn_ew_bwd_apply", dp, lddp, C);
-    EGM_REQUIRE(cf_4xC && npix > 0, "bn_ew_bwd_apply: bad args");
+    EGM_REQUIRE(cf_4xC && npix > 0 && C <= 2048, "bn_ew_bwd_apply: bad args (C <= 2048)");
     EGM_EW_DISPATCH(mode, hipLaunchKernelGGL((bn_ew_bwd_apply_kernel<T, MODE>), dim3(stream_grid(npix * (C >> 3))), dim3(256), 0,
                                              (hipStream_t)s, (const T*)g, ldg, (const T*)q, ldq, (const T*)y, ldy, cf_4xC, act, alpha,
                                              (T*)dy, lddy, (T*)dp, lddp, npix, C));

@@ -111,13 +111,18 @@ class table_namespace:
 
 class DeviceTable:
     """Packed C structs on the device.  Re-uploaded only when the bytes change; the upload is an async copy from a pinned
-    staging buffer, so it is legal inside hipGraph capture (replays re-copy the same bytes).  One set of buffers per table namespace."""
+    staging buffer, so it is legal inside hipGraph capture (replays re-copy the same bytes).  One set of buffers per table namespace.
+
+    Inside a capture a table may be needed with SEVERAL contents (the data-parallel step flushes the deferred weight gradients once
+    per captured backward half): a replay re-reads the pinned bytes at replay time, so each distinct content gets a buffer pair of its
+    own from a small pool reserved before the capture (pinned allocation is not legal while capturing)."""
+    POOL = 4
 
     def __init__(self):
-        self.slots = {}                      # tag -> [key, pinned, device, upload event]
+        self.slots = {}                      # tag -> [key, pinned, device, upload event, spare pairs, {blob: device} of this capture]
 
     def _slot(self):
-        return self.slots.setdefault(_table_tag[0], [None, None, None, None])
+        return self.slots.setdefault(_table_tag[0], [None, None, None, None, [], {}])
 
     def reserve(self, device, n=65536):
         """Allocate the staging buffers now (pinned allocation is not legal inside a hipGraph capture)."""
@@ -127,12 +132,29 @@ class DeviceTable:
             sl[1] = torch.empty(cap, dtype=torch.uint8).pin_memory()
             sl[2] = torch.empty(cap, dtype=torch.uint8, device=device)
             sl[0] = sl[3] = None
+            sl[4] = [(torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=device))
+                     for _ in range(self.POOL - 1)] if _table_tag[0] is not None else []
+            sl[5] = {}
 
     def get(self, blob: bytes, device):
         sl = self._slot()
         if blob == sl[0]:
             return sl[2]
         n = len(blob)
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            # inside a capture the primary pair is never rewritten (it may serve a content captured earlier): every further content
+            # takes a spare pair, whose pinned bytes are written once, here
+            hit = sl[5].get(blob)
+            if hit is not None:
+                return hit
+            if not sl[4] or sl[4][0][0].numel() < n:
+                raise RuntimeError("egm_unet_amd: table pool exhausted inside a hipGraph capture (DeviceTable.POOL)")
+            pinned, dev_buf = sl[4].pop(0)
+            pinned[:n] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+            dev_buf[:n].copy_(pinned[:n], non_blocking=True)
+            sl[5][blob] = dev_buf
+            sl.append((pinned, dev_buf))                       # the pair lives as long as the namespace
+            return dev_buf
         self.reserve(device, n)
         upload_pinned(sl, 1, 2, 3, torch.frombuffer(bytearray(blob), dtype=torch.uint8), n)
         sl[0] = blob
