@@ -23,6 +23,7 @@
 #include "common.h"
 #include "prologue.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -520,10 +521,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(WgradParams p) {
         const bool dy_bwd = PRE && p.predy.mode == EGM_PRE_BN_BWD, x_act = PRE && p.prex.mode != EGM_PRE_NONE;
         const int v4 = ptid & 3;                                        // the thread's vector inside a 32-channel row (same for all its slots)
         // slot geometry -> (inside the tensor?, pixel offset from the tile's / patch's first pixel, channel offset inside the block set)
+        // The slot arithmetic must stay INSIDE the tile loop: hoisted out of it, its ~27 per-slot invariants do not fit the register
+        // budget, and a scratch reload issued behind a burst of global loads waits for the whole burst (vmcnt retires in order) --
+        // measured 1000 clk per slot.  `opaque()` hides the thread index from the loop-invariant code motion, once per call.
+        auto opaque = [](int v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
+        int tix = ptid;                                                 // re-made opaque at the top of issue_tile / write_tile
         auto dy_geom = [&](int k, int oy_, int ox_, int& rel, int& cl) __attribute__((always_inline)) {
-            const int i = ptid + k * 256, pix = (i >> 2) & (TH * TW - 1), blk = i >> 10;    // TH*TW*VPR = 1024
+            const int i = tix + k * 256, pix = (i >> 2) & (TH * TW - 1), blk = i >> 10;     // TH*TW*VPR = 1024
             const int py = pix >> 5, px = pix & 31;
-            cl = blk * 32 + v4 * 8;
+            cl = blk * 32 + (tix & 3) * 8;
             rel = py * p.W + px;
             return i < ndy && oy_ + py < p.H && ox_ + px < p.W && co_base + cl < p.Cout;
         };
@@ -538,12 +544,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(WgradParams p) {
         }
         auto x_geom = [&](int k, int iy0, int ix0, int& rel, int& cl) __attribute__((always_inline)) {
             const int pk = xpk[k], blk = pk >> 20, py = (pk >> 10) & 1023, px = pk & 1023;
-            cl = blk * 32 + v4 * 8;
+            cl = blk * 32 + (tix & 3) * 8;
             rel = py * p.W + px;
             const int iy = iy0 + py, ix = ix0 + px;
             return pk >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         };
         auto issue_tile = [&](int n, int oy_, int ox_) __attribute__((always_inline)) {
+            tix = opaque(ptid);
             const long long o_dy = (long long)(n * p.H + oy_) * p.W + ox_;                // first pixel of the dy tile (inside the image)
             const long long o_x = (long long)(n * p.H + oy_ + offy) * p.W + ox_ + offx;   // first pixel of the x patch (may be outside)
             const bf16_t* dbase = dyg + o_dy * p.lddy + co_base;
@@ -565,45 +572,81 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(WgradParams p) {
                 if (ok) rx[k] = *reinterpret_cast<const uint4*>(xbase + rel * p.ldx + cl);
             }
         };
-        // transform + LDS write of the tile held in registers (tile coordinates n, oy_, ox_) into image pair `buf`
+        // transform + LDS write of the tile held in registers (tile coordinates n, oy_, ox_) into image pair `buf`.
+        // The per-channel coefficients of a slot depend on (32-channel block, v4) only: dy slots 4b .. 4b+3 share block b, so one
+        // coefficient set is read per block (eight 16-byte LDS reads) and kept in registers for its four slots; ONE uniform branch on
+        // the activation surrounds each slot loop (a switch inside would triple the loop and miss the instruction cache).
+        auto load_cf = [&](PreCoef8& kf, const float* cf, int cs, int rows) __attribute__((always_inline)) {
+            const float4* c4 = reinterpret_cast<const float4*>(cf);              // cf is 32-byte aligned: cl is a multiple of 8
+            const int s4 = cs >> 2;
+            float* dst[4] = {kf.sc, kf.sh, kf.cb, kf.cc};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r < rows) {
+                    const float4 lo = c4[r * s4], hi = c4[r * s4 + 1];
+                    dst[r][0] = lo.x; dst[r][1] = lo.y; dst[r][2] = lo.z; dst[r][3] = lo.w;
+                    dst[r][4] = hi.x; dst[r][5] = hi.y; dst[r][6] = hi.z; dst[r][7] = hi.w;
+                }
+            }
+        };
         auto write_tile = [&](int buf, int n, int oy_, int ox_) __attribute__((always_inline)) {
+            tix = opaque(ptid);
             unsigned char* dyb = smem + buf * img_bytes;
             unsigned char* xb = dyb + p.A * (TH * TW) * RB;
             bf16_t* obase = dy_writer ? og + ((long long)(n * p.H + oy_) * p.W + ox_) * p.ld_dy_out + co_base : nullptr;
+            if (PRE && dy_bwd) {
+                auto dy_pass = [&](auto act_tag) __attribute__((always_inline)) {
+                    constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-            for (int k = 0; k < DYVEC; ++k) {
-                const int i = ptid + k * 256;
-                if (i < ndy) {
-                    uint4 v = rdy[k];
-                    if (PRE && p.predy.mode != EGM_PRE_NONE) {
-                        int rel, cl;
-                        const bool ok = dy_geom(k, oy_, ox_, rel, cl);
-                        // (activations: ReLU or none -- the host entry routes the smooth ones to the 4-wave kernel; three variants
-                        //  of every slot's code would not fit the instruction cache)
-                        if (p.predy.act == EGM_ACT_RELU) v = pre_apply_rt<EGM_ACT_RELU>(bf16_t(), v, rya[k], cf_dy + cl, cs_dy, p.predy.mode, 0);
-                        else v = pre_apply_rt<EGM_ACT_NONE>(bf16_t(), v, rya[k], cf_dy + cl, cs_dy, p.predy.mode, 0);
-                        if (!ok) v = make_uint4(0, 0, 0, 0);
-                        else if (dy_writer) *reinterpret_cast<uint4*>(obase + rel * p.ld_dy_out + cl) = v;
+                    for (int b = 0; b < (DROW ? 1 : 2); ++b) {
+                        if (b < p.A) {
+                            PreCoef8 kf;
+                            load_cf(kf, cf_dy + b * 32 + (tix & 3) * 8, cs_dy, 4);
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk) {
+                                const int k = b * 4 + kk;
+                                int rel, cl;
+                                const bool ok = dy_geom(k, oy_, ox_, rel, cl);
+                                uint4 v = pre_apply8<EGM_PRE_BN_BWD, ACT>(rdy[k], rya[k], kf, 0);
+                                if (!ok) v = make_uint4(0, 0, 0, 0);
+                                else if (dy_writer) *reinterpret_cast<uint4*>(obase + rel * p.ld_dy_out + cl) = v;
+                                *reinterpret_cast<uint4*>(dyb + (tix + k * 256) * 16) = v;
+                            }
+                        }
                     }
-                    *reinterpret_cast<uint4*>(dyb + i * 16) = v;
-                }
-                if (PRE) __builtin_amdgcn_sched_barrier(0);              // one vector at a time: interleaving the slots only costs registers
+                };
+                if (p.predy.act == EGM_ACT_RELU) dy_pass(std::integral_constant<int, EGM_ACT_RELU>());
+                else dy_pass(std::integral_constant<int, EGM_ACT_NONE>());
+            } else {
+#pragma unroll
+                for (int k = 0; k < DYVEC; ++k)
+                    if (tix + k * 256 < ndy) *reinterpret_cast<uint4*>(dyb + (tix + k * 256) * 16) = rdy[k];
             }
+            if (PRE && x_act) {
+                auto x_pass = [&](auto act_tag) __attribute__((always_inline)) {
+                    constexpr int ACT = decltype(act_tag)::value;
+                    PreCoef8 kf;
+                    int cur_blk = -1;
 #pragma unroll
-            for (int k = 0; k < XVEC; ++k) {
-                const int i = ptid + k * 256;
-                if (i < nx) {
-                    uint4 v = rx[k];
-                    if (x_act) {
-                        int rel, cl;
-                        const bool ok = x_geom(k, oy_ + offy, ox_ + offx, rel, cl);
-                        if (p.prex.act == EGM_ACT_RELU) v = pre_apply_rt<EGM_ACT_RELU>(bf16_t(), v, v, cf_x + cl, cs_x, EGM_PRE_BN_ACT, 0);
-                        else v = pre_apply_rt<EGM_ACT_NONE>(bf16_t(), v, v, cf_x + cl, cs_x, EGM_PRE_BN_ACT, 0);
-                        if (!ok) v = make_uint4(0, 0, 0, 0);
+                    for (int k = 0; k < XVEC; ++k) {
+                        const int i = tix + k * 256;
+                        if (i < nx) {
+                            int rel, cl;
+                            const bool ok = x_geom(k, oy_ + offy, ox_ + offx, rel, cl);
+                            const int blk = cl >> 5;
+                            if (blk != cur_blk) { load_cf(kf, cf_x + cl, cs_x, 2); cur_blk = blk; }   // changes at most once per thread (B <= 2)
+                            uint4 v = pre_apply8<EGM_PRE_BN_ACT, ACT>(rx[k], rx[k], kf, 0);
+                            if (!ok) v = make_uint4(0, 0, 0, 0);
+                            *reinterpret_cast<uint4*>(xb + i * 16) = v;
+                        }
                     }
-                    *reinterpret_cast<uint4*>(xb + i * 16) = v;
-                }
-                if (PRE) __builtin_amdgcn_sched_barrier(0);
+                };
+                if (p.prex.act == EGM_ACT_RELU) x_pass(std::integral_constant<int, EGM_ACT_RELU>());
+                else x_pass(std::integral_constant<int, EGM_ACT_NONE>());
+            } else {
+#pragma unroll
+                for (int k = 0; k < XVEC; ++k)
+                    if (tix + k * 256 < nx) *reinterpret_cast<uint4*>(xb + (tix + k * 256) * 16) = rx[k];
             }
         };
         // Producers run one tile ahead in LDS and two ahead in registers.
@@ -822,7 +865,8 @@ int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW
     static const int ws_on = getenv("EGM_WGRAD_WS") ? atoi(getenv("EGM_WGRAD_WS")) : 1;
     // (measured, profiles/r02_*: the 5-, 7- and 9-tap layers run 10-20 % faster wave-specialised; the 1- and 3-tap ones are
     //  stage-latency bound and keep the 4-wave kernel with two workgroups per CU)
-    const bool ws_family = dtype == EGM_BF16 && ws_on && pl->ntaps >= 5;
+    // ... unless they carry operand prologues: the element-wise work belongs on producer waves, beside the MFMAs
+    const bool ws_family = dtype == EGM_BF16 && ws_on && (pl->ntaps >= 5 || pre);
     pl->ws = (ws_family && !smooth) ? 1 : 0;
     const int per_cu = ws_family ? 1 : ((pl->ntaps <= 3 && dtype == EGM_BF16) ? per_cu_small : 1);
     int nsplit = 256 * per_cu / blocks_per_split;
@@ -914,9 +958,12 @@ extern "C" long long egm_conv_wgrad_workspace(int N, int H, int W, int Cin, int 
 }
 
 extern "C" int egm_conv_wgrad_slabs(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil) {
+    return egm_conv_wgrad_slabs_pre(dtype, 0, N, H, W, Cin, Cout, KH, KW, dil);
+}
+extern "C" int egm_conv_wgrad_slabs_pre(int dtype, int pre, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil) {
     WgradPlan pl;
     if (KH == 1 && KW == 1) dil = 1;
-    if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl) != EGM_OK) return -1;
+    if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl, pre != 0) != EGM_OK) return -1;
     return pl.nsplit;
 }
 /* table: device array of {const float* slab; float* dw; int nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate;} (48 bytes) */
@@ -957,8 +1004,10 @@ extern "C" int egm_conv_wgrad_pre(int dtype, const void* x, int ldx, int xpre_mo
     if (KH == 1 && KW == 1) dil = 1;
     WgradPlan pl;
     const bool pre = xpre_mode != EGM_PRE_NONE || dypre_mode != EGM_PRE_NONE;
+    // the wave-specialised kernel builds: x = BN_ACT, dy = BN_BWD, activations ReLU / none; anything else takes the 4-wave kernel
     const bool smooth = (xpre_mode != EGM_PRE_NONE && xpre_act != EGM_ACT_RELU && xpre_act != EGM_ACT_NONE) ||
-                        (dypre_mode != EGM_PRE_NONE && dypre_act != EGM_ACT_RELU && dypre_act != EGM_ACT_NONE);
+                        (dypre_mode != EGM_PRE_NONE && dypre_act != EGM_ACT_RELU && dypre_act != EGM_ACT_NONE) ||
+                        dypre_mode == EGM_PRE_BN_ACT;
     if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl, pre, smooth) != EGM_OK)
         EGM_FAIL(EGM_ERR_UNSUPPORTED, "conv_wgrad: unsupported kernel %dx%d dil %d", KH, KW, dil);
     EGM_REQUIRE(pl.smem <= 160 * 1024, "conv_wgrad: LDS budget exceeded");

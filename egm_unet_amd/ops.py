@@ -438,7 +438,7 @@ def _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, dy_pre, dy_out, weight, dil, gro
            ptr(dy_out), CoutP if dy_out is not None else 0, None if defer else ptr(gw), ptr(ws), N, H, W, CinP, CoutP, Cin, Cout,
            KH, KW, dil, groups, 0, st)
     if defer:
-        nslab = L.query("egm_conv_wgrad_slabs", dt, N, H, W, CinP, CoutP, KH, KW, dil)
+        nslab = L.query("egm_conv_wgrad_slabs_pre", dt, 1 if (xm != PRE_NONE or dm != PRE_NONE) else 0, N, H, W, CinP, CoutP, KH, KW, dil)
         if not _pending_wgrad:
             Variable._execution_engine.queue_callback(_flush_wgrads)
         _pending_wgrad.append((ws, weight, nslab, KH * KW, CoutP, CinP, Cout, Cin, groups, weakref.ref(gw), gw.data_ptr()))

@@ -89,6 +89,8 @@ long long egm_conv_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int K
 int egm_conv_wgrad(int dtype, const void* x, int ldx, const void* dy, int lddy, float* dw_oihw_f32, void* workspace,
                    int N, int H, int W, int Cin, int Cout, int CinR, int CoutR, int KH, int KW, int dil, int groups,
                    int accumulate, egm_stream_t s);
+/* slab count of a call with (pre != 0) or without operand prologues (the two may be planned differently) */
+int egm_conv_wgrad_slabs_pre(int dtype, int pre, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
 /* egm_conv_wgrad with logical operands: x = act(bn(y_prev)) (EGM_PRE_BN_ACT on x, the conv's input as the forward saw it) and/or
  * dy = BatchNorm backward of (dz, y) (EGM_PRE_BN_BWD on dy).  dy_out (may be NULL): the logical dy [N,H,W,Cout] is also written
  * there, once, as a by-product of the staging, for the data-gradient call that follows (this replaces egm_bn_act_bwd_apply).

@@ -131,7 +131,12 @@ def test_wgrad_prologue_equals_materialised(case, dtype, actname):
     torch.cuda.synchronize()
     assert torch.equal(dy_out, dy), "dy by-product differs from egm_bn_act_bwd_apply"
     assert torch.isfinite(gw_a).all()
-    assert torch.equal(gw_a, gw_b), f"fused weight gradient differs: max {(gw_a - gw_b).abs().max():.3e} of {gw_a.abs().max():.3e}"
+    if dtype == torch.bfloat16 and k in (1, 3) and (k == 1 or dil > 1):
+        # 1- and 3-tap bf16 layers: with prologues the wave-specialised kernel runs (one workgroup per CU), without them the 4-wave
+        # kernel (two per CU): another split count, i.e. another fp32 summation order of the same products
+        assert float((gw_a - gw_b).abs().max()) <= 2e-6 * float(gw_a.abs().max()), (float((gw_a - gw_b).abs().max()), float(gw_a.abs().max()))
+    else:
+        assert torch.equal(gw_a, gw_b), f"fused weight gradient differs: max {(gw_a - gw_b).abs().max():.3e} of {gw_a.abs().max():.3e}"
 
 
 class _Chain(nn.Module):
@@ -187,10 +192,14 @@ def test_chain_fused_equals_materialised_and_torch(dtype):
     out_f, gx_f, g_f, st_f = _run_chain_hip(m, x.to(DEV), dtype, True)
     m.load_state_dict(state0)
     out_m, gx_m, g_m, st_m = _run_chain_hip(m, x.to(DEV), dtype, False)
-    # fused == materialised, bit for bit (outputs, input gradient, every parameter gradient, running statistics)
+    # fused == materialised, bit for bit (outputs, input gradient, running statistics); parameter gradients: bit for bit in fp32,
+    # to fp32 summation order in bf16 (the 1x1 / dilated weight gradients run with another split count when they carry prologues)
     assert torch.equal(out_f, out_m) and torch.equal(gx_f, gx_m)
     for n in g_f:
-        assert torch.equal(g_f[n], g_m[n]), n
+        if dtype == torch.float32:
+            assert torch.equal(g_f[n], g_m[n]), n
+        else:
+            assert float((g_f[n] - g_m[n]).abs().max()) <= 2e-6 * float(g_m[n].abs().max()) + 1e-12, n
     for n in st_f:
         assert torch.equal(st_f[n], st_m[n]), n
     # and both == PyTorch's own modules and autograd (fp32 CPU)
@@ -250,7 +259,9 @@ def test_model_fused_equals_materialised(dtype, which):
             toggle(default)
     (o1, l1, g1, b1), (o2, l2, g2, b2) = res
     assert torch.equal(o1, o2) and torch.equal(l1, l2)
-    bad = [n for n in g1 if not torch.equal(g1[n], g2[n])]
+    same = (lambda a, b: torch.equal(a, b)) if (dtype == torch.float32 or which == "elementwise") else \
+        (lambda a, b: float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-12)      # bf16 prologue path: see the chain test
+    bad = [n for n in g1 if not same(g1[n], g2[n])]
     assert not bad, f"{len(bad)} gradients differ between the fused and the materialised path, e.g. {bad[:5]}"
     bad = [n for n in b1 if not torch.equal(b1[n], b2[n])]
     assert not bad, f"buffers differ: {bad[:5]}"
