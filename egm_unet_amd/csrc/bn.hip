@@ -11,11 +11,13 @@ constexpr int kMaxPartialBlocks = 1024;
 
 // block = 256 threads = (256 / ncv) pixel rows x ncv channel-vectors; out[blk][2][C]
 // MODE 0: (x, x^2).  MODE 1 (BN backward): (dzp, dzp*xhat) with dzp = dz*act'(y*scale+shift), xhat = (y-mean)*rstd.
+// (bid, nb) = this block's index among the nb blocks working on the tensor: blockIdx / gridDim for the single-tensor kernels, a
+// slice of the grid for the multi-tensor ones (several BatchNorms of independent branches in one launch)
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void channel_partials_kernel(const T* __restrict__ a, int lda, const T* __restrict__ y, int ldy,
-                                                               const float* __restrict__ scale, const float* __restrict__ shift,
-                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                               int act, long long npix, int C, float* __restrict__ out) {
+__device__ __forceinline__ void channel_partials_body(const T* __restrict__ a, int lda, const T* __restrict__ y, int ldy,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      int act, long long npix, int C, float* __restrict__ out, int bid, int nb) {
     __shared__ float red[2 * 256 * 8];
     const int ncv = C >> 3, rows = 256 / ncv;
     const int tid = threadIdx.x, cv = tid % ncv, row = tid / ncv;
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(256) void channel_partials_kernel(const T* __restri
         __syncthreads();                                       // red[] is reused for the reduction below
     }
     if (row < rows) {
-        for (long long p = (long long)blockIdx.x * rows + row; p < npix; p += (long long)gridDim.x * rows) {
+        for (long long p = (long long)bid * rows + row; p < npix; p += (long long)nb * rows) {
             float v[8];
             load8(a + p * lda + cv * 8, v);
             if (MODE == 0) {
@@ -57,8 +59,15 @@ __global__ __launch_bounds__(256) void channel_partials_kernel(const T* __restri
         const int which = t / C, c = t - which * C, ccv = c >> 3, j = c & 7;
         float v = 0.f;
         for (int r = 0; r < rows; ++r) v += red[(which * 256 + r * ncv + ccv) * 8 + j];
-        out[((long long)blockIdx.x * 2 + which) * C + c] = v;
+        out[((long long)bid * 2 + which) * C + c] = v;
     }
+}
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void channel_partials_kernel(const T* __restrict__ a, int lda, const T* __restrict__ y, int ldy,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               int act, long long npix, int C, float* __restrict__ out) {
+    channel_partials_body<T, MODE>(a, lda, y, ldy, scale, shift, mean, rstd, act, npix, C, out, blockIdx.x, gridDim.x);
 }
 
 // sums [ntiles][2][C] -> out [2][C] in double, fixed order.  grid = C/8 blocks of 1024 threads (8 channels x 128 tile lanes).
@@ -92,16 +101,16 @@ __global__ __launch_bounds__(1024) void reduce_tiles_kernel(const float* __restr
     if (threadIdx.x < 8 && c < C) { out[c] = (float)s; out[C + c] = (float)q; }
 }
 
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ st, int ntiles, double count,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                           float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
-                                                           float* __restrict__ scale, float* __restrict__ shift,
-                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd, int C,
-                                                           int Creal) {
+__device__ __forceinline__ void bn_finalize_body(const float* __restrict__ st, int ntiles, double count,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                 float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                 float* __restrict__ scale, float* __restrict__ shift,
+                                                 float* __restrict__ save_mean, float* __restrict__ save_rstd, int C,
+                                                 int Creal, int bid) {
     __shared__ double red[2048];
     double s, q;
-    tiles_reduce(st, ntiles, C, blockIdx.x * 8, s, q, red);
-    const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+    tiles_reduce(st, ntiles, C, bid * 8, s, q, red);
+    const int c = bid * 8 + (threadIdx.x & 7);
     if (threadIdx.x < 8 && c >= Creal && c < C) { scale[c] = 0.f; shift[c] = 0.f; save_mean[c] = 0.f; save_rstd[c] = 0.f; }
     if (threadIdx.x < 8 && c < Creal) {
         const double mean = s / count;
@@ -120,18 +129,26 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         }
     }
 }
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ st, int ntiles, double count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                           float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                           float* __restrict__ scale, float* __restrict__ shift,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd, int C,
+                                                           int Creal) {
+    bn_finalize_body(st, ntiles, count, gamma, beta, eps, momentum, rmean, rvar, scale, shift, save_mean, save_rstd, C, Creal, blockIdx.x);
+}
 
 // BatchNorm backward, second stage: partial tiles [ntiles][2][C] of (sum dzp, sum dzp*xhat) -> sums [2][C] (= dbeta | dgamma) and the
 // coefficient rows cf [4][C] = scale | shift | cb | cc of EGM_PRE_BN_BWD (prologue.h), so that neither a reduce_tiles launch nor a
 // stand-alone apply pass is needed: the data-gradient and weight-gradient kernels of the conv in front compute dy while staging.
-__global__ __launch_bounds__(1024) void bn_bwd_coefs_kernel(const float* __restrict__ st, int ntiles, float inv_count,
-                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            const float* __restrict__ mean, const float* __restrict__ rstd, int train,
-                                                            float* __restrict__ sums, float* __restrict__ cf, int C) {
+__device__ __forceinline__ void bn_bwd_coefs_body(const float* __restrict__ st, int ntiles, float inv_count,
+                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                  const float* __restrict__ mean, const float* __restrict__ rstd, int train,
+                                                  float* __restrict__ sums, float* __restrict__ cf, int C, int bid) {
     __shared__ double red[2048];
     double s, q;
-    tiles_reduce(st, ntiles, C, blockIdx.x * 8, s, q, red);
-    const int c = blockIdx.x * 8 + (threadIdx.x & 7);
+    tiles_reduce(st, ntiles, C, bid * 8, s, q, red);
+    const int c = bid * 8 + (threadIdx.x & 7);
     if (threadIdx.x < 8 && c < C) {
         const float s0 = (float)s, s1 = (float)q;
         sums[c] = s0; sums[C + c] = s1;
@@ -144,6 +161,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_coefs_kernel(const float* __restr
         }
         cf[c] = scv; cf[C + c] = shift[c]; cf[2 * C + c] = cbv; cf[3 * C + c] = ccv;
     }
+}
+__global__ __launch_bounds__(1024) void bn_bwd_coefs_kernel(const float* __restrict__ st, int ntiles, float inv_count,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd, int train,
+                                                            float* __restrict__ sums, float* __restrict__ cf, int C) {
+    bn_bwd_coefs_body(st, ntiles, inv_count, scale, shift, mean, rstd, train, sums, cf, C, blockIdx.x);
 }
 
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -161,9 +184,9 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 // Streaming kernels below: when C/8 divides 256 a thread keeps the same 8 channels for its whole grid-stride loop, so the
 // per-channel coefficients are loaded once into registers and the loop body is pure 16-byte loads/stores.
 template <typename T>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, int act, T* __restrict__ z, int ldz,
-                                                         long long npix, int C) {
+__device__ __forceinline__ void bn_act_fwd_body(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                const float* __restrict__ shift, int act, T* __restrict__ z, int ldz,
+                                                long long npix, int C, int bid, int nb) {
     const int ncv = C >> 3;
     if (256 % ncv == 0) {
         // per-channel coefficients: staged once per block through LDS (every thread of every block reading the same few
@@ -175,8 +198,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
         float sc[8], sh[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { sc[j] = cf[cv * 8 + j]; sh[j] = cf[C + cv * 8 + j]; }
-        const long long stride = (long long)gridDim.x * ppb;
-        long long p = (long long)blockIdx.x * ppb + threadIdx.x / ncv;
+        const long long stride = (long long)nb * ppb;
+        long long p = (long long)bid * ppb + threadIdx.x / ncv;
         for (; p + stride < npix; p += 2 * stride) {              // two independent vectors in flight
             float v[8], u[8];
             load8(y + p * ldy + cv * 8, v);
@@ -196,7 +219,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
         return;
     }
     const long long total = npix * ncv;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    for (long long i = bid * 256LL + threadIdx.x; i < total; i += (long long)nb * 256) {
         const long long p = i / ncv; const int cv = (int)(i - p * ncv);
         float v[8];
         load8(y + p * ldy + cv * 8, v);
@@ -205,15 +228,21 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
         store8(z + p * ldz + cv * 8, v);
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int act, T* __restrict__ z, int ldz,
+                                                         long long npix, int C) {
+    bn_act_fwd_body<T>(y, ldy, scale, shift, act, z, ldz, npix, C, blockIdx.x, gridDim.x);
+}
 
 // dy = scale * (dzp - mean(dzp) - xhat * mean(dzp*xhat))   (train)   |   dy = scale * dzp   (eval)
 //    = ca*dzp + cb + cc*y   with per-channel ca = scale, cb = -scale*(m0 - mean*rstd*m1), cc = -scale*rstd*m1   (train)
 template <typename T>
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
-                                                               const float* __restrict__ scale, const float* __restrict__ shift,
-                                                               const float* __restrict__ mean, const float* __restrict__ rstd, int act,
-                                                               int train, const float* __restrict__ sums, float inv_count,
-                                                               T* __restrict__ dy, int lddy, long long npix, int C) {
+__device__ __forceinline__ void bn_act_bwd_apply_body(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd, int act,
+                                                      int train, const float* __restrict__ sums, float inv_count,
+                                                      T* __restrict__ dy, int lddy, long long npix, int C, int bid, int nb) {
     const int ncv = C >> 3;
     if (256 % ncv == 0) {
         __shared__ float cf[4 * 2048];                     // scale | shift | cb | cc, computed once per block
@@ -235,8 +264,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
             const int c = cv * 8 + j;
             sc[j] = cf[c]; sh[j] = cf[C + c]; cb[j] = cf[2 * C + c]; cc[j] = cf[3 * C + c];
         }
-        const long long stride = (long long)gridDim.x * ppb;
-        long long p = (long long)blockIdx.x * ppb + threadIdx.x / ncv;
+        const long long stride = (long long)nb * ppb;
+        long long p = (long long)bid * ppb + threadIdx.x / ncv;
         for (; p + stride < npix; p += 2 * stride) {              // two independent vector pairs in flight
             float g[8], yv[8], g2[8], y2[8];
             load8(dz + p * lddz + cv * 8, g);
@@ -262,7 +291,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
         return;
     }
     const long long total = npix * ncv;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    for (long long i = bid * 256LL + threadIdx.x; i < total; i += (long long)nb * 256) {
         const long long p = i / ncv; const int cv = (int)(i - p * ncv);
         float g[8], yv[8], o[8];
         load8(dz + p * lddz + cv * 8, g);
@@ -281,6 +310,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
         store8(dy + p * lddy + cv * 8, o);
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ y, int ldy,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd, int act,
+                                                               int train, const float* __restrict__ sums, float inv_count,
+                                                               T* __restrict__ dy, int lddy, long long npix, int C) {
+    bn_act_bwd_apply_body<T>(dz, lddz, y, ldy, scale, shift, mean, rstd, act, train, sums, inv_count, dy, lddy, npix, C, blockIdx.x, gridDim.x);
+}
 
 inline int stream_grid(long long total_threads) {
     long long b = (total_threads + 255) / 256;
@@ -295,6 +332,67 @@ inline int partial_blocks(long long npix, int C) {
     if (b > kMaxPartialBlocks) b = kMaxPartialBlocks;
     if (b < 1) b = 1;
     return (int)b;
+}
+
+// ---- multi-tensor forms: the BatchNorm passes of up to EGM_BN_MULTI_MAX INDEPENDENT layers (the parallel branches of
+// EdgeEnhancedGRFB, src/EGM-UNet.py:1256-1278: 8-32 channel tensors whose passes are launch-latency bound) in ONE launch each.
+// The descriptors travel by value as a kernel argument; a block finds its tensor by the cumulative block counts (blk0).
+struct BnMulti { egm_bn_desc e[EGM_BN_MULTI_MAX]; int blk0[EGM_BN_MULTI_MAX + 1]; int n; };
+
+__device__ __forceinline__ int multi_entry(const BnMulti& m, int& bid, int& nb) {
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < EGM_BN_MULTI_MAX; ++i) if (i < m.n && (int)blockIdx.x >= m.blk0[i]) k = i;
+    bid = blockIdx.x - m.blk0[k]; nb = m.blk0[k + 1] - m.blk0[k];
+    return k;
+}
+__global__ __launch_bounds__(1024) void bn_finalize_multi_kernel(BnMulti m) {
+    int bid, nb; const egm_bn_desc& d = m.e[multi_entry(m, bid, nb)];
+    bn_finalize_body(d.stats, d.ntiles, (double)d.npix, d.gamma, d.beta, d.eps, d.momentum, d.running_mean, d.running_var, d.coef,
+                     d.coef + d.C, d.coef + 2 * d.C, d.coef + 3 * d.C, d.C, d.C_real, bid);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_multi_kernel(BnMulti m) {
+    int bid, nb; const egm_bn_desc& d = m.e[multi_entry(m, bid, nb)];
+    bn_act_fwd_body<T>((const T*)d.y, d.ldy, d.coef, d.coef + d.C, d.act, (T*)d.z, d.ldz, d.npix, d.C, bid, nb);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_multi_kernel(BnMulti m) {
+    int bid, nb; const egm_bn_desc& d = m.e[multi_entry(m, bid, nb)];
+    channel_partials_body<T, 1>((const T*)d.dz, d.lddz, (const T*)d.y, d.ldy, d.coef, d.coef + d.C, d.coef + 2 * d.C, d.coef + 3 * d.C, d.act,
+                                d.npix, d.C, d.partials, bid, nb);
+}
+__global__ __launch_bounds__(1024) void bn_bwd_coefs_multi_kernel(BnMulti m) {
+    int bid, nb; const egm_bn_desc& d = m.e[multi_entry(m, bid, nb)];
+    bn_bwd_coefs_body(d.partials, d.nblocks, 1.f / (float)d.npix, d.coef, d.coef + d.C, d.coef + 2 * d.C, d.coef + 3 * d.C, d.train, d.sums,
+                      d.cf4, d.C, bid);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BnMulti m) {
+    int bid, nb; const egm_bn_desc& d = m.e[multi_entry(m, bid, nb)];
+    bn_act_bwd_apply_body<T>((const T*)d.dz, d.lddz, (const T*)d.y, d.ldy, d.coef, d.coef + d.C, d.coef + 2 * d.C, d.coef + 3 * d.C, d.act,
+                             d.train, d.sums, 1.f / (float)d.npix, (T*)d.dy, d.lddy, d.npix, d.C, bid, nb);
+}
+
+// which: 0 finalize, 1 fwd apply, 2 bwd reduce, 3 bwd coefs, 4 bwd apply -> blocks a tensor gets (the single-tensor launch geometry)
+int multi_blocks(const egm_bn_desc& d, int which) {
+    switch (which) {
+        case 0: case 3: return (d.C + 7) / 8;
+        case 2: return partial_blocks(d.npix, d.C);
+        default: return stream_grid(d.npix * (d.C >> 3));
+    }
+}
+int multi_build(const egm_bn_desc* descs, int n, int which, BnMulti* m) {
+    if (!descs || n < 1 || n > EGM_BN_MULTI_MAX) return -1;
+    m->n = n; m->blk0[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const egm_bn_desc& d = descs[i];
+        if (d.C <= 0 || d.C % 8 || d.C > 1024 || d.npix <= 0 || !d.coef) return -1;
+        m->e[i] = d;
+        m->blk0[i + 1] = m->blk0[i] + multi_blocks(d, which);
+    }
+    for (int i = n; i < EGM_BN_MULTI_MAX; ++i) m->blk0[i + 1] = m->blk0[n];
+    return m->blk0[n];
 }
 
 }  // namespace
@@ -401,5 +499,33 @@ extern "C" int egm_bn_act_bwd_apply(int dtype, const void* dz, int lddz, const v
                                                  lddz, (const T*)y, ldy, scale, shift, save_mean, save_rstd, act, train, sums,
                                                  1.f / (float)npix, (T*)dy, lddy, npix, C));
     EGM_CHECK_LAUNCH("bn_act_bwd_apply");
+    return EGM_OK;
+}
+
+// ---- multi-tensor entry points (descs: HOST array of n <= EGM_BN_MULTI_MAX descriptors, copied into the kernel argument) ----------
+extern "C" int egm_bn_multi(int dtype, int which, const egm_bn_desc* descs, int n, egm_stream_t s) {
+    BnMulti m;
+    const int grid = multi_build(descs, n, which, &m);
+    EGM_REQUIRE(grid > 0, "bn_multi: bad descriptors (n=%d, 1..%d tensors, C %% 8 == 0, C <= 1024)", n, EGM_BN_MULTI_MAX);
+    for (int i = 0; i < n; ++i) {
+        const egm_bn_desc& d = descs[i];
+        switch (which) {
+            case EGM_BN_MULTI_FINALIZE: EGM_REQUIRE(d.stats && d.ntiles > 0 && d.C_real > 0 && d.C_real <= d.C, "bn_multi finalize: bad entry %d", i); break;
+            case EGM_BN_MULTI_FWD: EGM_REQUIRE(d.y && d.z && egm_aligned16(d.y) && egm_aligned16(d.z) && d.ldy >= d.C && d.ldz >= d.C, "bn_multi fwd: bad entry %d", i); break;
+            case EGM_BN_MULTI_BWD_REDUCE: EGM_REQUIRE(d.dz && d.y && d.partials && egm_aligned16(d.dz) && d.lddz >= d.C && d.ldy >= d.C, "bn_multi bwd reduce: bad entry %d", i); break;
+            case EGM_BN_MULTI_BWD_COEFS: EGM_REQUIRE(d.partials && d.nblocks > 0 && d.sums && d.cf4, "bn_multi bwd coefs: bad entry %d", i); break;
+            case EGM_BN_MULTI_BWD_APPLY: EGM_REQUIRE(d.dz && d.y && d.dy && d.sums && egm_aligned16(d.dy) && d.lddy >= d.C, "bn_multi bwd apply: bad entry %d", i); break;
+            default: EGM_FAIL(EGM_ERR_ARG, "bn_multi: unknown pass %d", which);
+        }
+    }
+    hipStream_t st = (hipStream_t)s;
+    switch (which) {
+        case EGM_BN_MULTI_FINALIZE: hipLaunchKernelGGL(bn_finalize_multi_kernel, dim3(grid), dim3(1024), 0, st, m); break;
+        case EGM_BN_MULTI_BWD_COEFS: hipLaunchKernelGGL(bn_bwd_coefs_multi_kernel, dim3(grid), dim3(1024), 0, st, m); break;
+        case EGM_BN_MULTI_FWD: EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_fwd_multi_kernel<T>), dim3(grid), dim3(256), 0, st, m)); break;
+        case EGM_BN_MULTI_BWD_REDUCE: EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_reduce_multi_kernel<T>), dim3(grid), dim3(256), 0, st, m)); break;
+        case EGM_BN_MULTI_BWD_APPLY: EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_bwd_apply_multi_kernel<T>), dim3(grid), dim3(256), 0, st, m)); break;
+    }
+    EGM_CHECK_LAUNCH("bn_multi");
     return EGM_OK;
 }

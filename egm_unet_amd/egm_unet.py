@@ -222,9 +222,22 @@ class EdgeEnhancedGRFB(nn.Module):
             buf, (_, sd, se, sc) = cat
         else:
             buf, sd, se, sc = None, None, None, None
-        d = self._seq(self.branch_dir, xe_d, sd)
-        e = self._seq(self.branch_edge, xe_e, se)
-        c = self._seq(self.branch_ctx, xe_c, sc)
+        if ops.fuse_bn():
+            d = self._seq(self.branch_dir, xe_d, sd)                  # operand-prologue path: one branch after the other
+            e = self._seq(self.branch_edge, xe_e, se)
+            c = self._seq(self.branch_ctx, xe_c, sc)
+        else:
+            # The three branches are independent and work on 8-32 channel tensors whose BatchNorm passes are launch-latency bound:
+            # they advance in lockstep, and layers of equal depth share their BatchNorm launches (ops.multi_conv_bn_act).
+            bd, be, bc = self.branch_dir, self.branch_edge, self.branch_ctx
+
+            def item(m, t, o=None):
+                return (t, m.conv, m.bn, ACT_RELU if m.relu is not None else ACT_NONE, m._dil, m._groups, o)
+            d, e, c = ops.multi_conv_bn_act([item(bd[0], xe_d), item(be[0], xe_e), item(bc[0], xe_c)])     # heads: 1x1, 1x1, 3x3
+            e = be[1](e)                                                                                  # EdgeAwareFeatureEnhancer(i)
+            e, c = ops.multi_conv_bn_act([item(be[2], e), item(bc[1], c)])                                # grouped 3x3
+            d, e, c = ops.multi_conv_bn_act([item(bd[1], d), item(be[3], e), item(bc[2], c)])             # dilated 3x3 (12 / 24 / 36)
+            d, e, c = ops.multi_conv_bn_act([item(bd[2], d, sd), item(be[4], e, se), item(bc[3], c, sc)])  # 1x1 tails -> concat slots
         cat = ops.cat_channels([x_cat, d, e, c], buf)
         out_f = self.fusion_conv(cat)
         # relu(out*scale + BN(conv1x1(x))): the shortcut's BatchNorm apply and the residual ReLU are one pass (csrc/bn_fused.hip)

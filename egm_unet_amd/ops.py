@@ -624,6 +624,134 @@ class _BnAct(Function):
         return gy, None, ggamma, gbeta, None, None, None, None, None, None, None
 
 
+# ----------------------------------------------------------------------------------------------------------
+# several independent conv -> BatchNorm(+act) layers as one autograd node with multi-tensor BatchNorm passes
+# ----------------------------------------------------------------------------------------------------------
+BN_MULTI_MAX = 4
+_BN_FINALIZE, _BN_FWD, _BN_BWD_REDUCE, _BN_BWD_COEFS, _BN_BWD_APPLY = range(5)    # enum egm_bn_multi_pass
+_FUSE_BN_MULTI = os.environ.get("EGM_BN_MULTI", "1") != "0"
+
+
+def _bn_desc(y=None, z=None, dz=None, dy=None, coef=None, stats=None, gamma=None, beta=None, rm=None, rv=None, partials=None, sums=None,
+             cf4=None, npix=0, ldy=0, ldz=0, lddz=0, lddy=0, ntiles=0, nblocks=0, C=0, C_real=0, act=0, train=0, eps=0.0, momentum=0.0):
+    """one packed egm_bn_desc (include/egm_hip.h)"""
+    dp = lambda t: 0 if t is None else t.data_ptr()
+    return struct.pack("<13Qq10i2f", dp(y), dp(z), dp(dz), dp(dy), dp(coef), dp(stats), dp(gamma), dp(beta), dp(rm), dp(rv), dp(partials),
+                       dp(sums), dp(cf4), npix, ldy, ldz, lddz, lddy, ntiles, nblocks, C, C_real, act, train, eps, momentum)
+
+
+class _MultiConvBN(Function):
+    """K <= 4 INDEPENDENT conv -> BatchNorm -> activation layers (the parallel branches of EdgeEnhancedGRFB at equal depth) as one
+    autograd node: the K convolutions are launched back to back, then ONE finalize launch and ONE apply launch serve all K BatchNorms;
+    backward: ONE partial-sum launch, ONE coefficient launch, ONE apply launch, then the K data and weight gradients.  Every tensor
+    goes through exactly the arithmetic of conv_bn_act (same kernels' bodies, same block decomposition), so results are bit-identical
+    to K separate nodes; what disappears is 2 x (K - 1) forward and 3 x (K - 1) backward launches of 5 us each on tensors whose
+    passes take about as long as a launch."""
+
+    @staticmethod
+    def forward(ctx, meta, *flat):
+        K = len(meta)
+        L, st = lib(), stream()
+        saved, descs_fin, descs_fwd, outs, keep = [], b"", b"", [], []
+        ctx.meta = []
+        for k, mk in enumerate(meta):
+            x, weight, bias, gamma, beta = flat[5 * k:5 * k + 5]
+            rm, rv, eps, momentum, act, training, dil, groups, out_slot = mk
+            x, ldx = _nhwc(x)
+            Cout, Cin_g = weight.shape[0], weight.shape[1]
+            y, stats, wd = _conv_forward(x, ldx, None, ACT_NONE, weight, bias, dil, groups, training)
+            CoutP, npix, dev = y.shape[3], _npix(y), y.device
+            coef = _f32((4, CoutP), dev)
+            if training:
+                descs_fin += _bn_desc(coef=coef, stats=stats, gamma=gamma.detach(), beta=beta.detach(), rm=rm, rv=rv, npix=npix,
+                                      ntiles=stats.shape[0], C=CoutP, C_real=Cout, eps=eps, momentum=momentum)
+                keep.append(stats)
+            else:
+                L.call("egm_bn_eval_coeffs", ptr(gamma.detach()), ptr(beta.detach()), ptr(rm), ptr(rv), eps, ptr(coef[0]), ptr(coef[1]),
+                       ptr(coef[2]), ptr(coef[3]), CoutP, Cout, st)
+            z, ldz = _slot_or_new(out_slot, tuple(y.shape), y.dtype, dev)
+            descs_fwd += _bn_desc(y=y, z=z, coef=coef, npix=npix, ldy=CoutP, ldz=ldz, C=CoutP, act=act)
+            if ctx.needs_input_grad[1 + 5 * k + 1]:
+                _note_conv_use(weight)
+            saved += [x, weight, wd, y, coef]
+            outs.append(z)
+            ctx.meta.append((dil, groups, bias is not None, Cin_g * groups, Cout, act, training))
+        dt = dtype_code(outs[0].dtype)
+        if descs_fin:
+            L.call("egm_bn_multi", dt, _BN_FINALIZE, descs_fin, len(descs_fin) // 160, st)
+        L.call("egm_bn_multi", dt, _BN_FWD, descs_fwd, K, st)
+        ctx.save_for_backward(*saved)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gz):
+        K = len(ctx.meta)
+        L, st = lib(), stream()
+        sv = ctx.saved_tensors
+        per, d_red, d_coef, d_app = [], b"", b"", b""
+        for k in range(K):
+            x, weight, wd, y, coef = sv[5 * k:5 * k + 5]
+            dil, groups, has_bias, Cin, Cout, act, training = ctx.meta[k]
+            g, ldg = _nhwc(gz[k])
+            x, ldx = _nhwc(x)
+            N, H, W, CinP = x.shape
+            CoutP, npix, dev = y.shape[3], _npix(y), y.device
+            nb = L.query("egm_channel_partials_blocks", npix, CoutP)
+            part, sums, cf4 = _f32(nb * 2 * CoutP, dev), _f32((2, CoutP), dev), _f32((4, CoutP), dev)
+            dy = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev)
+            common = dict(y=y, dz=g, coef=coef, partials=part, sums=sums, cf4=cf4, npix=npix, ldy=CoutP, lddz=ldg, nblocks=nb, C=CoutP,
+                          act=act, train=1 if training else 0)
+            d_red += _bn_desc(**common)
+            d_coef += _bn_desc(**common)
+            d_app += _bn_desc(dy=dy, lddy=CoutP, **common)
+            per.append((x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP))
+        dt = dtype_code(per[0][0].dtype)
+        L.call("egm_bn_multi", dt, _BN_BWD_REDUCE, d_red, K, st)
+        L.call("egm_bn_multi", dt, _BN_BWD_COEFS, d_coef, K, st)
+        L.call("egm_bn_multi", dt, _BN_BWD_APPLY, d_app, K, st)
+        grads = [None]
+        for k in range(K):
+            x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP = per[k]
+            dil, groups, has_bias, Cin, Cout, act, training = ctx.meta[k]
+            KH, KW = weight.shape[2], weight.shape[3]
+            base = 1 + 5 * k
+            gx = gw = gb = None
+            if ctx.needs_input_grad[base]:
+                gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=x.device)
+                L.call("egm_conv_fwd", dt, ptr(dy), CoutP, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
+            if ctx.needs_input_grad[base + 1]:
+                gw = _conv_wgrad(x, ldx, None, ACT_NONE, dy, CoutP, None, None, weight, dil, groups, Cin, Cout)
+            if has_bias and ctx.needs_input_grad[base + 2]:
+                gb = _f32(Cout, x.device, zero=True)
+            ggamma = sums[1, :Cout] if ctx.needs_input_grad[base + 3] else None
+            gbeta = sums[0, :Cout] if ctx.needs_input_grad[base + 4] else None
+            grads += [gx, gw, gb, ggamma, gbeta]
+        return tuple(grads)
+
+
+def multi_conv_bn_act(items):
+    """items: K <= 4 tuples (x, conv, bn, act, dil, groups, out) of INDEPENDENT layers (x: NHWC tensor or Lazy) -> list of K outputs.
+    With the BatchNorm passes shared between the layers (_MultiConvBN); falls back to K conv_bn_act calls when disabled or K == 1."""
+    if not _FUSE_BN_MULTI or len(items) == 1 or len(items) > BN_MULTI_MAX:
+        return [conv_bn_act(x, conv, bn, act, dil=dil, groups=groups, out=out) for x, conv, bn, act, dil, groups, out in items]
+    meta, flat = [], []
+    for x, conv, bn, act, dil, groups, out in items:
+        if bn.training and bn.num_batches_tracked is not None and not getattr(bn, "_egm_counter_managed", False):
+            bn.num_batches_tracked.add_(1)
+        training = bn.training or bn.running_mean is None
+        momentum = 0.1 if bn.momentum is None else bn.momentum
+        meta.append((bn.running_mean, bn.running_var, bn.eps, momentum, act, training, dil, groups, None if out is None else [out]))
+        flat += [materialize(x), conv.weight, conv.bias, bn.weight, bn.bias]
+    return list(_MultiConvBN.apply(meta, *flat))
+
+
+def fuse_bn_multi(enabled=None):
+    global _FUSE_BN_MULTI
+    if enabled is not None:
+        _FUSE_BN_MULTI = bool(enabled)
+    return _FUSE_BN_MULTI
+
+
 EW_GATE, EW_SAR = 0, 1                     # enum egm_ew_mode
 _FUSE_BN_EW = os.environ.get("EGM_FUSE_BN_EW", "1") != "0"
 

@@ -158,6 +158,25 @@ int egm_bn_bwd_coefs(const float* partials, int ntiles, long long count, const f
                      const float* save_mean, const float* save_rstd, int train, float* sums_2xC, float* cf_4xC, int C,
                      egm_stream_t s);
 
+/* Multi-tensor forms: the BatchNorm passes of up to EGM_BN_MULTI_MAX INDEPENDENT layers in one launch each (the parallel branches of
+ * EdgeEnhancedGRFB, src/EGM-UNet.py:1256-1278, work on 8-32 channel tensors whose passes are launch-latency bound).  `descs` is a HOST
+ * array (it is copied into the kernel argument); every pass reads the fields it needs and ignores the others; coef = [4][C] rows
+ * scale | shift | save_mean | save_rstd.  Same arithmetic and block decomposition per tensor as the single-tensor entry points. */
+#define EGM_BN_MULTI_MAX 4
+enum egm_bn_multi_pass { EGM_BN_MULTI_FINALIZE = 0, EGM_BN_MULTI_FWD = 1, EGM_BN_MULTI_BWD_REDUCE = 2, EGM_BN_MULTI_BWD_COEFS = 3,
+                         EGM_BN_MULTI_BWD_APPLY = 4 };
+typedef struct egm_bn_desc {
+    const void* y;  void* z;  const void* dz;  void* dy;        /* BatchNorm input, output, gradient of the output, of the input */
+    float* coef;                                                  /* [4][C] */
+    const float* stats;                                           /* finalize: conv partial tiles [ntiles][2][C] */
+    const float* gamma;  const float* beta;  float* running_mean;  float* running_var;
+    float* partials;  float* sums;  float* cf4;                   /* backward: [nblocks][2][C], [2][C], [4][C] */
+    long long npix;
+    int ldy, ldz, lddz, lddy, ntiles, nblocks, C, C_real, act, train;
+    float eps, momentum;
+} egm_bn_desc;
+int egm_bn_multi(int dtype, int pass, const egm_bn_desc* descs, int n, egm_stream_t s);
+
 /* BatchNorm(+act) fused with the element-wise op behind it (z and dz never reach memory; same rounding points as the unfused
  * chain, so results agree bit for bit):
  *   EGM_EW_GATE  out = p*(1 + z)          EdgeAwareFeatureEnhancer, src/EGM-UNet.py:884-886 (z = sigmoid(BN(y)))

@@ -224,13 +224,14 @@ def test_chain_fused_equals_materialised_and_torch(dtype):
             close(st_f[n], b, n)
 
 
-@pytest.mark.parametrize("which", ["prologue", "elementwise"])
+@pytest.mark.parametrize("which", ["prologue", "elementwise", "multi"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_model_fused_equals_materialised(dtype, which):
     """EGM-UNet train step: logits, loss and all 333 parameter gradients identical with and without (a) the Lazy / operand-prologue
-    path and (b) the BatchNorm + element-wise fusions of csrc/bn_fused.hip (EdgeAwareFeatureEnhancer gate, GRFB residual tail)."""
+    path, (b) the BatchNorm + element-wise fusions of csrc/bn_fused.hip (EdgeAwareFeatureEnhancer gate, GRFB residual tail) and (c) the
+    multi-tensor BatchNorm passes shared by the lockstep GRFB branches (ops.multi_conv_bn_act)."""
     from egm_unet_amd import GRFBUNet, ops
-    toggle = ops.fuse_bn if which == "prologue" else ops.fuse_bn_ew
+    toggle = {"prologue": ops.fuse_bn, "elementwise": ops.fuse_bn_ew, "multi": ops.fuse_bn_multi}[which]
     default = toggle()
     from egm_unet_amd.train_utils import criterion
     torch.manual_seed(11)
@@ -259,7 +260,7 @@ def test_model_fused_equals_materialised(dtype, which):
             toggle(default)
     (o1, l1, g1, b1), (o2, l2, g2, b2) = res
     assert torch.equal(o1, o2) and torch.equal(l1, l2)
-    same = (lambda a, b: torch.equal(a, b)) if (dtype == torch.float32 or which == "elementwise") else \
+    same = (lambda a, b: torch.equal(a, b)) if (dtype == torch.float32 or which != "prologue") else \
         (lambda a, b: float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-12)      # bf16 prologue path: see the chain test
     bad = [n for n in g1 if not same(g1[n], g2[n])]
     assert not bad, f"{len(bad)} gradients differ between the fused and the materialised path, e.g. {bad[:5]}"
