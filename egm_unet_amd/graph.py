@@ -25,10 +25,15 @@ replay, so LR schedulers keep working (a captured graph bakes by-value arguments
 `warmup` REAL eager training steps on the example batch (allocator warm-up, lazy kernel attributes, momentum buffers); pass
 restore_after_warmup=True to get weights, BatchNorm statistics and momentum back to their values from before the warm-up.
 """
+import itertools
+
 import torch
 
 from . import ops
 from .train_utils.train_and_eval import criterion
+
+
+_serial = itertools.count()
 
 
 class GraphedTrainStep:
@@ -57,7 +62,8 @@ class GraphedTrainStep:
         side.wait_stream(cur)
         # warm-up and capture share one table namespace of their own: the pointer tables the graph re-uploads on every replay are
         # written here and never again (ops.table_namespace)
-        self._ns = ops.table_namespace(("graph", id(self)))
+        self._tag = ("graph", next(_serial))          # never reused (id() of a dead step would hand its stale tables to a new one)
+        self._ns = ops.table_namespace(self._tag)
         with torch.cuda.stream(side), self._ns:       # warm-up on a side stream (allocator, lazy kernel attributes, SGD state)
             for _ in range(max(1, warmup)):
                 self.warmup_loss = self._eager().detach()
@@ -115,6 +121,12 @@ class GraphedTrainStep:
         self.opt.grad_source = red.views
         with self._ns, torch.cuda.graph(self.gC, pool=self.gA.pool()):
             self.opt.step()
+
+    def __del__(self):
+        try:
+            ops.drop_table_namespace(self._tag)
+        except Exception:
+            pass
 
     def _push_lr(self):
         lr = float(self.opt.param_groups[0]["lr"])

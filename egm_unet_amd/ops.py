@@ -109,6 +109,15 @@ class table_namespace:
         _table_tag[0] = self.prev
 
 
+_all_tables = weakref.WeakSet()
+
+
+def drop_table_namespace(tag):
+    """Forget the buffers every DeviceTable holds for `tag` (a captured graph that no longer exists)."""
+    for t in list(_all_tables):
+        t.slots.pop(tag, None)
+
+
 class DeviceTable:
     """Packed C structs on the device.  Re-uploaded only when the bytes change; the upload is an async copy from a pinned
     staging buffer, so it is legal inside hipGraph capture (replays re-copy the same bytes).  One set of buffers per table namespace.
@@ -120,6 +129,7 @@ class DeviceTable:
 
     def __init__(self):
         self.slots = {}                      # tag -> [key, pinned, device, upload event, spare pairs, {blob: device} of this capture]
+        _all_tables.add(self)
 
     def _slot(self):
         return self.slots.setdefault(_table_tag[0], [None, None, None, None, [], {}])
@@ -704,14 +714,16 @@ class _MultiConvBN(Function):
             d_red += _bn_desc(**common)
             d_coef += _bn_desc(**common)
             d_app += _bn_desc(dy=dy, lddy=CoutP, **common)
-            per.append((x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP))
+            # every temporary stays referenced until the launches that use it are enqueued (freed earlier, the caching allocator
+            # would hand its memory to the next layer's temporaries: the kernels are not in the stream yet)
+            per.append((x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP, part, cf4))
         dt = dtype_code(per[0][0].dtype)
         L.call("egm_bn_multi", dt, _BN_BWD_REDUCE, d_red, K, st)
         L.call("egm_bn_multi", dt, _BN_BWD_COEFS, d_coef, K, st)
         L.call("egm_bn_multi", dt, _BN_BWD_APPLY, d_app, K, st)
         grads = [None]
         for k in range(K):
-            x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP = per[k]
+            x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP = per[k][:12]
             dil, groups, has_bias, Cin, Cout, act, training = ctx.meta[k]
             KH, KW = weight.shape[2], weight.shape[3]
             base = 1 + 5 * k
