@@ -20,7 +20,7 @@ PRE_NONE, PRE_BN_ACT, PRE_BN_BWD = 0, 1, 2            # enum egm_prologue
 
 _CTYPES = {
     "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "long long": ctypes.c_longlong,
-    "egm_stream_t": ctypes.c_void_p,
+    "egm_stream_t": ctypes.c_void_p, "unsigned long long": ctypes.c_ulonglong,
 }
 
 

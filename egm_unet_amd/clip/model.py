@@ -31,10 +31,10 @@ class ResidualAttentionBlock(nn.Module):
         self.ln_2 = LayerNorm(d_model)
         self.n_head = n_head
 
-    def run(self, x, mode):
-        """x [B, L, D]; mode 'csa' | 'causal' | 'full'."""
+    def run(self, x, mode, cls_mask=None):
+        """x [B, L, D]; mode 'csa' | 'causal' | 'full'; cls_mask: optional [B, L-1] fp32 multiplier of the class token's attention row."""
         qkv = O.linear(O.layernorm(x, self.ln_1), self.attn.in_proj_weight, self.attn.in_proj_bias)
-        a = O.attention(qkv, self.n_head, mode)
+        a = O.attention(qkv, self.n_head, mode, cls_mask)
         x = O.linear(a, self.attn.out_proj.weight, self.attn.out_proj.bias, residual=x)
         h = O.linear(O.layernorm(x, self.ln_2), self.mlp.c_fc.weight, self.mlp.c_fc.bias, act=2)          # QuickGELU fused
         return O.linear(h, self.mlp.c_proj.weight, self.mlp.c_proj.bias, residual=x)
@@ -75,8 +75,9 @@ class VisionTransformer(nn.Module):
             self._pos_cache = {key: torch.cat([pos[:1].float(), grid]).contiguous()}
         return self._pos_cache[key]
 
-    def run(self, img, dtype, extract_layers=(), csa_all_layers=True):
-        """img fp32 NCHW -> (cls feature [B, output_dim], [activations [B, L, D] at extract_layers])."""
+    def run(self, img, dtype, extract_layers=(), csa_all_layers=True, cls_mask=None):
+        """img fp32 NCHW -> (cls feature [B, output_dim], [activations [B, L, D] at extract_layers]).
+        cls_mask = (layer index | 'all', [B, tokens] fp32): see CLIPDensePredT.visual_forward."""
         B, C, H, W = img.shape
         P = self.patch_size
         gh, gw = H // P, W // P
@@ -91,7 +92,8 @@ class VisionTransformer(nn.Module):
         acts = []
         n = len(self.transformer.resblocks)
         for i, blk in enumerate(self.transformer.resblocks):
-            x = blk.run(x, "csa" if (csa_all_layers or i == n - 1) else "full")
+            m = cls_mask[1] if (cls_mask is not None and cls_mask[0] in ("all", i)) else None
+            x = blk.run(x, "csa" if (csa_all_layers or i == n - 1) else "full", m)
             if i in extract_layers:
                 acts.append(x)
         cls = O.layernorm(x[:, 0].contiguous(), self.ln_post)

@@ -74,14 +74,16 @@ def layernorm(x, ln):
     return y.reshape(x.shape)
 
 
-def attention(qkv, n_heads, mode):
-    """qkv [B, L, 3D] -> [B, L, D].  mode: 'csa' (softmax(qq^T s) + softmax(kk^T s)), 'causal', 'full'."""
+def attention(qkv, n_heads, mode, cls_mask=None):
+    """qkv [B, L, 3D] -> [B, L, D].  mode: 'csa' (softmax(qq^T s) + softmax(kk^T s)), 'causal', 'full'.
+    cls_mask [nmask, L-1] fp32: multiplies the class token's attention row, head bh taking row bh % nmask (the reference's pairing,
+    models/clipseg.py:111-117); runs on the unfused path (the probabilities are materialised)."""
     B, L, D3 = qkv.shape
     D = D3 // 3
     dh = D // n_heads
     Lp = (L + 7) // 8 * 8
     dt, dev = qkv.dtype, qkv.device
-    if dt == torch.bfloat16 and dh == 64 and qkv.is_contiguous():
+    if dt == torch.bfloat16 and dh == 64 and qkv.is_contiguous() and cls_mask is None:
         # fused path: scores and probabilities stay on chip (csrc/vit.hip attention_fused_kernel)
         out = torch.empty((B, L, D), dtype=dt, device=dev)
         lib().call("egm_attention_fused", dtype_code(dt), ptr(qkv), D3, B, L, n_heads, dh, {"full": 0, "causal": 1, "csa": 2}[mode], ptr(out), D,
@@ -104,6 +106,11 @@ def attention(qkv, n_heads, mode):
     else:
         scores(0, D)
         L_.call("egm_softmax_rows", code, ptr(S), Lp, ptr(P), Lp, B * n_heads * L, L, 1 if mode == "causal" else 0, 0, stream())
+    if cls_mask is not None:
+        m = cls_mask.float().contiguous()
+        if m.shape[1] != L - 1:
+            raise RuntimeError(f"attention: class-token mask has {m.shape[1]} entries, the sequence {L - 1} patch tokens")
+        L_.call("egm_attn_mask_cls", code, ptr(P), Lp, L * Lp, ptr(m), m.shape[0], B * n_heads, L - 1, stream())
     out = torch.empty((B, L, D), dtype=dt, device=dev)
     gemm(P, Lp, qkv, D3, False, out, D, L, dh, L, dt, nb1=B, nb2=n_heads, sA=(n_heads * L * Lp, L * Lp), sB=(L * D3, dh), sC=(L * D, dh), offB=2 * D)
     return out

@@ -102,11 +102,44 @@ def layernorm(x, ln):
     return LayerNormFn.apply(x, ln.weight, ln.bias, ln.eps)
 
 
-class AttentionFn(Function):
-    """Full (unmasked) multi-head self attention on packed qkv [B, L, 3D] -> [B, L, D] (nn.MultiheadAttention core)."""
+def _new_seed():
+    """64-bit dropout seed from torch's CPU generator (so torch.manual_seed makes a run reproducible)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def _dropout_raw(x, p, seed, residual=None):
+    out = torch.empty_like(x)
+    lib().call("egm_dropout", dtype_code(x.dtype), ptr(x), ptr(residual), ptr(out), x.numel(), float(p), ctypes.c_ulonglong(seed), stream())
+    return out
+
+
+class DropoutFn(Function):
+    """residual + dropout(x, p): nn.TransformerEncoderLayer's dropout / dropout1 / dropout2 (the residual add of the post-norm block
+    rides along).  The keep mask is a counter-based hash of (seed, element index): backward regenerates it."""
 
     @staticmethod
-    def forward(ctx, qkv, n_heads):
+    def forward(ctx, x, p, residual):
+        x = x.contiguous()
+        ctx.p, ctx.seed, ctx.has_res = float(p), _new_seed(), residual is not None
+        return _dropout_raw(x, p, ctx.seed, None if residual is None else residual.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return _dropout_raw(g, ctx.p, ctx.seed), None, (g if ctx.has_res else None)
+
+
+def dropout(x, p, residual=None):
+    """p == 0: plain residual add through the linear's own epilogue is used by the callers instead (no kernel here)."""
+    return DropoutFn.apply(x, p, residual)
+
+
+class AttentionFn(Function):
+    """Full (unmasked) multi-head self attention on packed qkv [B, L, 3D] -> [B, L, D] (nn.MultiheadAttention core), with its
+    attention-weight dropout (p_drop > 0 in train mode)."""
+
+    @staticmethod
+    def forward(ctx, qkv, n_heads, p_drop=0.0):
         B, L, D3 = qkv.shape
         D, dt, dev = D3 // 3, qkv.dtype, qkv.device
         dh, Lp = D // n_heads, (L + 7) // 8 * 8
@@ -115,16 +148,22 @@ class AttentionFn(Function):
         O.gemm(qkv, D3, qkv, D3, True, S, Lp, L, L, dh, dt, alpha=dh ** -0.5, c_f32=True, nb1=B, nb2=n_heads, sA=(L * D3, dh), sB=(L * D3, dh),
                sC=(n_heads * L * Lp, L * Lp), offA=0, offB=D)
         lib().call("egm_softmax_rows", dtype_code(dt), ptr(S), Lp, ptr(P), Lp, B * n_heads * L, L, 0, 0, stream())
+        ctx.p_drop, ctx.seed = float(p_drop), 0
+        Pd = P
+        if p_drop > 0.0:
+            ctx.seed = _new_seed()
+            Pd = _dropout_raw(P, p_drop, ctx.seed)                     # the dropped weights multiply V; softmax' own output is kept for backward
         out = torch.empty((B, L, D), dtype=dt, device=dev)
-        O.gemm(P, Lp, qkv, D3, False, out, D, L, dh, L, dt, nb1=B, nb2=n_heads, sA=(n_heads * L * Lp, L * Lp), sB=(L * D3, dh), sC=(L * D, dh),
+        O.gemm(Pd, Lp, qkv, D3, False, out, D, L, dh, L, dt, nb1=B, nb2=n_heads, sA=(n_heads * L * Lp, L * Lp), sB=(L * D3, dh), sC=(L * D, dh),
                offB=2 * D)
-        ctx.save_for_backward(qkv, P)
+        ctx.save_for_backward(qkv, P, Pd if p_drop > 0.0 else None)
         ctx.n_heads = n_heads
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        qkv, P = ctx.saved_tensors
+        qkv, P, Pd = ctx.saved_tensors
+        Pd = P if Pd is None else Pd
         H = ctx.n_heads
         B, L, D3 = qkv.shape
         D, dt, dev = D3 // 3, qkv.dtype, qkv.device
@@ -135,8 +174,10 @@ class AttentionFn(Function):
         # dP = dO @ V^T  (fp32)
         dP = torch.empty((B * H, L, Lp), dtype=torch.float32, device=dev)
         O.gemm(gout, D, qkv, D3, True, dP, Lp, L, L, dh, dt, c_f32=True, nb1=B, nb2=H, sA=(L * D, dh), sB=(L * D3, dh), sC=bh, offB=2 * D)
-        # dV = P^T @ dO
-        PT, Lr = _transpose(P, L, Lp, Lp, batch=B * H, sbatch=L * Lp)   # [B*H][Lp][Lr]
+        if ctx.p_drop > 0.0:                                        # gradient w.r.t. the dropped weights -> w.r.t. softmax' output
+            dP = _dropout_raw(dP, ctx.p_drop, ctx.seed)
+        # dV = P'^T @ dO  (P' = the weights that multiplied V)
+        PT, Lr = _transpose(Pd, L, Lp, Lp, batch=B * H, sbatch=L * Lp)   # [B*H][Lp][Lr]
         O.gemm(PT, Lr, gout, D, False, dqkv, D3, L, dh, L, dt, nb1=B, nb2=H, sA=(H * Lp * Lr, Lp * Lr), sB=(L * D, dh), sC=(L * D3, dh), offC=2 * D)
         # dS = P * (dP - rowsum(dP * P)) * scale   (scale folded here: S = scale * q k^T)
         dS = torch.empty_like(P)
@@ -145,11 +186,11 @@ class AttentionFn(Function):
         O.gemm(dS, Lp, qkv, D3, False, dqkv, D3, L, dh, L, dt, nb1=B, nb2=H, sA=bh, sB=(L * D3, dh), sC=(L * D3, dh), offB=D, offC=0)
         dST, _ = _transpose(dS, L, Lp, Lp, batch=B * H, sbatch=L * Lp)
         O.gemm(dST, Lr, qkv, D3, False, dqkv, D3, L, dh, L, dt, nb1=B, nb2=H, sA=(H * Lp * Lr, Lp * Lr), sB=(L * D3, dh), sC=(L * D3, dh), offB=0, offC=D)
-        return dqkv, None
+        return dqkv, None, None
 
 
-def attention(qkv, n_heads):
-    return AttentionFn.apply(qkv, n_heads)
+def attention(qkv, n_heads, p_drop=0.0):
+    return AttentionFn.apply(qkv, n_heads, p_drop)
 
 
 class FilmFn(Function):

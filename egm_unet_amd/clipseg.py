@@ -70,6 +70,7 @@ class CLIPDensePredT(nn.Module):
         self.extra_blocks = nn.ModuleList([])
         self.n_heads = n_heads
         self.compute_dtype = torch.float32
+        self.decoder_dropout = None          # None: the encoder layers' own p (0.1, as in the reference's train mode); 0.0 disables it
 
     def set_compute_dtype(self, dtype):
         self.clip_model.set_compute_dtype(dtype)
@@ -100,11 +101,23 @@ class CLIPDensePredT(nn.Module):
 
     @torch.no_grad()
     def visual_forward(self, x_inp, extract_layers=(), skip=False, mask=None):
-        """-> (visual_q [B, 512] fp32, activations [L, B, 768] fp32 like the reference, affinities [] (not materialised))."""
-        if mask is not None:
-            raise ValueError("mask not supported")
+        """-> (visual_q [B, 512] fp32, activations [L, B, 768] fp32 like the reference, affinities [] (not materialised)).
+        mask = (layer | 'all', 'cls_token', seg [B, H, W]): the visual-prompt mask of CLIPDensePredTMasked (models/clipseg.py:222-231):
+        seg is sampled (nearest, like nnf.interpolate's default) onto the token grid and multiplies the class token's attention row
+        in the selected layers."""
         require_gpu()
-        q, acts = self.model.run(x_inp.to(self.model.conv1.weight.device), self.compute_dtype, extract_layers=tuple(extract_layers))
+        dev = self.model.conv1.weight.device
+        cls_mask = None
+        if mask is not None:
+            mask_layer, mask_type, seg = mask
+            if mask_type != "cls_token":
+                raise NotImplementedError("egm_unet_amd: visual_forward masks of type 'cls_token' only (what CLIPDensePredTMasked uses)")
+            g = x_inp.shape[2] // self.model.patch_size
+            seg = seg.to(dev).float()
+            iy = (torch.arange(g, device=dev) * seg.shape[1] // g).long()          # nearest source index = floor(dst * in / out)
+            ix = (torch.arange(g, device=dev) * seg.shape[2] // g).long()
+            cls_mask = (mask_layer, seg[:, iy][:, :, ix].reshape(seg.shape[0], g * g).contiguous())
+        q, acts = self.model.run(x_inp.to(dev), self.compute_dtype, extract_layers=tuple(extract_layers), cls_mask=cls_mask)
         self._acts_bf = acts                                           # batch-first, compute dtype: consumed by forward()
         return q.float(), [a.float().permute(1, 0, 2) for a in acts], []
 
@@ -118,23 +131,30 @@ class CLIPDensePredT(nn.Module):
 
     def forward(self, inp_image, conditional=None, return_features=False, mask=None):
         """models/clipseg.py:436-496.  eval(): inference path, no autograd.  train(): the decoder (reduces, FiLM, blocks, trans_conv)
-        is differentiable through the HIP autograd operators of clip/train_ops.py; the CLIP backbone stays frozen (:155-156).
-        nn.TransformerEncoderLayer's dropout (p=0.1 in the reference's train mode) is not applied."""
+        is differentiable through the HIP autograd operators of clip/train_ops.py; the CLIP backbone stays frozen (:155-156);
+        nn.TransformerEncoderLayer's dropout is applied (self.decoder_dropout overrides its p; 0.0 switches it off)."""
         assert type(return_features) == bool
         if mask is not None:
-            raise ValueError("mask not supported")
+            raise ValueError("mask not supported")                  # as the reference (models/clipseg.py:442-443)
         if self.training and torch.is_grad_enabled():
             return self._forward_train(inp_image, conditional, return_features)
         with torch.no_grad():
             return self._forward_eval(inp_image, conditional, return_features)
 
     def _encoder_layer_train(self, blk, a):
+        """nn.TransformerEncoderLayer in train mode (post-norm, ReLU): dropout p on the attention weights, behind the attention output
+        projection, behind the ReLU and behind the second feed-forward linear (models/clipseg.py:421-422, p = 0.1 by default)."""
         from .clip import train_ops as T
+        p = self.decoder_dropout if self.decoder_dropout is not None else float(blk.dropout.p)
         qkv = T.linear(a, blk.self_attn.in_proj_weight, blk.self_attn.in_proj_bias)
-        att = T.attention(qkv, self.n_heads)
-        a = T.layernorm(T.linear(att, blk.self_attn.out_proj.weight, blk.self_attn.out_proj.bias, residual=a), blk.norm1)
-        h = T.linear(a, blk.linear1.weight, blk.linear1.bias, act=1)
-        return T.layernorm(T.linear(h, blk.linear2.weight, blk.linear2.bias, residual=a), blk.norm2)
+        att = T.attention(qkv, self.n_heads, p)
+        if p == 0.0:
+            a = T.layernorm(T.linear(att, blk.self_attn.out_proj.weight, blk.self_attn.out_proj.bias, residual=a), blk.norm1)
+            h = T.linear(a, blk.linear1.weight, blk.linear1.bias, act=1)
+            return T.layernorm(T.linear(h, blk.linear2.weight, blk.linear2.bias, residual=a), blk.norm2)
+        a = T.layernorm(T.dropout(T.linear(att, blk.self_attn.out_proj.weight, blk.self_attn.out_proj.bias), p, residual=a), blk.norm1)
+        h = T.dropout(T.linear(a, blk.linear1.weight, blk.linear1.bias, act=1), p)
+        return T.layernorm(T.dropout(T.linear(h, blk.linear2.weight, blk.linear2.bias), p, residual=a), blk.norm2)
 
     def _forward_train(self, inp_image, conditional, return_features):
         from .clip import train_ops as T
@@ -189,3 +209,27 @@ class CLIPDensePredT(nn.Module):
         if return_features:
             return out, visual_q, cond, activations
         return out,
+
+
+class CLIPDensePredTMasked(CLIPDensePredT):
+    """CLIPSeg conditioned on a support image + its segmentation (models/clipseg.py:500-525): the conditional vector is the CLIP
+    image feature of the support image, computed with the class token's attention restricted to the masked region in every layer."""
+
+    def __init__(self, version="ViT-B/32", extract_layers=(3, 6, 9), cond_layer=0, reduce_dim=128, n_heads=4, prompt="fixed", extra_blocks=0,
+                 reduce_cond=None, fix_shift=False, learn_trans_conv_only=False, refine=None, limit_to_clip_only=False, upsample=False,
+                 add_calibration=False, n_tokens=None, **kw):
+        super().__init__(version=version, extract_layers=extract_layers, cond_layer=cond_layer, reduce_dim=reduce_dim, n_heads=n_heads,
+                         prompt=prompt, extra_blocks=extra_blocks, reduce_cond=reduce_cond, fix_shift=fix_shift,
+                         learn_trans_conv_only=learn_trans_conv_only, limit_to_clip_only=limit_to_clip_only, upsample=upsample,
+                         add_calibration=add_calibration, n_tokens=n_tokens, **kw)
+
+    def visual_forward_masked(self, img_s, seg_s):
+        return super().visual_forward(img_s, mask=("all", "cls_token", seg_s))
+
+    def forward(self, img_q, cond_or_img_s, seg_s=None, return_features=False):
+        if seg_s is None:
+            cond = cond_or_img_s
+        else:
+            with torch.no_grad():
+                cond, _, _ = self.visual_forward_masked(cond_or_img_s, seg_s)
+        return super().forward(img_q, cond, return_features=return_features)

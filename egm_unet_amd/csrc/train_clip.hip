@@ -212,6 +212,36 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamEntry* __res
 
 #define EGM_T2(dtype, ...) EGM_DISPATCH_DTYPE(dtype, __VA_ARGS__)
 
+// ---- dropout (nn.TransformerEncoderLayer's p = 0.1 in the CLIPSeg decoder's train mode, models/clipseg.py:421-422) ------------------
+// Counter-based keep mask: element i of a call is kept iff u(seed, i) >= p with u a 24-bit uniform from a splitmix64 hash, so the
+// backward pass regenerates the mask from (seed, i) instead of storing it.  out = residual + keep * x / (1 - p).
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, long long i, float p) {
+    unsigned long long z = seed + (unsigned long long)i * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.f / 16777216.f) >= p;
+}
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, const T* __restrict__ residual, T* __restrict__ out, long long n, float p, float inv_keep,
+                               unsigned long long seed) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = dropout_keep(seed, i, p) ? to_f32(x[i]) * inv_keep : 0.f;
+        out[i] = from_f32<T>(residual ? to_f32(residual[i]) + v : v);
+    }
+}
+// P[bh][0][1 + j] *= mask[bh % nmask][j]: the visual-prompt mask of CLIPDensePredTMasked on the class token's attention row
+// (forward_multihead_attention, models/clipseg.py:111-117, including its `attn_mask.repeat(n_heads, 1)` pairing of masks with heads)
+template <typename T>
+__global__ void attn_mask_cls_kernel(T* __restrict__ P, int ldp, long long head_stride, const float* __restrict__ mask, int nmask, int nbh, int ntok) {
+    const long long total = (long long)nbh * ntok;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int bh = (int)(i / ntok), j = (int)(i - (long long)bh * ntok);
+        T* cell = P + bh * head_stride + 1 + j;                       // row 0 of this (batch, head)
+        *cell = from_f32<T>(to_f32(*cell) * mask[(long long)(bh % nmask) * ntok + j]);
+    }
+}
+
 extern "C" int egm_transpose(int dtype, const void* src, int rows, int cols, int ld_src, long long batch_stride_src, void* dst, int ld_dst,
                              long long batch_stride_dst, int batch, egm_stream_t s) {
     EGM_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows && batch > 0 && batch < 65536, "transpose: bad args");
@@ -298,5 +328,27 @@ extern "C" int egm_adamw_multi(const void* table_dev, int ntensors, long long to
     hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)s, (const AdamEntry*)table_dev, ntensors, lr,
                        beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2));
     EGM_CHECK_LAUNCH("adamw_multi");
+    return EGM_OK;
+}
+
+extern "C" int egm_dropout(int dtype, const void* x, const void* residual, void* out, long long n, float p, unsigned long long seed,
+                           egm_stream_t s) {
+    EGM_REQUIRE(x && out && n > 0 && p >= 0.f && p < 1.f, "dropout: bad args");
+    const long long blocks = (n + 255) / 256;
+    const int grid = (int)(blocks > 4096 ? 4096 : blocks);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dropout_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)residual,
+                                                 (T*)out, n, p, 1.f / (1.f - p), seed));
+    EGM_CHECK_LAUNCH("dropout");
+    return EGM_OK;
+}
+
+extern "C" int egm_attn_mask_cls(int dtype, void* P, int ldp, long long head_stride, const float* mask, int nmask, int nbh, int ntok,
+                                 egm_stream_t s) {
+    EGM_REQUIRE(P && mask && nmask > 0 && nbh > 0 && ntok > 0 && ldp >= ntok + 1, "attn_mask_cls: bad args");
+    const long long total = (long long)nbh * ntok, blocks = (total + 255) / 256;
+    const int grid = (int)(blocks > 4096 ? 4096 : blocks);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_mask_cls_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)s, (T*)P, ldp, head_stride,
+                                                 mask, nmask, nbh, ntok));
+    EGM_CHECK_LAUNCH("attn_mask_cls");
     return EGM_OK;
 }

@@ -487,6 +487,17 @@ int egm_adamw_chunk(void);
 int egm_adamw_multi(const void* table_dev, int ntensors, long long total_chunks, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int step, egm_stream_t s);
 
+/* ---- CLIPSeg decoder training: dropout, visual-prompt mask ---------------------------------------------------------------------
+ * nn.TransformerEncoderLayer(dropout=0.1) in train mode (models/clipseg.py:421-422): out = residual + keep*x/(1-p), keep regenerated
+ * from (seed, element index) by a counter-based hash, so the backward is the same call on the gradient (residual = NULL).
+ * x/out may be fp32 (dtype EGM_F32) or bf16. */
+int egm_dropout(int dtype, const void* x, const void* residual, void* out, long long n, float p, unsigned long long seed,
+                egm_stream_t s);
+/* CLIPDensePredTMasked (models/clipseg.py:500-525; forward_multihead_attention :111-117): the class token's attention row of every
+ * (batch, head) is multiplied by a [nmask][ntok] mask, head bh taking mask row bh % nmask (the reference's repeat() pairing). */
+int egm_attn_mask_cls(int dtype, void* probs, int ldp, long long head_stride, const float* mask, int nmask, int nbh, int ntok,
+                      egm_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -200,3 +200,32 @@ def test_ensemble_matches_reference_fixture():
         assert_close(fused.cpu(), ref_fused, rtol=1e-5, atol=1e-5, what="fused logits")
         agree = float((pred.cpu()[0] == torch.from_numpy(fx["pred"][i].astype(np.int64))).float().mean())
         assert agree > 0.9995, agree          # argmax of logits that differ in the last fp32 bit may flip on exact near-ties only
+
+
+def test_clipseg_masked_matches_reference_fixture():
+    """CLIPDensePredTMasked (models/clipseg.py:500-525): conditional vector from a support image with the class token's attention masked
+    by its segmentation in every layer (batch of 2: the reference pairs masks with heads through attn_mask.repeat(n_heads, 1)), then the
+    query decode -- against tests/golden/clipseg_masked.npz, produced by the reference's own class (tools/make_golden_clip_masked.py)."""
+    from oracle import clip_ref as C
+    from egm_unet_amd.clipseg import CLIPDensePredTMasked
+    fx = load_fixture("clipseg_masked")
+    m = CLIPDensePredTMasked(version="ViT-B/16", reduce_dim=64)
+    m.clip_model.load_state_dict(C.make_clip_state(seed=0))
+    m.load_state_dict(C.make_decoder_state(seed=0), strict=False)
+    m.to(DEV).eval()
+    img_q = torch.from_numpy(fx["img_q"].astype(np.float32)).to(DEV)
+    img_s = torch.from_numpy(fx["img_s"].astype(np.float32)).to(DEV)
+    seg = torch.from_numpy(fx["seg"].astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        cond, _, _ = m.visual_forward_masked(img_s, seg)
+        out = m(img_q, img_s, seg)[0]
+    assert_close(cond.cpu(), fx["cond"], rtol=2e-3, atol=2e-3, what="masked conditional")
+    # the mask matters: the result is far closer to the masked fixture than to the unmasked conditional
+    assert rel(cond.cpu(), torch.from_numpy(fx["cond"])) < 0.1 * rel(torch.from_numpy(fx["cond_plain"]), torch.from_numpy(fx["cond"]))
+    assert_close(out[:, :, ::4, ::4].cpu(), fx["out"], rtol=2e-3, atol=3e-3, what="mask logits (subsampled)")
+    assert_close(out[:, :, 100:164, 100:164].cpu(), fx["out_crop"], rtol=2e-3, atol=3e-3, what="mask logits (crop)")
+    # bf16 path: the probabilities are materialised for the mask (unfused attention); it tracks fp32
+    m.set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        cond_bf, _, _ = m.visual_forward_masked(img_s, seg)
+    assert rel(cond_bf.cpu(), torch.from_numpy(fx["cond"])) < 0.05

@@ -95,6 +95,7 @@ def test_decoder_gradients_match_reference_fixture_fp32():
     from egm_unet_amd.clip import train_ops as T
     fx, tr = load_fixture("clipseg_fwd"), load_fixture("clipseg_train")
     m = _model(torch.float32).train()
+    m.decoder_dropout = 0.0             # the fixture is the reference in eval mode with autograd on (tools/make_golden_clip.py): no dropout
     img = torch.from_numpy(fx["img"].astype(np.float32)).to(DEV)
     target = (torch.rand(2, 1, 352, 352, generator=torch.Generator().manual_seed(int(tr["target_seed"]))) < 0.3).float().to(DEV)
     out = m(img, torch.from_numpy(fx["cond"]).to(DEV))[0]
@@ -124,6 +125,7 @@ def test_bf16_training_step_reduces_loss_and_tracks_fp32():
     losses = {}
     for dtype in (torch.float32, torch.bfloat16):
         m = _model(dtype).train()
+        m.decoder_dropout = 0.0         # fp32 and bf16 runs must see the same function
         dec = [p for k, p in m.named_parameters() if p.requires_grad]
         opt = T.AdamW(dec, lr=1e-3, weight_decay=1e-2)
         ls = []
@@ -157,3 +159,82 @@ def test_adamw_matches_torch():
         assert torch.allclose(a.detach(), b.detach().cpu(), rtol=2e-6, atol=2e-7)
     sd = o_mine.state_dict()
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dropout_kernel_statistics_and_backward_mask(dtype):
+    """egm_dropout: keep rate 1 - p, survivors scaled by 1/(1-p), residual added after the mask, backward = the SAME mask on the gradient
+    (regenerated from the seed), another seed = another mask, p = 0 = identity."""
+    from egm_unet_amd.clip import train_ops as T
+    torch.manual_seed(123)
+    x = torch.ones(64, 53, 64, device=DEV, dtype=dtype, requires_grad=True)
+    res = torch.full_like(x, 2.0)
+    for p in (0.1, 0.5):
+        y = T.dropout(x, p, residual=res)
+        kept = (y.detach().float() != 2.0)
+        frac = float(kept.float().mean())
+        assert abs(frac - (1 - p)) < 0.01, (p, frac)
+        assert torch.allclose(y.detach().float()[kept], torch.tensor(2.0 + 1.0 / (1 - p)), rtol=1e-2)
+        (gx,) = torch.autograd.grad(y, x, torch.ones_like(y))
+        assert torch.equal(gx.float() != 0, kept), "backward mask differs from the forward mask"
+        assert torch.allclose(gx.float()[kept], torch.tensor(1.0 / (1 - p)), rtol=1e-2)
+        y2 = T.dropout(x, p, residual=res)
+        assert not torch.equal(y2.detach().float() != 2.0, kept), "two calls must draw different masks"
+    assert torch.equal(T.dropout(x, 0.0).detach(), x.detach())
+
+
+def test_decoder_dropout_train_mode():
+    """train(): nn.TransformerEncoderLayer's dropout (p = 0.1) is active in the decoder like in the reference -- two forward passes
+    differ, gradients are finite, p = 0 reproduces the deterministic path bit for bit; eval(): deterministic."""
+    from egm_unet_amd.clip import train_ops as T
+    fx = load_fixture("clipseg_fwd")
+    img = torch.from_numpy(fx["img"].astype(np.float32)).to(DEV)
+    cond = torch.from_numpy(fx["cond"]).to(DEV)
+    target = torch.zeros(2, 1, 352, 352, device=DEV); target[:, :, 100:250, 80:300] = 1.0
+    m = _model(torch.float32).train()
+    assert m.decoder_dropout is None and abs(m.blocks[0].dropout.p - 0.1) < 1e-9
+    torch.manual_seed(5)
+    o1 = m(img, cond)[0]
+    o2 = m(img, cond)[0]
+    assert not torch.equal(o1, o2), "dropout must randomise the training forward"
+    torch.manual_seed(5)
+    o1b = m(img, cond)[0]
+    assert torch.equal(o1, o1b), "same torch seed, same masks"
+    loss = T.bce_with_logits(o1, target)
+    loss.backward()
+    grads = [p.grad for p in m.parameters() if p.requires_grad]
+    assert all(g is not None and torch.isfinite(g).all() for g in grads)
+    # the dropped model stays close to the deterministic one (p = 0.1): same sign on most pixels
+    m.decoder_dropout = 0.0
+    od = m(img, cond)[0]
+    assert torch.equal(od, m(img, cond)[0])
+    assert float(((o1 > 0) == (od > 0)).float().mean()) > 0.8
+    m.eval()
+    with torch.no_grad():
+        assert torch.equal(m(img, cond)[0], m(img, cond)[0])
+
+
+def test_attention_dropout_gradients_match_torch_with_same_mask():
+    """AttentionFn with p_drop > 0 against torch autograd on softmax(qk^T) * mask / (1-p) @ v, the mask read back from the kernel."""
+    from egm_unet_amd.clip import train_ops as T
+    g = torch.Generator().manual_seed(9)
+    B, L, D, H, p = 2, 21, 64, 4, 0.25
+    qkv = torch.randn(B, L, 3 * D, generator=g)
+    gout = torch.randn(B, L, D, generator=g)
+    seeds = []
+    orig = T._new_seed
+    T._new_seed = lambda: seeds.append(orig()) or seeds[-1]
+    try:
+        xq = qkv.to(DEV).requires_grad_(True)
+        out = T.attention(xq, H, p)
+        out.backward(gout.to(DEV))
+    finally:
+        T._new_seed = orig
+    Lp = (L + 7) // 8 * 8
+    keep = T._dropout_raw(torch.ones(B * H, L, Lp, device=DEV), p, seeds[0])[:, :, :L].cpu().view(B, H, L, L) * (1 - p)   # 0 / 1
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = [t.view(B, L, H, D // H).transpose(1, 2) for t in qr.chunk(3, -1)]
+    P = torch.softmax(q @ k.transpose(-1, -2) * (D // H) ** -0.5, -1) * keep / (1 - p)
+    (P @ v).transpose(1, 2).reshape(B, L, D).backward(gout)
+    assert rel(out.detach(), (P @ v).transpose(1, 2).reshape(B, L, D).detach()) < 2e-5
+    assert rel(xq.grad, qr.grad) < 1e-4
