@@ -618,6 +618,25 @@ extern "C" int egm_vec_add_f32(float* y, const float* x, long long n, egm_stream
     EGM_CHECK_LAUNCH("vec_add_f32");
     return EGM_OK;
 }
+// dst[r][col0_dst + c] = src[r][col0_src + c] for c < ncols: re-layout of an fp32 weight matrix whose input channels come from tensors
+// that were each padded to a multiple of 8 before being concatenated (FusionConv.down with two distinct inputs, src/EGM-UNet.py:1223-1224)
+__global__ void copy_cols_f32_kernel(const float* __restrict__ src, int ld_src, int col0_src, float* __restrict__ dst, int ld_dst, int col0_dst,
+                                     int rows, int ncols) {
+    const long long total = (long long)rows * ncols;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / ncols), c = (int)(i - (long long)r * ncols);
+        dst[(long long)r * ld_dst + col0_dst + c] = src[(long long)r * ld_src + col0_src + c];
+    }
+}
+extern "C" int egm_copy_cols_f32(const float* src, int ld_src, int col0_src, float* dst, int ld_dst, int col0_dst, int rows, int ncols,
+                                 egm_stream_t s) {
+    EGM_REQUIRE(src && dst && rows > 0 && ncols > 0 && col0_src >= 0 && col0_dst >= 0 && col0_src + ncols <= ld_src && col0_dst + ncols <= ld_dst,
+                "copy_cols_f32: bad args");
+    hipLaunchKernelGGL(copy_cols_f32_kernel, dim3(stream_grid((long long)rows * ncols)), dim3(256), 0, (hipStream_t)s, src, ld_src, col0_src, dst,
+                       ld_dst, col0_dst, rows, ncols);
+    EGM_CHECK_LAUNCH("copy_cols_f32");
+    return EGM_OK;
+}
 extern "C" int egm_fill_f32(float* y, float v, long long n, egm_stream_t s) {
     EGM_REQUIRE(y && n > 0, "fill_f32: bad args");
     hipLaunchKernelGGL(fill_f32_kernel, dim3(stream_grid(n)), dim3(256), 0, (hipStream_t)s, y, v, n);

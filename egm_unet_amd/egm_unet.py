@@ -143,8 +143,11 @@ class FusionConv(nn.Module):
         """x2 is None (or x1 itself) == the reference call fusion_conv(concat, concat): cat([x, x]) is never built, the two
         halves of `down.weight` are summed instead; conv3+conv5+conv7 run as one 7x7 conv with the summed kernels."""
         if x2 is not None and x2 is not x1:
+            # two distinct inputs: each is padded to a multiple of 8 channels on its own, so the weight's input columns move to the
+            # padded positions (no-op when the channel count is a multiple of 8 already)
+            k = self.down.weight.shape[1] // 2
             x1 = ops.cat_channels([x1, x2])
-            wdown = self.down.weight
+            wdown = self.down.weight if k % 8 == 0 else ops.spread_cols(self.down.weight, (k, k))
         else:
             wdown = ops.fold2(self.down.weight)
         f = ops.conv2d(x1, wdown, self.down.bias)

@@ -1425,6 +1425,41 @@ def fold2(w):
     return _Fold2.apply(w)
 
 
+class _SpreadCols(Function):
+    """[rows, sum(real), 1, 1] -> [rows, sum(pad8(real)), 1, 1]: the input-channel columns of a 1x1 weight moved to where the channels sit
+    after each source tensor was padded to a multiple of 8 on its own (zeros in the gaps).  Backward gathers the columns back."""
+
+    @staticmethod
+    def forward(ctx, w, real):
+        rows, st = w.shape[0], stream()
+        tot_r, tot_p = sum(real), sum(pad8(c) for c in real)
+        out = torch.zeros((rows, tot_p, 1, 1), dtype=torch.float32, device=w.device)
+        wc = w.detach().contiguous()
+        o_r = o_p = 0
+        for c in real:
+            lib().call("egm_copy_cols_f32", ptr(wc), tot_r, o_r, ptr(out), tot_p, o_p, rows, c, st)
+            o_r, o_p = o_r + c, o_p + pad8(c)
+        ctx.real = tuple(real)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        real = ctx.real
+        rows, st = g.shape[0], stream()
+        tot_r, tot_p = sum(real), sum(pad8(c) for c in real)
+        gc = g.contiguous()
+        dw = torch.empty((rows, tot_r, 1, 1), dtype=torch.float32, device=g.device)
+        o_r = o_p = 0
+        for c in real:
+            lib().call("egm_copy_cols_f32", ptr(gc), tot_p, o_p, ptr(dw), tot_r, o_r, rows, c, st)
+            o_r, o_p = o_r + c, o_p + pad8(c)
+        return dw, None
+
+
+def spread_cols(w, real):
+    return _SpreadCols.apply(w, real)
+
+
 class _Merge357(Function):
     @staticmethod
     def forward(ctx, w3, w5, w7, b3, b5, b7):

@@ -218,6 +218,9 @@ int egm_sum4(int dtype, const void* a, int lda, const void* b, int ldb, const vo
 /* fp32 vector add: y[i] += x[i] (parameter-gradient accumulation) */
 int egm_vec_add_f32(float* y, const float* x, long long n, egm_stream_t s);
 int egm_fill_f32(float* y, float v, long long n, egm_stream_t s);
+/* fp32 matrix column block copy: dst[r][col0_dst + c] = src[r][col0_src + c], c < ncols (weight re-layout for inputs padded per tensor) */
+int egm_copy_cols_f32(const float* src, int ld_src, int col0_src, float* dst, int ld_dst, int col0_dst, int rows, int ncols,
+                      egm_stream_t s);
 
 /* ---- EdgeAwareFeatureEnhancer pieces (src/EGM-UNet.py:872-886) -------------------------------------------------- */
 /* out = x - avgpool3x3(x) (zero pad, divisor 9).  Self-adjoint: the same call is its own backward. */

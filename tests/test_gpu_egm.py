@@ -36,8 +36,8 @@ def test_fusion_conv_fixture_two_inputs():
     fx = load_fixture("fusion_conv")
     m = FusionConv(28, 16)
     load_module_state(m, fx)
-    # fixture has 28 real channels per input (not a multiple of 8): pad inputs to 32 and widen `down` accordingly
-    pytest.skip("two-input FusionConv with 28-channel inputs is exercised through edge_grfb fixtures (single-input fold)")
+    # 28 real channels per input (not a multiple of 8): each input is padded to 32 on its own and `down.weight`'s columns follow
+    run_block(m, fx, 2, grad_tol=GT)
 
 
 @pytest.mark.parametrize("name,c", [("edge_grfb_c64", 64), ("edge_grfb_c32", 32)])
