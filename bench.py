@@ -57,11 +57,20 @@ class KernelTimer:
 
     REPS = 4          # conv launches are re-issued back to back so the event pair brackets kernel time, not launch gaps
 
+    @staticmethod
+    def _canon(name, args):
+        """The *_pre entry points (operand prologues) recorded under the plain names with the plain argument layout."""
+        if name == "egm_conv_fwd_pre":          # (dtype, x, ldx, [pre_mode, pre_act, pre_cf, pre_aux, pre_ld_aux], wf, bias, ...)
+            return "egm_conv_fwd", args[:3] + args[8:]
+        if name == "egm_conv_wgrad_pre":        # (dtype, x, ldx, [3 x-prologue], dy, lddy, [5 dy-prologue, dy_out, ld_dy_out], dw, ws, N, ...)
+            return "egm_conv_wgrad", args[:3] + args[6:8] + args[15:]
+        return name, args
+
     def __enter__(self):
         def timed(name, *args):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = 1
-            if name in ("egm_conv_fwd", "egm_conv_wgrad"):
+            if name in ("egm_conv_fwd", "egm_conv_wgrad", "egm_conv_fwd_pre", "egm_conv_wgrad_pre"):
                 # idempotent (same inputs, outputs overwritten with the same values): the first call does the work of the step,
                 # REPS more are timed as a train, which matches the per-launch durations rocprofv3 reports for the graph replay
                 self._orig(name, *args)
@@ -70,7 +79,8 @@ class KernelTimer:
             for _ in range(reps):
                 self._orig(name, *args)
             e1.record()
-            self.records.append((name, args, _Span(e0, e1, reps), None))
+            cname, cargs = self._canon(name, args)
+            self.records.append((cname, cargs, _Span(e0, e1, reps), None))
         self.lib.call = timed
         return self
 
@@ -178,7 +188,15 @@ def cpu_baseline(seconds_budget=25.0):
         if time.time() - t_start > seconds_budget:
             break
     best = min(times[1:]) if len(times) > 1 else times[0]
-    return {"value": round(2.0 / best, 4), "unit": "images/s", "cores": threads, "kind": "port",
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(2.0 / best, 4), "unit": "images/s", "cores": threads, "cpu_model": cpu_model, "kind": "port",
             "sample": f"{len(times)} train steps (fwd+loss+bwd+SGD) of EGM-UNet(3,2,32) at bs 2x3x512x512 fp32 on the CPU oracle; best of steps after the first"}
 
 
@@ -439,6 +457,7 @@ def main():
         opt.step()
         return loss
 
+    capture_error = None
     if args.eager:
         step = eager_step
     else:
@@ -451,6 +470,7 @@ def main():
             if reducer is not None:
                 reducer.hooks_enabled = True
             args.eager = True
+            capture_error = f"{type(e).__name__}: {str(e)[:160]}"
             step = eager_step
 
     def fence():
@@ -487,14 +507,17 @@ def main():
         dom_key, dom = max(((k, v) for k, v in agg.items() if v[2] > 0), key=lambda kv: kv[1][1])
         achieved = dom[2] / (dom[1] * 1e-3) / 1e12
         traffic = None          # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # command; FETCH_SIZE doubled per the gfx950 note of the guide)
+        traffic_source = None   # command; FETCH_SIZE doubled per the gfx950 note of the guide): a CHECKED-IN measurement, not this run's
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (9, 8, 7, 6, 5, 4, 3, 2, 1)) if os.path.exists(q)), "")
         if os.path.exists(tpath) and args.dtype == "bf16":
+            traffic_source = (os.path.relpath(tpath, ROOT) + ": rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this command, recorded "
+                              "earlier and checked in (FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); not collected by this run")
             for k, v in json.load(open(tpath)).items():
                 if k.startswith(dom_key.split("[")[0].replace("egm_", "")) and dom_key.split("[")[1][:3] in k:
                     traffic = v["hbm_bytes_per_launch_corrected"]
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3,
                     "unit": "TFLOP/s", "frac": round(achieved / (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3), 4),
-                    "traffic": traffic, "kernel": dom_key, "algorithmic_bytes_per_launch": round(dom[3] / dom[0]), "launches_per_step": dom[0],
+                    "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None, "kernel": dom_key, "algorithmic_bytes_per_launch": round(dom[3] / dom[0]), "launches_per_step": dom[0],
                     "avg_launch_ms": round(dom[1] / dom[0], 4), "algorithmic_gflop_per_launch": round(dom[2] / dom[0] / 1e9, 3),
                     "share_of_step_kernel_time": round(dom[1] / total_ms, 3),
                     # sum over the launches of min(MFMA, HBM)-roofline time / measured time: the high-resolution layers of this
@@ -519,7 +542,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"EGM-UNet GRFBUNet(3,2,base_c=32) fwd+5-term-loss+bwd+SGD, {args.batch}x3x{args.size}x{args.size} per GPU "
                                    "(BASELINE.json configs[1])",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "launch": "eager" if args.eager else "hipGraph replay", "final_loss": round(final_loss, 4)},
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "launch": (f"eager (capture failed: {capture_error})" if capture_error else "eager") if args.eager else
+                       ("hipGraph replay" if world == 1 or not getattr(step, "split", False) else
+                        "3 hipGraph replays per step (fwd + decoder bwd | encoder bwd | SGD), RCCL all-reduce of bucket 0 / 1 between them on a side stream"),
+                       "final_loss": round(final_loss, 4)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

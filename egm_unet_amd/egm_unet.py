@@ -374,8 +374,8 @@ class GRFB(nn.Module):
 class RecursiveGatedAttention(nn.Module):
     def __init__(self, dim, order=2, reduction=8, kernel_size=3):
         super().__init__()
-        if order != 2 or kernel_size != 3:
-            raise NotImplementedError("egm_unet_amd: RecursiveGatedAttention is built for order=2, kernel 3 (as EGM-UNet uses it)")
+        if order < 1 or kernel_size != 3:
+            raise NotImplementedError("egm_unet_amd: RecursiveGatedAttention is built for a 3x3 depthwise kernel (as EGM-UNet uses it)")
         self.order, self.dim = order, dim
         self.split_sizes = [dim // (2 ** i) for i in range(1, order)]
         self.split_sizes.append(dim // (2 ** (order - 1)))
@@ -411,10 +411,16 @@ class RecursiveGatedAttention(nn.Module):
         fused = ops.conv2d(x, self.proj_in.weight, self.proj_in.bias)
         base, gates = ops.split_channels(fused, s0)
         gates = ops.dwconv3(gates, self.dwconv.weight, self.dwconv.bias, self.scale)
-        g0, g1 = ops.split_channels(gates, s0)
-        out = ops.bcast_gate(base, self._gate(0, g0))
-        out = ops.conv2d(out, self.transform_convs[0].weight, self.transform_convs[0].bias)
-        out = ops.bcast_gate(out, self._gate(1, g1))
+        pieces, rest = [], gates                                                # torch.split(gates, split_sizes): order pieces
+        for i in range(self.order - 1):
+            piece, rest = ops.split_channels(rest, self.split_sizes[i])
+            pieces.append(piece)
+        pieces.append(rest)
+        out = base
+        for i in range(self.order):                                              # recursive gating (src/EGM-UNet.py:534-545)
+            out = ops.bcast_gate(out, self._gate(i, pieces[i]))
+            if i < self.order - 1:
+                out = ops.conv2d(out, self.transform_convs[i].weight, self.transform_convs[i].bias)
         return ops.conv2d(out, self.proj_out.weight, self.proj_out.bias)
 
 

@@ -66,6 +66,16 @@ def test_rga_fixture():
     run_block(m, fx, 1, grad_tol=GT)
 
 
+def test_rga_order3_fixture():
+    """RecursiveGatedAttention(128, order=3): split sizes [32, 32, 64], two transform convs -- the generic recursion of
+    src/EGM-UNet.py:518-547 against the reference's own forward / backward (tools/make_golden_rga.py)."""
+    from egm_unet_amd.egm_unet import RecursiveGatedAttention
+    fx = load_fixture("rga_d128_o3")
+    m = RecursiveGatedAttention(128, order=3)
+    load_module_state(m, fx)
+    run_block(m, fx, 1, grad_tol=GT)
+
+
 def test_egm_down_fixture():
     from egm_unet_amd.egm_unet import Down
     fx = load_fixture("egm_down")

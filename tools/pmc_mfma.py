@@ -10,11 +10,12 @@ import re
 import sys
 
 FAMILIES = [
-    ("conv fwd/dgrad 3x3, 64-wide cout tiles (conv_igemm_pipe_kernel<2,3,3,2>)", re.compile(r"conv_igemm_pipe_kernel<2, 3, 3, 2>")),
-    ("conv fwd/dgrad 3x3, tall tiles (conv_igemm_pipe_kernel<1,3,3,4>)", re.compile(r"conv_igemm_pipe_kernel<1, 3, 3, 4>")),
-    ("conv fwd/dgrad 1x1 (conv_igemm_pipe_kernel<*,1,1,2>)", re.compile(r"conv_igemm_pipe_kernel<\d, 1, 1, 2>")),
-    ("conv wgrad 3x3 (conv_wgrad_kernel<bf16,9>)", re.compile(r"conv_wgrad_kernel<.*bf16_t, 9>")),
-    ("conv wgrad 1x1 (conv_wgrad_kernel<bf16,1>)", re.compile(r"conv_wgrad_kernel<.*bf16_t, 1>")),
+    ("conv fwd/dgrad 3x3, 64-wide cout tiles (conv_igemm_pipe_kernel<2,3,3,2>)", re.compile(r"conv_igemm_pipe_kernel<2, 3, 3, 2")),
+    ("conv fwd/dgrad 3x3, tall tiles (conv_igemm_pipe_kernel<1,3,3,4>)", re.compile(r"conv_igemm_pipe_kernel<1, 3, 3, 4")),
+    ("conv fwd/dgrad 1x1 (conv_igemm_pipe_kernel<*,1,1,2>)", re.compile(r"conv_igemm_pipe_kernel<\d, 1, 1, 2")),
+    ("conv wgrad 3x3, wave-specialised (conv_wgrad_ws_kernel<9>)", re.compile(r"conv_wgrad_ws_kernel<9")),
+    ("conv wgrad 7-tap rows, wave-specialised (conv_wgrad_ws_kernel<7>)", re.compile(r"conv_wgrad_ws_kernel<7")),
+    ("conv wgrad 1x1 (conv_wgrad_kernel<bf16,1>)", re.compile(r"conv_wgrad_kernel<.*bf16_t, 1")),
 ]
 
 

@@ -10,15 +10,17 @@ import re
 import sys
 
 FAMILIES = [
-    ("conv_fwd[3x3] (conv_igemm_pipe_kernel<*,3,3,*>)", re.compile(r"conv_igemm_pipe_kernel<\d+, 3, 3, \d+>")),
-    ("conv_fwd[1x1] (conv_igemm_pipe_kernel<*,1,1,*>)", re.compile(r"conv_igemm_pipe_kernel<\d+, 1, 1, \d+>")),
-    ("conv_wgrad[3x3] (conv_wgrad_kernel<bf16,9>)", re.compile(r"conv_wgrad_kernel<.*bf16_t, 9>")),
-    ("conv_wgrad[1x1] (conv_wgrad_kernel<bf16,1>)", re.compile(r"conv_wgrad_kernel<.*bf16_t, 1>")),
+    ("conv_fwd[3x3] (conv_igemm_pipe_kernel<*,3,3,*>)", re.compile(r"conv_igemm_pipe_kernel<\d+, 3, 3, \d+")),
+    ("conv_fwd[1x1] (conv_igemm_pipe_kernel<*,1,1,*>)", re.compile(r"conv_igemm_pipe_kernel<\d+, 1, 1, \d+")),
+    ("conv_wgrad[3x3] (conv_wgrad_ws_kernel<9> / conv_wgrad_kernel<bf16,9>)", re.compile(r"conv_wgrad_ws_kernel<9|conv_wgrad_kernel<.*bf16_t, 9")),
+    ("conv_wgrad[1x1] (conv_wgrad_kernel<bf16,1> / conv_wgrad_ws_kernel<1>)", re.compile(r"conv_wgrad_kernel<.*bf16_t, 1|conv_wgrad_ws_kernel<1")),
+    ("bn_ew (fused BatchNorm + element-wise, fwd / bwd reduce / bwd apply)", re.compile(r"bn_ew_")),
+    ("bn multi-tensor passes (GRFB branches)", re.compile(r"bn_\w*multi_kernel")),
     ("bn_act_bwd_apply", re.compile(r"bn_act_bwd_apply_kernel")),
     ("bn_act_bwd_reduce (channel_partials_kernel<bf16,1>)", re.compile(r"channel_partials_kernel<.*bf16_t, 1>")),
     ("bn_act_fwd", re.compile(r"bn_act_fwd_kernel")),
     ("wgrad_reduce_multi", re.compile(r"wgrad_reduce_multi_kernel")),
-    ("conv_wgrad[dilated rows] (conv_wgrad_kernel<bf16,3>)", re.compile(r"conv_wgrad_kernel<.*bf16_t, 3>")),
+    ("conv_wgrad[dilated rows] (conv_wgrad_kernel<bf16,3>)", re.compile(r"conv_wgrad_kernel<.*bf16_t, 3")),
     ("mca_fused_fwd", re.compile(r"mca_fused_fwd_kernel")),
     ("upcat_fwd (in place: upsampled half only)", re.compile(r"upcat_fwd_kernel")),
     ("maxpool2_fwd", re.compile(r"maxpool2_fwd_kernel")),
