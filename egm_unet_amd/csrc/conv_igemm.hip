@@ -36,6 +36,11 @@ int egm_conv_direct_launch(const void* x, int ldx, const PreArgs& pre, const voi
                            float* stats, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int NT, int nct, int G, size_t smem,
                            egm_stream_t s);
 
+// conv_ws.hip: wave-specialised 3x3 kernel for the wide layers
+int egm_conv_ws_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int* nct_out, int* G_out);
+int egm_conv_ws_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, float* stats, int N, int H,
+                       int W, int Cin, int Cout, int nct, int G, egm_stream_t s);
+
 namespace {
 
 constexpr int TH = 8, TW = 32, KC = 32;
@@ -748,12 +753,14 @@ int launch_pipe(ConvParams& p, int G, hipStream_t st) {
 }
 
 // One place decides kernel, tile shape and grouping, so the stats-tile count the caller allocates always matches the launch.
-struct ConvPlan { bool pipe, direct; int R, NT, tiles_y, tiles_x, npt, nct, G; size_t smem; };
+struct ConvPlan { bool pipe, direct, ws; int R, NT, tiles_y, tiles_x, npt, nct, G; size_t smem; };
 ConvPlan conv_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int pre_mode = EGM_PRE_NONE) {
     ConvPlan c;
     if (KH == 1 && KW == 1) dil = 1;
     // prologues the fast kernels are not built with (the BatchNorm-backward form; anything in front of a 7x7) take the generic kernel
     const bool fast_ok = pre_mode == EGM_PRE_NONE || (pre_mode == EGM_PRE_BN_ACT && KH != 7);
+    c.ws = pre_mode == EGM_PRE_NONE && egm_conv_ws_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.nct, &c.G) != 0;
+    if (c.ws) { c.pipe = c.direct = false; c.R = 2; c.NT = 2; c.tiles_y = c.tiles_x = c.npt = 0; c.smem = 0; return c; }
     c.direct = fast_ok && Cin > 0 && egm_conv_direct_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.NT, &c.nct, &c.G, &c.smem) != 0;
     if (c.direct) { c.pipe = false; c.R = 0; c.tiles_y = c.tiles_x = c.npt = 0; return c; }
     c.pipe = fast_ok && pipe_eligible(dtype, KH, KW, dil);
@@ -841,6 +848,7 @@ extern "C" int egm_conv_fwd_pre(int dtype, const void* x, int ldx, int pre_mode,
     p.ldx = ldx; p.ldy = ldy; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.dil = dil; p.bias_n = bias ? bias_n : 0;
     p.pre.mode = pre_mode; p.pre.act = pre_act; p.pre.cf = pre_cf; p.pre.aux = pre_aux; p.pre.ld_aux = pre_ld_aux; p.pre.C = Cin;
     const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, pre_mode);
+    if (c.ws) return egm_conv_ws_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, c.nct, c.G, s);
     if (c.direct)
         return egm_conv_direct_launch(x, ldx, p.pre, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, KH, KW, dil, c.NT,
                                       c.nct, c.G, c.smem, s);
