@@ -11,6 +11,7 @@
 // transpose, 16-byte coalesced stores, per-group BatchNorm partial sums.
 //
 // HBM-bound for the narrow layers (C <= 64), MFMA-bound for 256 -> 256; algorithmic work as for conv_igemm.hip.
+#include <type_traits>
 #include "common.h"
 #include "prologue.h"
 #include <stdlib.h>
@@ -32,7 +33,8 @@ __device__ __forceinline__ bf16x8_t as_frag(uint4 v) { return __builtin_bit_cast
 // PRE (EGM_PRE_NONE / EGM_PRE_BN_ACT, prologue.h): the loaded channel vectors are transformed in registers on their way into the
 // MFMA operand (BatchNorm apply + activation of the producing layer); the coefficient rows sit in LDS behind the out tiles; taps
 // that fall outside the image stay exactly zero.
-template <int NT, int PRE>
+// K1: the 1x1 instantiation (no tap groups: its register count, and with it the occupancy the streaming layers live on, stays low)
+template <int NT, int PRE, bool K1>
 __global__ __launch_bounds__(256) void conv_direct_kernel(DirectParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int OROW = NT * 64 + 16, NV = NT * 4;
@@ -92,7 +94,16 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(DirectParams p) {
     const bool row_blocks = (p.W & 31) == 0;                                 // a 32-pixel block never straddles an image row
     const unsigned char* arow = wts + (size_t)r31 * p.wrow + h * 16;
 
-    for (int blk = grp * 4 + wv; blk < p.nblk; blk += p.G * 4) {
+    // Block order: the pixel blocks are cut into 8 contiguous bands, one per XCD (grp % 8 == blockIdx % 8 == XCD), and the groups of
+    // an XCD sweep their band front to back together, so the nine taps of a dilated conv hit lines the SAME L2 fetched a few rows
+    // earlier (live window = rows in flight + 2 dil rows) instead of every XCD pulling the whole input through its own L2.
+    const bool banded = p.G >= 8;
+    const int xcd = grp & 7, gl = grp >> 3;
+    const int gpx = banded ? (p.G - xcd + 7) >> 3 : p.G;                   // groups on this XCD
+    const int band = banded ? (p.nblk + 7) >> 3 : p.nblk;                    // blocks per band
+    const int blk0 = banded ? xcd * band : 0;
+    const int blk_end = (blk0 + band < p.nblk) ? blk0 + band : p.nblk;
+    for (int blk = blk0 + (banded ? gl : grp) * 4 + wv; blk < blk_end; blk += gpx * 4) {
         const long long pix = (long long)blk * 32 + r31;
         const bool pvalid = pix < npix;
         int n, y, x;
@@ -108,44 +119,71 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(DirectParams p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
 
-        for (int t = 0; t < ntaps; ++t) {
-            const int sy = (t / p.KW - p.KH / 2) * p.dil, sx = (t % p.KW - p.KW / 2) * p.dil;
-            const int ys = y + sy, xs = x + sx;
-            if (row_blocks && (ys < 0 || ys >= p.H)) continue;               // uniform: the whole block's source row is outside
-            const bool ok = pvalid && ys >= 0 && ys < p.H && xs >= 0 && xs < p.W;
-            const bf16_t* src = xg + ((long long)(n * p.H + ys) * p.W + xs) * p.ldx + h * 8;
-            const unsigned char* at = arow + (size_t)t * NT * 32 * p.wrow;
-            for (int k0 = 0; k0 < nks; k0 += 8) {                            // up to 8 k-steps (128 channels) of loads in flight
-                uint4 fb[8];
+        // Taps are loaded TG at a time with KS k-steps each, ALL issued before the first MFMA: with one tap in flight per wave the
+        // kernel was latency-bound (9 dependent round trips per block: 51 us for the 32 -> 32 dilated layers at 8 x 256^2); 16-20
+        // independent 16-byte loads per lane bring that to 41 us.  (Measured dead end, r02: a two-deep software pipeline over
+        // (block, tap group) items with exact vmcnt waits ran 2.4x SLOWER -- 15k instructions per kernel, past the instruction cache.)
+        auto run_taps = [&](auto tg_c, auto ks_c) __attribute__((always_inline)) {
+            constexpr int TG = decltype(tg_c)::value, KS = decltype(ks_c)::value;
+            for (int k0 = 0; k0 < nks; k0 += KS) {
+                for (int t0 = 0; t0 < ntaps; t0 += TG) {
+                    uint4 fb[TG][KS];
+                    bool rowok[TG];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    fb[k] = make_uint4(0, 0, 0, 0);
-                    if (ok && k0 + k < nks && (k0 + k) * 16 + h * 8 < p.Cin) fb[k] = *reinterpret_cast<const uint4*>(src + (k0 + k) * 16);
-                }
-                if (PRE != EGM_PRE_NONE) {
-                    EGM_ACT_SWITCH(p.pre.act,
-                        _Pragma("unroll")
-                        for (int k = 0; k < 8; ++k) {
+                    for (int u = 0; u < TG; ++u) {
+                        const int t = t0 + u;
+                        const int sy = (t / p.KW - p.KH / 2) * p.dil, sx = (t % p.KW - p.KW / 2) * p.dil;
+                        const int ys = y + sy, xs = x + sx;
+                        rowok[u] = t < ntaps && !(row_blocks && (ys < 0 || ys >= p.H));   // uniform: the whole block's source row is outside
+                        const bool ok = t < ntaps && pvalid && ys >= 0 && ys < p.H && xs >= 0 && xs < p.W;
+                        const bf16_t* src = xg + ((long long)(n * p.H + ys) * p.W + xs) * p.ldx + h * 8;
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) {
+                            fb[u][k] = make_uint4(0, 0, 0, 0);
+                            if (ok && k0 + k < nks && (k0 + k) * 16 + h * 8 < p.Cin) fb[u][k] = *reinterpret_cast<const uint4*>(src + (k0 + k) * 16);
+                        }
+                        if (PRE != EGM_PRE_NONE) {
+                            EGM_ACT_SWITCH(p.pre.act,
+                                _Pragma("unroll")
+                                for (int k = 0; k < KS; ++k) {
+                                    if (k0 + k < nks) {
+                                        PreCoef8 kf;
+                                        pre_load_coef8<PRE>(kf, cfl + (k0 + k) * 16 + h * 8, cs);
+                                        const uint4 v = pre_apply8<PRE, ACT>(fb[u][k], fb[u][k], kf, p.pre.act);
+                                        fb[u][k] = ok ? v : make_uint4(0, 0, 0, 0);
+                                    }
+                                });
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < TG; ++u) {
+                        if (!rowok[u]) continue;
+                        const unsigned char* at = arow + (size_t)(t0 + u) * NT * 32 * p.wrow;
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) {
                             if (k0 + k < nks) {
-                                PreCoef8 kf;
-                                pre_load_coef8<PRE>(kf, cfl + (k0 + k) * 16 + h * 8, cs);
-                                const uint4 v = pre_apply8<PRE, ACT>(fb[k], fb[k], kf, p.pre.act);
-                                fb[k] = ok ? v : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) {
+                                    const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(at + (size_t)nt * 32 * p.wrow + (k0 + k) * 32);
+                                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, as_frag(fb[u][k]), acc[nt], 0, 0, 0);
+                                }
                             }
-                        });
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (k0 + k < nks) {
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(at + (size_t)nt * 32 * p.wrow + (k0 + k) * 32);
-                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, as_frag(fb[k]), acc[nt], 0, 0, 0);
                         }
                     }
                 }
             }
-        }
+        };
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>; using I8 = std::integral_constant<int, 8>;
+        using I9 = std::integral_constant<int, 9>;
+        if constexpr (K1) run_taps(I1(), I8());
+        else if (PRE != EGM_PRE_NONE) {                     // the transform's temporaries leave room for fewer loads in flight
+            if (nks > 4) run_taps(I1(), I8());
+            else if (nks <= 2) run_taps(I3(), I2());
+            else run_taps(I2(), I4());
+        } else if (nks <= 2) run_taps(I9(), I2());          // 18 loads in flight
+        else if (nks <= 4) run_taps(I5(), I4());            // 20
+        else run_taps(I2(), I8());                          // 16
 
         // ---- epilogue.  D layout: col (pixel) = lane&31, row (cout) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -200,11 +238,11 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(DirectParams p) {
     }
 }
 
-template <int NT, int PRE>
+template <int NT, int PRE, bool K1>
 int launch_direct_pre(const DirectParams& p, size_t smem, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct_kernel<NT, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct_kernel<NT, PRE, K1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024);
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_direct: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
@@ -212,15 +250,15 @@ int launch_direct_pre(const DirectParams& p, size_t smem, hipStream_t st) {
     if (PRE != EGM_PRE_NONE) smem += (size_t)2 * ((p.Cin + 15) / 16 * 16) * sizeof(float);
     EGM_REQUIRE(smem <= 160 * 1024, "conv_direct: LDS budget exceeded (%zu)", smem);
     const int grid = ((p.G + 7) / 8) * 8 * p.nct;
-    hipLaunchKernelGGL((conv_direct_kernel<NT, PRE>), dim3(grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((conv_direct_kernel<NT, PRE, K1>), dim3(grid), dim3(256), smem, st, p);
     EGM_CHECK_LAUNCH("conv_direct");
     return EGM_OK;
 }
 template <int NT>
 int launch_direct(const DirectParams& p, size_t smem, hipStream_t st) {
-    if (p.pre.mode == EGM_PRE_BN_ACT) return launch_direct_pre<NT, EGM_PRE_BN_ACT>(p, smem, st);
+    if (p.pre.mode == EGM_PRE_BN_ACT) return p.KH == 1 ? launch_direct_pre<NT, EGM_PRE_BN_ACT, true>(p, smem, st) : launch_direct_pre<NT, EGM_PRE_BN_ACT, false>(p, smem, st);
     if (p.pre.mode != EGM_PRE_NONE) EGM_FAIL(EGM_ERR_UNSUPPORTED, "conv_direct: prologue mode %d not built", p.pre.mode);
-    return launch_direct_pre<NT, EGM_PRE_NONE>(p, smem, st);
+    return p.KH == 1 ? launch_direct_pre<NT, EGM_PRE_NONE, true>(p, smem, st) : launch_direct_pre<NT, EGM_PRE_NONE, false>(p, smem, st);
 }
 
 }  // namespace

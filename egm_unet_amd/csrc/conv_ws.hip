@@ -252,7 +252,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsParams p) {
 // Planning shared with conv_igemm.hip's conv_plan(): returns 0 when this kernel does not take the shape.  *G_out = pixel groups
 // (= BatchNorm statistics tiles), *nct_out = cout tiles.
 int egm_conv_ws_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int* nct_out, int* G_out) {
-    static const int on = getenv("EGM_CONV_WS") ? atoi(getenv("EGM_CONV_WS")) : 1;
+    // Off by default: measured 7-11 % SLOWER than the 4-wave pipelined kernel on every wide layer of the headline config (r02,
+    // tools/conv_ab.py: e.g. 256->256 @ 64^2 48.6 vs 43.9 us) -- both kernels read 1 KB of LDS fragments per MFMA (2x2 tiles per
+    // wave), which is the limit either way, and the pipelined kernel keeps two workgroups per CU.  EGM_CONV_WS=1 opts in.
+    static const int on = getenv("EGM_CONV_WS") ? atoi(getenv("EGM_CONV_WS")) : 0;
     if (!on || dtype != EGM_BF16 || KH != 3 || KW != 3 || dil != 1) return 0;
     if (Cin < 64 || Cin % KC != 0 || Cout < 64) return 0;
     const int npt = N * egm_cdiv(H, TH) * egm_cdiv(W, TW);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace CSV: per-kernel totals and the heaviest (kernel, grid) shapes.
-usage: prof_summary.py <kernel_trace.csv> <steps_in_trace> [out.md]"""
+usage: prof_summary.py <kernel_trace.csv> <steps_in_trace> [out.md [timeline.tsv]]"""
 import collections
 import csv
 import re
@@ -23,6 +23,13 @@ def main():
         wins = [(a, b) for a, b in zip(marks, marks[1:])]
         mode = collections.Counter(b - a for a, b in wins).most_common(1)[0][0]
         wins = [(a, b) for a, b in wins if b - a == mode]
+        if len(sys.argv) > 4:                        # timeline: launch order of one step, durations averaged over the windows
+            with open(sys.argv[4], "w") as tl:
+                for j in range(mode):
+                    rs = [rows[a + j] for a, b in wins]
+                    d = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rs) / len(rs) / 1e3
+                    g = int(rs[0]["Grid_Size_X"]) // max(1, int(rs[0]["Workgroup_Size_X"]))
+                    tl.write(f"{j}\t{short(rs[0]['Kernel_Name'])}\t{g}\t{d:.1f}\n")
         rows = [r for a, b in wins for r in rows[a:b]]
         steps = len(wins)
     per_k, per_s = collections.defaultdict(lambda: [0, 0]), collections.defaultdict(lambda: [0, 0])
