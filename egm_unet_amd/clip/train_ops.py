@@ -303,7 +303,7 @@ class AdamW(torch.optim.Optimizer):
                     raise RuntimeError("egm_unet_amd AdamW: parameters of one group must share the step count")
                 g = p.grad if (p.grad.is_contiguous() and p.grad.dtype == torch.float32) else p.grad.contiguous().float()
                 keep.append(g)
-                blob += struct.pack("<QQQQq", p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+                blob += struct.pack("<QQQQqq", p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), chunks)
                 chunks += (p.numel() + ch - 1) // ch
             if not keep:
                 continue

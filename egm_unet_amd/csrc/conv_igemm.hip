@@ -644,22 +644,12 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, T* __restrict__ wf
 
 
 // all convolution weights of a model in ONE launch: table of descriptors, block -> (conv, chunk) by a scan of the chunk counts
-struct PackEntry { const float* w; void* wf; void* wd; int Cout, Cin, CoutP, CinP, KH, KW, groups, pad; };
+struct PackEntry { const float* w; void* wf; void* wd; int Cout, Cin, CoutP, CinP, KH, KW, groups, chunk0; };
 constexpr int kPackChunk = 1024;
 template <typename T>
 __global__ __launch_bounds__(256) void conv_pack_multi_kernel(const PackEntry* __restrict__ tab, int n) {
-    __shared__ int s_t, s_c;
-    if (threadIdx.x == 0) {
-        long long b = blockIdx.x; int t = 0;
-        for (; t < n; ++t) {
-            const long long nch = ((long long)tab[t].KH * tab[t].KW * tab[t].CoutP * tab[t].CinP + kPackChunk - 1) / kPackChunk;
-            if (b < nch) break;
-            b -= nch;
-        }
-        s_t = t; s_c = (int)b;
-    }
-    __syncthreads();
-    if (s_t >= n) return;
+    const int s_t = egm_find_entry(tab, n, (long long)blockIdx.x);
+    const int s_c = (int)((long long)blockIdx.x - (long long)tab[s_t].chunk0);
     const PackEntry e = tab[s_t];
     const long long total = (long long)e.KH * e.KW * e.CoutP * e.CinP;
     const int cin_g = e.Cin / e.groups, cout_g = e.Cout / e.groups;

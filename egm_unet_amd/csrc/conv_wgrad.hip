@@ -775,25 +775,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 
 // deferred reduction of MANY convolutions' slabs in one launch (end of backward): block -> (conv, 64-element chunk)
-struct WredEntry { const float* slab; float* dw; int nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate; };
+struct WredEntry { const float* slab; float* dw; int nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate, chunk0, pad; };
 // block = kWredElems consecutive packed elements of one conv: 64 float4 columns x 4 slab lanes, two slabs per lane in flight.  (One
 // float per lane left 8 KiB in flight per CU: 1 GB of slabs per step read at 2.6 TB/s.)  Summation order per element is fixed:
 // lane sl adds slabs sl, sl+4, ... in order, the four lanes are combined as (0+1)+(2+3).
 constexpr int kWredElems = 256;
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WredEntry* __restrict__ tab, int n) {
     __shared__ float4 red[256];
-    __shared__ int s_t, s_c;
-    if (threadIdx.x == 0) {
-        long long b = blockIdx.x; int t = 0;
-        for (; t < n; ++t) {
-            const long long nch = ((long long)tab[t].taps * tab[t].CoutP * tab[t].CinP + kWredElems - 1) / kWredElems;
-            if (b < nch) break;
-            b -= nch;
-        }
-        s_t = t; s_c = (int)b;
-    }
-    __syncthreads();
-    if (s_t >= n) return;
+    const int s_t = egm_find_entry(tab, n, (long long)blockIdx.x);
+    const int s_c = (int)((long long)blockIdx.x - (long long)tab[s_t].chunk0);
     const WredEntry w = tab[s_t];
     const long long total = (long long)w.taps * w.CoutP * w.CinP;           // multiple of 8 (CinP is)
     const int cin_g = w.CinR / w.groups, cout_g = w.CoutR / w.groups;

@@ -364,23 +364,13 @@ __global__ void ensemble_miou_kernel(const unsigned long long* __restrict__ hist
 }
 
 // ---- fused multi-tensor SGD -----------------------------------------------------------------------------
-struct SgdEntry { float* p; const float* g; float* buf; long long n; };
+struct SgdEntry { float* p; const float* g; float* buf; long long n; long long chunk0; };
 constexpr int kSgdChunk = 2048;                               // elements per block (8 per thread)
 // block b -> (tensor, chunk) by binary search over the running chunk count computed from the table itself
 __global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdEntry* __restrict__ tab, int ntensors, const float* __restrict__ lr_dev,
                                                         float lr, float momentum, float wd, float gscale, int first) {
-    __shared__ int s_t, s_c;
-    if (threadIdx.x == 0) {
-        long long b = blockIdx.x; int t = 0;
-        for (; t < ntensors; ++t) {                           // <= few hundred tensors: a linear scan by one lane is cheap
-            const long long nch = (tab[t].n + kSgdChunk - 1) / kSgdChunk;
-            if (b < nch) break;
-            b -= nch;
-        }
-        s_t = t; s_c = (int)b;
-    }
-    __syncthreads();
-    if (s_t >= ntensors) return;
+    const int s_t = egm_find_entry(tab, ntensors, (long long)blockIdx.x);
+    const int s_c = (int)((long long)blockIdx.x - (long long)tab[s_t].chunk0);
     const SgdEntry e = tab[s_t];
     const float rate = lr_dev ? lr_dev[0] : lr;
     const long long base = (long long)s_c * kSgdChunk;

@@ -174,22 +174,12 @@ __global__ void bce_bwd_kernel(const float* __restrict__ x, const float* __restr
 }
 
 // ---- fused multi-tensor AdamW (decoupled weight decay, torch.optim.AdamW semantics) ----------------------------------------
-struct AdamEntry { float* p; const float* g; float* m; float* v; long long n; };
+struct AdamEntry { float* p; const float* g; float* m; float* v; long long n; long long chunk0; };
 constexpr int kAdamChunk = 2048;
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamEntry* __restrict__ tab, int ntensors, float lr, float b1, float b2, float eps,
                                                           float wd, float bc1, float bc2_sqrt) {
-    __shared__ int s_t, s_c;
-    if (threadIdx.x == 0) {
-        long long b = blockIdx.x; int t = 0;
-        for (; t < ntensors; ++t) {
-            const long long nch = (tab[t].n + kAdamChunk - 1) / kAdamChunk;
-            if (b < nch) break;
-            b -= nch;
-        }
-        s_t = t; s_c = (int)b;
-    }
-    __syncthreads();
-    if (s_t >= ntensors) return;
+    const int s_t = egm_find_entry(tab, ntensors, (long long)blockIdx.x);
+    const int s_c = (int)((long long)blockIdx.x - (long long)tab[s_t].chunk0);
     const AdamEntry e = tab[s_t];
     const long long base = (long long)s_c * kAdamChunk;
     const float step_size = lr / bc1;

@@ -243,7 +243,7 @@ def prepack_model(model, dtype):
         Cout, Cin_g, KH, KW = m.weight.shape
         Cin = Cin_g * m.groups
         blob += struct.pack("<QQQiiiiiiii", m.weight.data_ptr(), wf.data_ptr(), wd.data_ptr(), Cout, Cin, pad8(Cout), pad8(Cin), KH, KW,
-                            m.groups, 0)
+                            m.groups, chunks)                  # last field = index of the entry's first workgroup
         chunks += (KH * KW * pad8(Cout) * pad8(Cin) + chunk - 1) // chunk
     dev = convs[0].weight.device
     table = st["table"].get(bytes(blob), dev)
@@ -314,7 +314,7 @@ def _flush_wgrads(ready_only=False):
     blob, chunks = bytearray(), 0
     per = lib().cdll.egm_wgrad_reduce_chunk()
     for ws, weight, nslab, taps, CoutP, CinP, Cout, Cin, groups, gref, gptr in todo:
-        blob += struct.pack("<QQiiiiiiii", ws.data_ptr(), gptr, nslab, taps, CoutP, CinP, Cout, Cin, groups, 0)
+        blob += struct.pack("<QQiiiiiiiiii", ws.data_ptr(), gptr, nslab, taps, CoutP, CinP, Cout, Cin, groups, 0, chunks, 0)
         chunks += (taps * CoutP * CinP + per - 1) // per
     dev = todo[0][1].device
     _wgrad_table.reserve(dev); _wgrad_table_partial.reserve(dev)      # both exist before any capture can need them

@@ -20,7 +20,7 @@ class SGD(torch.optim.Optimizer):
 
     @staticmethod
     def _alloc_table(cap, dev):
-        return torch.empty((cap, 4), dtype=torch.int64).pin_memory(), torch.empty((cap, 4), dtype=torch.int64, device=dev)
+        return torch.empty((cap, 5), dtype=torch.int64).pin_memory(), torch.empty((cap, 5), dtype=torch.int64, device=dev)
 
     def _device_table(self, slot, rows, dev):
         slot = (ops._table_tag[0],) + slot            # a captured graph's tables are its own (ops.table_namespace)
@@ -67,10 +67,13 @@ class SGD(torch.optim.Optimizer):
             for first in (True, False):
                 if not rows[first]:
                     continue
-                table = self._device_table((gi, first), rows[first], group["params"][0].device)
                 ch = lib().cdll.egm_sgd_chunk()
-                chunks = sum((r[3] + ch - 1) // ch for r in rows[first])
-                lib().call("egm_sgd_multi", ptr(table), len(rows[first]), chunks, ptr(self.lr_dev), float(group["lr"]), float(group["momentum"]),
+                chunks, full = 0, []
+                for r in rows[first]:                # fifth field: index of the tensor's first workgroup
+                    full.append(r + (chunks,))
+                    chunks += (r[3] + ch - 1) // ch
+                table = self._device_table((gi, first), full, group["params"][0].device)
+                lib().call("egm_sgd_multi", ptr(table), len(full), chunks, ptr(self.lr_dev), float(group["lr"]), float(group["momentum"]),
                            float(group["weight_decay"]), float(self.grad_scale), 1 if first else 0, stream())
         ops.bump_weight_generation()
         return loss

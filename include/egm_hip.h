@@ -64,8 +64,9 @@ int egm_nhwc_to_nchw(int dtype, const void* src, int ld, void* dst_f32, int N, i
 int egm_conv_pack(int dtype, const void* w_oihw_f32, void* wf, void* wd, int Cout, int Cin, int KH, int KW, int groups,
                   egm_stream_t s);
 /* Every conv weight of a model in one launch.  table_dev: device array of 56-byte entries
- * {const float* w; void* wf; void* wd; int Cout, Cin, CoutP, CinP, KH, KW, groups, pad;}; total_chunks = sum over entries of
- * ceil(KH*KW*CoutP*CinP / egm_conv_pack_chunk()). */
+ * {const float* w; void* wf; void* wd; int Cout, Cin, CoutP, CinP, KH, KW, groups, chunk0;}; an entry takes
+ * ceil(KH*KW*CoutP*CinP / egm_conv_pack_chunk()) workgroups ("chunks"), chunk0 = the sum of the chunk counts of the entries before
+ * it (the kernels of all *_multi entry points find their entry by binary search on chunk0), total_chunks = the sum over all. */
 int egm_conv_pack_chunk(void);
 int egm_conv_pack_multi(int dtype, const void* table_dev, int n, long long total_chunks, egm_stream_t s);
 /* y = conv(x, wf) (+bias).  Cin/Cout are the PADDED counts of wf.  bias (fp32, bias_n <= Cout valid entries; the rest count as 0) may be NULL.
@@ -100,9 +101,9 @@ int egm_conv_wgrad_pre(int dtype, const void* x, int ldx, int xpre_mode, int xpr
                        void* dy_out, int ld_dy_out, float* dw_oihw_f32, void* workspace, int N, int H, int W, int Cin, int Cout,
                        int CinR, int CoutR, int KH, int KW, int dil, int groups, int accumulate, egm_stream_t s);
 /* Deferred form: egm_conv_wgrad with dw == NULL writes only the partial slabs (egm_conv_wgrad_slabs() of them) into the
- * workspace; egm_wgrad_reduce_multi() then finishes MANY convolutions in one launch.  table_dev: device array of 48-byte
- * entries {const float* slab; float* dw; int nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate;};
- * total_chunks = sum over entries of ceil(taps*CoutP*CinP / egm_wgrad_reduce_chunk()). */
+ * workspace; egm_wgrad_reduce_multi() then finishes MANY convolutions in one launch.  table_dev: device array of 56-byte
+ * entries {const float* slab; float* dw; int nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate, chunk0, pad;};
+ * chunks per entry = ceil(taps*CoutP*CinP / egm_wgrad_reduce_chunk()), chunk0 / total_chunks as for egm_conv_pack_multi. */
 int egm_conv_wgrad_slabs(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
 int egm_wgrad_reduce_chunk(void);   /* packed elements reduced by one workgroup of egm_wgrad_reduce_multi */
 int egm_wgrad_reduce_multi(const void* table_dev, int n, long long total_chunks, egm_stream_t s);
@@ -397,8 +398,9 @@ int egm_ensemble_fuse(const float* clip_logits, const float* unet_logits, float 
 int egm_ensemble_alpha_hist(const float* clip_logits, const float* unet_logits, const long long* target, const float* alphas, int na,
                             int N, int C, int hc, int wc, int H, int W, unsigned long long* hist, egm_stream_t s);
 int egm_ensemble_miou(const unsigned long long* hist, int na, int C, float* miou, egm_stream_t s);
-/* torch.optim.SGD(momentum, weight_decay) (train.py:115-118) over a device table of {float* p; const float* g; float* buf;
- * long long n;} entries: g' = g*grad_scale + wd*p; v = first_step ? g' : mu*v + g'; p -= lr*v.
+/* torch.optim.SGD(momentum, weight_decay) (train.py:115-118) over a device table of 40-byte {float* p; const float* g; float* buf;
+ * long long n; long long chunk0;} entries (chunk0 as for egm_conv_pack_multi): g' = g*grad_scale + wd*p;
+ * v = first_step ? g' : mu*v + g'; p -= lr*v.
  * lr_dev (device scalar) overrides lr when non-NULL. */
 int egm_sgd_chunk(void);   /* elements per workgroup; total_chunks = sum over tensors of ceil(n / egm_sgd_chunk()) */
 int egm_sgd_multi(const void* table_dev, int ntensors, long long total_chunks, const float* lr_dev, float lr, float momentum,
@@ -470,7 +472,7 @@ int egm_augment_u8(const void* img_hwc3, const void* mask_hw, int H, int W, int 
  * dP fp32).  egm_layernorm_bwd: dx and per-block partials [egm_layernorm_bwd_blocks(rows)][2][D] of (dbeta, dgamma) for
  * egm_reduce_tiles.  egm_film_fwd/bwd: out = mul[b,:]*a + add[b,:] and its gradients.  egm_pixel_unshuffle: gradient of
  * egm_pixel_shuffle (rows of the tok_off leading tokens are zero).  egm_bce_logits_*: nn.BCEWithLogitsLoss(mean).
- * egm_adamw_multi: torch.optim.AdamW step over a device table of 40-byte {p, g, m, v, n} entries. */
+ * egm_adamw_multi: torch.optim.AdamW step over a device table of 48-byte {p, g, m, v, n, chunk0} entries. */
 int egm_transpose(int dtype, const void* src, int rows, int cols, int ld_src, long long batch_stride_src, void* dst, int ld_dst,
                   long long batch_stride_dst, int batch, egm_stream_t s);
 int egm_relu_bwd(int dtype, const void* g, const void* out, void* dst, long long n, egm_stream_t s);
