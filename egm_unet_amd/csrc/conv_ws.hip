@@ -5,10 +5,13 @@
 // The 3x3 encoder / decoder convs of the U-Net stacks (src/EGM-UNet.py:49,52,893,899; DoubleConv, DoubleConv1) from 64 channels up,
 // forward and (with the flipped pack `wd`) data gradient: the layers that are MFMA-bound (AI 287 .. 1117 FLOP/B).
 //
-// Same tile as conv_igemm_pipe_kernel<2,3,3,2> -- one workgroup = 8 x 32 pixels x 64 couts, K loop over 32-channel chunks, the
-// (8+2) x (32+2) halo patch and the 9 x 64 weight rows of the chunk in LDS -- but the workgroup has EIGHT waves with two roles
-// (the structure of conv_wgrad_ws_kernel):
-//   * waves 0-3, one per SIMD, are CONSUMERS: their loop holds nothing but LDS fragment reads and 72 MFMAs per stage; no global
+// One workgroup = 16 x 32 pixels x 64 couts, K loop over 16-channel chunks, the (16+2) x (32+2) halo patch and the 9 x 64 weight rows
+// of the chunk in LDS (57 KB per stage, two stages).  The point of the shape is LDS bandwidth: every v_mfma_f32_32x32x16_bf16 (32 clk)
+// of the 8 x 32-pixel kernels (conv_igemm_pipe_kernel<2,3,3,2>, and this kernel's first version) needs 0.83 KB of LDS fragments, i.e.
+// 106 B/clk for four SIMDs plus the staging writes against the CU's 128 B/clk -- they are LDS-bound at 30-45 % MFMA-busy.  With FOUR
+// output rows per consumer wave the six weight fragments of a kernel column and the six patch-row fragments feed 24 MFMAs: 0.5 KB per
+// MFMA.  16-channel chunks keep two stages inside 160 KB.  The workgroup has EIGHT waves with two roles (as conv_wgrad_ws_kernel):
+//   * waves 0-3, one per SIMD, are CONSUMERS (4 rows x 32 pixels x 64 couts each): their loop holds nothing but LDS fragment reads and 72 MFMAs per stage; no global
 //     load, no LDS write, no address arithmetic for staging.  In the 4-wave pipelined kernel the same wave issues the next stage's
 //     global loads before its MFMAs and writes them to LDS after them, behind two barriers per stage: 52 % of its time was the MFMA
 //     loop (tools/diag_conv_phases.py), MFMA-busy 29 % time-weighted (profiles/r02_pmc_mfma_util.json).
@@ -25,17 +28,18 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 namespace {
 
-constexpr int TH = 8, TW = 32, KC = 32, PS = 80;                 // tile, channel chunk, LDS row bytes (32 ch bf16 + 16 B pad)
+constexpr int TH = 16, TW = 32, KC = 16, PS = 48;                // tile, channel chunk, LDS row bytes (16 ch bf16 + 16 B pad)
+constexpr int VPR = KC / 8, RPS = 256 / VPR;                      // 16-byte vectors per LDS row; rows per producer sweep (128)
 constexpr int PH = TH + 2, PW = TW + 2, NT = 2, NTAPS = 9;
-constexpr int PATCH_BYTES = PH * PW * PS;                         // 27200
-constexpr int WROWS = NTAPS * NT * 32, WTS_BYTES = WROWS * PS;    // 576 rows, 46080
-constexpr int STAGE_BYTES = PATCH_BYTES + WTS_BYTES;              // 73280
+constexpr int PATCH_BYTES = PH * PW * PS;                         // 29376
+constexpr int WROWS = NTAPS * NT * 32, WTS_BYTES = WROWS * PS;    // 576 rows, 27648
+constexpr int STAGE_BYTES = PATCH_BYTES + WTS_BYTES;              // 57024
 constexpr int OROW = NT * 64 + 16, OPIX = 16;                     // out tile: 16 pixels x 64 couts per wave and pass
 constexpr int OUT_BYTES = 4 * OPIX * OROW;                        // 9216
-constexpr int PVEC = (PH * PW * 4 + 255) / 256;                   // 6 patch vectors per producer thread
-constexpr int WVEC = (WROWS * 4 + 255) / 256;                     // 9 weight vectors per producer thread
+constexpr int PVEC = (PH * PW * VPR + 255) / 256;                 // 5 patch vectors per producer thread
+constexpr int WVEC = (WROWS * VPR + 255) / 256;                   // 5 weight vectors per producer thread
 static_assert(2 * STAGE_BYTES + OUT_BYTES <= 160 * 1024, "LDS budget");
-static_assert((WROWS * 4) % 256 == 0, "weight slab is a whole number of producer sweeps");
+static_assert(RPS % (NT * 32) == 0, "a producer sweep covers whole taps of the weight slab");
 
 struct WsParams {
     const void* x; const void* w; const float* bias; void* y; float* stats;
@@ -47,7 +51,7 @@ __device__ __forceinline__ bf16x8_t ldfrag(const unsigned char* row, int ks, int
     return *reinterpret_cast<const bf16x8_t*>(row + ks * 32 + h * 16);
 }
 
-__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsParams p) {
+__global__ __launch_bounds__(512) void conv3x3_ws_kernel(WsParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x, q = b >> 3;
     const int ct = q % p.nct;
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsParams p) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wv >= 4;
     const int tpi = p.tiles_y * p.tiles_x;
-    const int nchunks = p.Cin / KC;                                // Cin is a multiple of 32 (host check)
+    const int nchunks = p.Cin / KC;                                // Cin is a multiple of 16 (host check)
     // stage list of this workgroup: (pixel tile grp + k G, chunk c): the same in both roles
     const int ntiles = (p.npt - grp + p.G - 1) / p.G;
     const int nstages = ntiles * nchunks;
@@ -68,13 +72,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsParams p) {
         const int ptid = tid & 255;
         const bf16_t* __restrict__ xg = reinterpret_cast<const bf16_t*>(p.x);
         const bf16_t* __restrict__ wg = reinterpret_cast<const bf16_t*>(p.w);
-        const int lds_off0 = (ptid >> 2) * PS + (ptid & 3) * 16;  // slot k of a thread: vector ptid + 256 k = row (ptid >> 2) + 64 k
-        const bool p_tail_ok = ptid + (PVEC - 1) * 256 < PH * PW * 4;
-        // weight slab row (ptid>>2) + 64 k = tap (k of 9), cout j = ptid >> 2 (64 rows per tap): offsets affine in k
-        const int w_rel0 = ((co0 + (ptid >> 2)) * p.Cin) + (ptid & 3) * 8;
-        const int w_step = p.Cout * p.Cin;
-        const bool w_row_ok = co0 + (ptid >> 2) < p.Cout;
-        uint4 rp[PVEC], rw[WVEC];
+        // slot k of a thread: vector ptid + 256 k = LDS row (ptid / VPR) + RPS k, 16-byte column ptid % VPR
+        const int prow = ptid / VPR, pcol = ptid % VPR;
+        const int lds_off0 = prow * PS + pcol * 16;
+        const bool p_tail_ok = ptid + (PVEC - 1) * 256 < PH * PW * VPR;
+        const bool w_tail_ok = ptid + (WVEC - 1) * 256 < WROWS * VPR;
+        // weight slab row prow + RPS k = tap (RPS / 64) k + prow / 64, cout prow % 64: offsets affine in k
+        const int w_rel0 = (((prow / (NT * 32)) * p.Cout + co0 + prow % (NT * 32)) * p.Cin) + pcol * 8;
+        const int w_step = (RPS / (NT * 32)) * p.Cout * p.Cin;
+        const bool w_row_ok = co0 + prow % (NT * 32) < p.Cout;
+        uint4 rpA[PVEC], rwA[WVEC], rpB[PVEC], rwB[WVEC];          // two stages in flight in registers
         auto opaque = [](int v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
         auto stage_coords = [&](int s, int& n, int& oy0, int& ox0, int& c0) __attribute__((always_inline)) {
             const int t = s / nchunks;
@@ -83,16 +90,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsParams p) {
             n = pt / tpi; const int trem = pt - n * tpi;
             oy0 = (trem / p.tiles_x) * TH; ox0 = (trem % p.tiles_x) * TW;
         };
-        auto issue = [&](int s) __attribute__((always_inline)) {
+        auto issue = [&](int s, uint4 (&rp)[PVEC], uint4 (&rw)[WVEC]) __attribute__((always_inline)) {
             int n, oy0, ox0, c0;
             stage_coords(s, n, oy0, ox0, c0);
             const int tix = opaque(ptid);                           // keeps the slot arithmetic inside the loop (see conv_wgrad.hip)
             const int y0 = oy0 - 1, x0 = ox0 - 1;
             const bool interior = y0 >= 0 && y0 + PH <= p.H && x0 >= 0 && x0 + PW <= p.W;
-            const bf16_t* base = xg + ((long long)(n * p.H + y0) * p.W + x0) * p.ldx + c0 + (tix & 3) * 8;
+            const bf16_t* base = xg + ((long long)(n * p.H + y0) * p.W + x0) * p.ldx + c0 + (tix % VPR) * 8;
 #pragma unroll
             for (int k = 0; k < PVEC; ++k) {
-                const int pix = (tix >> 2) + 64 * k, py = pix / PW, px = pix - py * PW;
+                const int pix = tix / VPR + RPS * k, py = pix / PW, px = pix - py * PW;
                 bool ok = k < PVEC - 1 || p_tail_ok;
                 if (!interior) ok = ok && y0 + py >= 0 && y0 + py < p.H && x0 + px >= 0 && x0 + px < p.W;
                 rp[k] = make_uint4(0, 0, 0, 0);
@@ -102,28 +109,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsParams p) {
 #pragma unroll
             for (int k = 0; k < WVEC; ++k) {
                 rw[k] = make_uint4(0, 0, 0, 0);
-                if (w_row_ok) rw[k] = *reinterpret_cast<const uint4*>(wbase + w_rel0 + k * w_step);
+                if (w_row_ok && (k < WVEC - 1 || w_tail_ok)) rw[k] = *reinterpret_cast<const uint4*>(wbase + w_rel0 + k * w_step);
             }
         };
-        auto write = [&](int buf) __attribute__((always_inline)) {
+        auto write = [&](int buf, uint4 (&rp)[PVEC], uint4 (&rw)[WVEC]) __attribute__((always_inline)) {
             unsigned char* patch = smem + buf * STAGE_BYTES;
             unsigned char* wts = patch + PATCH_BYTES;
 #pragma unroll
             for (int k = 0; k < PVEC; ++k)
-                if (k < PVEC - 1 || p_tail_ok) *reinterpret_cast<uint4*>(patch + lds_off0 + k * 64 * PS) = rp[k];
+                if (k < PVEC - 1 || p_tail_ok) *reinterpret_cast<uint4*>(patch + lds_off0 + k * RPS * PS) = rp[k];
 #pragma unroll
-            for (int k = 0; k < WVEC; ++k) *reinterpret_cast<uint4*>(wts + lds_off0 + k * 64 * PS) = rw[k];
+            for (int k = 0; k < WVEC; ++k)
+                if (k < WVEC - 1 || w_tail_ok) *reinterpret_cast<uint4*>(wts + lds_off0 + k * RPS * PS) = rw[k];
         };
-        // producers run one stage ahead in LDS and two ahead in registers
-        if (nstages > 0) issue(0);
-        if (nstages > 0) { write(0); if (nstages > 1) issue(1); }
+        // producers run one stage ahead in LDS and THREE ahead in registers: stage s+1 is written from the set that then takes the
+        // loads of stage s+3, so a load has two whole stage periods to land (one period left the L2 / HBM latency exposed:
+        // 1.2 us per stage with idle consumers against ~1 us of MFMA work)
+        if (nstages > 0) issue(0, rpA, rwA);
+        if (nstages > 1) issue(1, rpB, rwB);
+        if (nstages > 0) { write(0, rpA, rwA); if (nstages > 2) issue(2, rpA, rwA); }
         __syncthreads();
-        for (int s = 0; s < nstages; ++s) {
-            if (s + 1 < nstages) {
-                write((s + 1) & 1);
-                if (s + 2 < nstages) issue(s + 2);
+        for (int s = 0; s < nstages; s += 2) {
+            if (s + 1 < nstages) {                                  // stage s is being multiplied
+                write((s + 1) & 1, rpB, rwB);
+                if (s + 3 < nstages) issue(s + 3, rpB, rwB);
             }
             __syncthreads();
+            if (s + 1 < nstages) {                                  // stage s + 1 is being multiplied
+                if (s + 2 < nstages) {
+                    write(s & 1, rpA, rwA);
+                    if (s + 4 < nstages) issue(s + 4, rpA, rwA);
+                }
+                __syncthreads();
+            }
         }
         if (p.stats != nullptr) { __syncthreads(); __syncthreads(); }   // the consumers' statistics reduction
         return;
@@ -132,13 +150,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsParams p) {
     // ---- consumers
     const int cw = wv, r31 = lane & 31, h = lane >> 5;
     bf16_t* __restrict__ yg = reinterpret_cast<bf16_t*>(p.y);
-    constexpr int R = 2, NV = NT * 4;
+    constexpr int R = TH / 4, NV = NT * 4;                          // output rows per consumer wave
     f32x16_t acc[R][NT];
-    float ssum[8], ssq[8], bias8[8];
+    float ssum[8], ssq[8];
     zero8(ssum); zero8(ssq);
     const int cv = lane % NV, slot = lane / NV;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const int co = co0 + cv * 8 + j; bias8[j] = (p.bias != nullptr && co < p.bias_n) ? p.bias[co] : 0.f; }
     unsigned char* ot = outt + cw * OPIX * OROW;
     __syncthreads();
     for (int s = 0; s < nstages; ++s) {
@@ -154,29 +170,47 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsParams p) {
         const unsigned char* patch = smem + (s & 1) * STAGE_BYTES;
         const unsigned char* brow = patch + ((R * cw) * PW + r31) * PS;
         const unsigned char* arow = patch + PATCH_BYTES + r31 * PS;
-        // A = weights (rows = couts), B = patch (cols = pixels); per k-step and kernel column the weight fragments of the three kernel
-        // rows stay in registers across the four patch rows (0.83 LDS fragment reads per MFMA)
+        // A = weights (rows = couts), B = patch (cols = pixels).  A fragment SET = one (k-step, kernel column): the weight fragments of
+        // the three kernel rows (x NT) and the R + 2 patch-row fragments, 12 reads feeding 24 MFMAs.  Two sets are in flight: the reads
+        // of set i+1 are issued before the MFMAs of set i (left to the compiler the loop ran at 62 clk per MFMA: reads and MFMAs
+        // alternate behind lgkmcnt(1) waits).
+        constexpr int NSET = (KC / 16) * 3;
+        bf16x8_t faA[3][NT], fbA[R + 2], faB[3][NT], fbB[R + 2];
+        auto load_set = [&](int i, bf16x8_t (&fa)[3][NT], bf16x8_t (&fb)[R + 2]) __attribute__((always_inline)) {
+            const int ks = i / 3, ws = i - ks * 3;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+            for (int wr = 0; wr < 3; ++wr)
 #pragma unroll
-            for (int ws = 0; ws < 3; ++ws) {
-                bf16x8_t fa[3][NT];
+                for (int n2 = 0; n2 < NT; ++n2) fa[wr][n2] = ldfrag(arow + ((wr * 3 + ws) * NT + n2) * 32 * PS, ks, h);
 #pragma unroll
-                for (int wr = 0; wr < 3; ++wr)
+            for (int rho = 0; rho < R + 2; ++rho) fb[rho] = ldfrag(brow + (rho * PW + ws) * PS, ks, h);
+        };
+        auto mfma_set = [&](bf16x8_t (&fa)[3][NT], bf16x8_t (&fb)[R + 2]) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int n2 = 0; n2 < NT; ++n2) fa[wr][n2] = ldfrag(arow + ((wr * 3 + ws) * NT + n2) * 32 * PS, ks, h);
+            for (int rho = 0; rho < R + 2; ++rho)
 #pragma unroll
-                for (int rho = 0; rho < R + 2; ++rho) {
-                    const bf16x8_t fb = ldfrag(brow + (rho * PW + ws) * PS, ks, h);
+                for (int m = 0; m < R; ++m) {
+                    const int wr = rho - m;
+                    if (wr >= 0 && wr < 3) {
 #pragma unroll
-                    for (int m = 0; m < R; ++m) {
-                        const int wr = rho - m;
-                        if (wr >= 0 && wr < 3) {
-#pragma unroll
-                            for (int n2 = 0; n2 < NT; ++n2) acc[m][n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[wr][n2], fb, acc[m][n2], 0, 0, 0);
-                        }
+                        for (int n2 = 0; n2 < NT; ++n2) acc[m][n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[wr][n2], fb[rho], acc[m][n2], 0, 0, 0);
                     }
                 }
+        };
+        {
+            load_set(0, faA, fbA);
+#pragma unroll
+            for (int i = 0; i < NSET; ++i) {
+                if (i & 1) {
+                    if (i + 1 < NSET) load_set(i + 1, faA, fbA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_set(faB, fbB);
+                } else {
+                    if (i + 1 < NSET) load_set(i + 1, faB, fbB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_set(faA, fbA);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (c == nchunks - 1) {
@@ -209,9 +243,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsParams p) {
                         float v[8];
                         load8(reinterpret_cast<const bf16_t*>(ot + pl * OROW + cv * 16), v);
                         if (oy < p.H && ox < p.W && co < p.Cout) {
-                            if (p.bias != nullptr) {
+                            if (p.bias != nullptr) {                    // rare on this path (convs in front of a BatchNorm have no bias): read here
 #pragma unroll
-                                for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<bf16_t>(v[j] + bias8[j]));
+                                for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<bf16_t>(v[j] + (co + j < p.bias_n ? p.bias[co + j] : 0.f)));
                             }
                             store8(yg + ((long long)(n * p.H + oy) * p.W + ox) * p.ldy + co, v);
 #pragma unroll
@@ -252,16 +286,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(WsParams p) {
 // Planning shared with conv_igemm.hip's conv_plan(): returns 0 when this kernel does not take the shape.  *G_out = pixel groups
 // (= BatchNorm statistics tiles), *nct_out = cout tiles.
 int egm_conv_ws_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int* nct_out, int* G_out) {
-    // Off by default: measured 7-11 % SLOWER than the 4-wave pipelined kernel on every wide layer of the headline config (r02,
-    // tools/conv_ab.py: e.g. 256->256 @ 64^2 48.6 vs 43.9 us) -- both kernels read 1 KB of LDS fragments per MFMA (2x2 tiles per
-    // wave), which is the limit either way, and the pipelined kernel keeps two workgroups per CU.  EGM_CONV_WS=1 opts in.
+    // Off by default: measured 5-10 % SLOWER than the 4-wave pipelined kernel on every wide layer of the headline config (r02,
+    // tools/conv_ab.py: 256->256 @ 64^2 48.1 vs 43.9 us, 128->128 @ 128^2 52.1 vs 47.2), in both forms tried (8 x 32 tiles with
+    // 32-channel stages; this 16 x 32 / 16-channel form with 40 % fewer LDS fragment bytes and two fragment sets in flight -- same
+    // time, so neither LDS bandwidth nor LDS latency is the limit).  Phase elimination on 256->256 @ 64^2 (one pixel tile and 16 stages
+    // per workgroup): empty stage loop 8.2 us, + producers 27.9 (load latency, hidden once the consumers work), MFMA + epilogue
+    // without producers 38.5, everything 48.1.  At one workgroup per CU the 8 us of launch / first-stage latency / statistics
+    // reduction and the ~5 us epilogue of every workgroup are exposed, and the MFMA loop itself runs at ~52 clk per MFMA; the
+    // pipelined kernel hides one workgroup's prologue and epilogue behind its co-resident twin.  EGM_CONV_WS=1 opts in.
     static const int on = getenv("EGM_CONV_WS") ? atoi(getenv("EGM_CONV_WS")) : 0;
     if (!on || dtype != EGM_BF16 || KH != 3 || KW != 3 || dil != 1) return 0;
     if (Cin < 64 || Cin % KC != 0 || Cout < 64) return 0;
     const int npt = N * egm_cdiv(H, TH) * egm_cdiv(W, TW);
     const int nct = egm_cdiv(Cout, NT * 32);
     if ((long long)npt * nct < 256) return 0;                       // too little work to fill the chip one workgroup per CU
-    int g = (256 / nct) / 8 * 8;                                    // one workgroup per CU (156 KB of LDS each)
+    int g = (256 / nct) / 8 * 8;                                    // one workgroup per CU (123 KB of LDS each)
     if (g < 8) g = 8;
     if (g > npt) g = npt;
     *nct_out = nct; *G_out = g;
