@@ -609,6 +609,79 @@ __global__ __launch_bounds__(256) void sa_conv7_bwd_w_final_kernel(const float* 
 
 inline int group_for(int ncv) { int g = 1; while (g < ncv) g <<= 1; return g; }
 
+// ---- ChannelAttentionModule.fc on the pooled rows (src/EGM-UNet.py:1171-1190): logits = W2 . relu(W0 . p), R = 2N rows of C channels,
+// hidden width Cr = C / reduction.  The rows are 16 x 16..128 numbers: as two 1x1 conv launches + a ReLU launch (+ their weight packs,
+// data and weight gradient launches in backward) they were 7 forward and 9 backward launches of a few workgroups each; here ONE
+// workgroup does the forward and ONE the backward (weights in fp32, h rounded to the storage type like the activation it replaces).
+template <typename T>
+__global__ __launch_bounds__(256) void ca_mlp_fwd_kernel(const T* __restrict__ pooled, int ldp, const float* __restrict__ w0,
+                                                         const float* __restrict__ w2, float* __restrict__ h_out, T* __restrict__ logits,
+                                                         int ldo, int R, int C, int Cr) {
+    extern __shared__ float ca_smem[];
+    float* sp = ca_smem;                 // [R][C]
+    float* sh = ca_smem + R * C;         // [R][Cr]
+    for (int i = threadIdx.x; i < R * C; i += 256) { const int r = i / C, c = i - r * C; sp[i] = to_f32(pooled[(long long)r * ldp + c]); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * Cr; i += 256) {
+        const int r = i / Cr, j = i - r * Cr;
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a = fmaf(w0[j * C + c], sp[r * C + c], a);
+        a = to_f32(from_f32<T>(a));
+        a = a > 0.f ? a : 0.f;
+        sh[i] = a; h_out[i] = a;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * C; i += 256) {
+        const int r = i / C, c = i - r * C;
+        float a = 0.f;
+        for (int j = 0; j < Cr; ++j) a = fmaf(w2[c * Cr + j], sh[r * Cr + j], a);
+        logits[(long long)r * ldo + c] = from_f32<T>(a);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ca_mlp_bwd_kernel(const T* __restrict__ dl, int ldd, const T* __restrict__ pooled, int ldp,
+                                                         const float* __restrict__ h, const float* __restrict__ w0,
+                                                         const float* __restrict__ w2, float* __restrict__ dw0, float* __restrict__ dw2,
+                                                         T* __restrict__ dpooled, int lddp, int R, int C, int Cr) {
+    extern __shared__ float ca_smem[];
+    float* sdl = ca_smem;                // [R][C]
+    float* sp = sdl + R * C;             // [R][C]
+    float* sh = sp + R * C;              // [R][Cr]
+    float* sdh = sh + R * Cr;            // [R][Cr]
+    for (int i = threadIdx.x; i < R * C; i += 256) {
+        const int r = i / C, c = i - r * C;
+        sdl[i] = to_f32(dl[(long long)r * ldd + c]); sp[i] = to_f32(pooled[(long long)r * ldp + c]);
+    }
+    for (int i = threadIdx.x; i < R * Cr; i += 256) sh[i] = h[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * Cr; i += 256) {                    // dh = (W2^T dl) . relu'(h), rounded like the activation gradient
+        const int r = i / Cr, j = i - r * Cr;
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a = fmaf(w2[c * Cr + j], sdl[r * C + c], a);
+        a = to_f32(from_f32<T>(a));
+        sdh[i] = sh[i] > 0.f ? a : 0.f;
+    }
+    for (int i = threadIdx.x; i < C * Cr; i += 256) {                    // dW2[c][j] = sum_r dl[r][c] h[r][j]
+        const int c = i / Cr, j = i - c * Cr;
+        float a = 0.f;
+        for (int r = 0; r < R; ++r) a = fmaf(sdl[r * C + c], sh[r * Cr + j], a);
+        dw2[i] = a;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Cr * C; i += 256) {                    // dW0[j][c] = sum_r dh[r][j] p[r][c]
+        const int j = i / C, c = i - j * C;
+        float a = 0.f;
+        for (int r = 0; r < R; ++r) a = fmaf(sdh[r * Cr + j], sp[r * C + c], a);
+        dw0[i] = a;
+    }
+    for (int i = threadIdx.x; i < R * C; i += 256) {                     // dp = W0^T dh
+        const int r = i / C, c = i - r * C;
+        float a = 0.f;
+        for (int j = 0; j < Cr; ++j) a = fmaf(w0[j * C + c], sdh[r * Cr + j], a);
+        dpooled[(long long)r * lddp + c] = from_f32<T>(a);
+    }
+}
+
 }  // namespace
 
 #define EGM_REQ_VEC(name, ptr, ld, C)                                                                      \
@@ -774,6 +847,28 @@ extern "C" int egm_global_avgmax_bwd(int dtype, const void* gout, const int* arg
     return EGM_OK;
 }
 
+extern "C" int egm_ca_mlp_fwd(int dtype, const void* pooled, int ldp, const float* w0, const float* w2, float* h, void* logits, int ldo, int R,
+                              int C, int Cr, egm_stream_t s) {
+    EGM_REQUIRE(pooled && w0 && w2 && h && logits, "ca_mlp_fwd: null pointer");
+    EGM_REQUIRE(R > 0 && C > 0 && Cr > 0 && ldp >= C && ldo >= C, "ca_mlp_fwd: bad shape R=%d C=%d Cr=%d", R, C, Cr);
+    const size_t smem = (size_t)(R * C + R * Cr) * sizeof(float);
+    EGM_REQUIRE(smem <= 64 * 1024, "ca_mlp_fwd: %d rows x %d channels do not fit one workgroup's LDS", R, C);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ca_mlp_fwd_kernel<T>), dim3(1), dim3(256), smem, (hipStream_t)s, (const T*)pooled, ldp, w0, w2, h,
+                                                 (T*)logits, ldo, R, C, Cr));
+    EGM_CHECK_LAUNCH("ca_mlp_fwd");
+    return EGM_OK;
+}
+extern "C" int egm_ca_mlp_bwd(int dtype, const void* dlogits, int ldd, const void* pooled, int ldp, const float* h, const float* w0,
+                              const float* w2, float* dw0, float* dw2, void* dpooled, int lddp, int R, int C, int Cr, egm_stream_t s) {
+    EGM_REQUIRE(dlogits && pooled && h && w0 && w2 && dw0 && dw2 && dpooled, "ca_mlp_bwd: null pointer");
+    EGM_REQUIRE(R > 0 && C > 0 && Cr > 0 && ldd >= C && ldp >= C && lddp >= C, "ca_mlp_bwd: bad shape R=%d C=%d Cr=%d", R, C, Cr);
+    const size_t smem = (size_t)(2 * R * C + 2 * R * Cr) * sizeof(float);
+    EGM_REQUIRE(smem <= 64 * 1024, "ca_mlp_bwd: %d rows x %d channels do not fit one workgroup's LDS", R, C);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ca_mlp_bwd_kernel<T>), dim3(1), dim3(256), smem, (hipStream_t)s, (const T*)dlogits, ldd,
+                                                 (const T*)pooled, ldp, h, w0, w2, dw0, dw2, (T*)dpooled, lddp, R, C, Cr));
+    EGM_CHECK_LAUNCH("ca_mlp_bwd");
+    return EGM_OK;
+}
 extern "C" int egm_fusion_combine_fwd(int dtype, const void* f, int ldf, const void* sv, int lds, const void* sa, int ldsa, const void* ca,
                                       void* out, int ldo, int N, long long HW, int C, egm_stream_t s) {
     EGM_REQ_VEC("fusion_combine_fwd", f, ldf, C); EGM_REQ_VEC("fusion_combine_fwd", sv, lds, C); EGM_REQ_VEC("fusion_combine_fwd", sa, ldsa, 8);

@@ -101,12 +101,11 @@ class ChannelAttentionModule(nn.Module):
         self.fc = nn.Sequential(nn.Conv2d(in_channels, in_channels // reduction, 1, bias=False), nn.ReLU(inplace=True),
                                 nn.Conv2d(in_channels // reduction, in_channels, 1, bias=False))
         self.sigmoid = nn.Sigmoid()
+        self.fc[0]._egm_no_prepack = self.fc[2]._egm_no_prepack = True      # read as fp32 matrices by egm_ca_mlp_*, never a conv launch
 
     def logits(self, f):
         """-> [2N,1,1,C]: fc(avg_pool) stacked over fc(max_pool); the sigmoid of their sum is applied in fusion_combine."""
-        pooled = ops.global_avgmax(f)
-        h = ops.act(ops.conv2d(pooled, self.fc[0].weight), ACT_RELU)
-        return ops.conv2d(h, self.fc[2].weight)
+        return ops.ca_mlp(ops.global_avgmax(f), self.fc[0].weight, self.fc[2].weight)
 
 
 class SpatialAttentionModule(nn.Module):

@@ -1359,6 +1359,38 @@ def global_avgmax(x):
     return _GlobalAvgMax.apply(x)
 
 
+class _CaMlp(Function):
+    """ChannelAttentionModule.fc on the pooled rows [R,1,1,C]: W2 . relu(W0 . p) as one launch forward, one backward (egm_ca_mlp_*)."""
+
+    @staticmethod
+    def forward(ctx, pooled, w0, w2):
+        R, Cp = pooled.shape[0], pooled.shape[3]
+        Cr, C = w0.shape[0], w0.shape[1]
+        pooled = pooled.contiguous()
+        w0c, w2c = w0.detach().contiguous(), w2.detach().contiguous()
+        h = torch.empty((R, Cr), dtype=torch.float32, device=pooled.device)
+        out = (torch.empty if Cp == C else torch.zeros)((R, 1, 1, Cp), dtype=pooled.dtype, device=pooled.device)
+        lib().call("egm_ca_mlp_fwd", dtype_code(pooled.dtype), ptr(pooled), Cp, ptr(w0c), ptr(w2c), ptr(h), ptr(out), Cp, R, C, Cr, stream())
+        ctx.save_for_backward(pooled, h, w0c, w2c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pooled, h, w0, w2 = ctx.saved_tensors
+        R, Cp = pooled.shape[0], pooled.shape[3]
+        Cr, C = w0.shape[0], w0.shape[1]
+        g = g.contiguous()
+        dw0, dw2 = torch.empty_like(w0), torch.empty_like(w2)
+        dp = (torch.empty if Cp == C else torch.zeros)(pooled.shape, dtype=pooled.dtype, device=pooled.device)
+        lib().call("egm_ca_mlp_bwd", dtype_code(pooled.dtype), ptr(g), Cp, ptr(pooled), Cp, ptr(h), ptr(w0), ptr(w2), ptr(dw0), ptr(dw2),
+                   ptr(dp), Cp, R, C, Cr, stream())
+        return dp, dw0, dw2
+
+
+def ca_mlp(pooled, w0, w2):
+    return _CaMlp.apply(pooled, w0, w2)
+
+
 class _FusionCombine(Function):
     """f + s*sigmoid(sa[...,0])*sigmoid(ca_avg + ca_max); ca: [2N,1,1,C]."""
 

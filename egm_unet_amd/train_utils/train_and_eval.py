@@ -65,7 +65,10 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch, num_classes, l
     step, step_shape = None, None
     pending = None                      # (pinned loss buffer, event, lr) of the step whose loss has not been read yet
     if use_graph:
-        lr_pinned = torch.zeros(1, dtype=torch.float32).pin_memory()
+        # two pinned lr scalars used in turn, each rewritten only after the upload that last read it has executed (the device runs
+        # up to a step behind the host: a single buffer let the copy of step i pick up the learning rate of step i+1)
+        lr_pinned = [torch.zeros(1, dtype=torch.float32).pin_memory() for _ in range(2)]
+        lr_events = [None, None]
         # a step captured in an earlier epoch is reused while model, optimizer, precision and class count are the same objects / values
         # (its graph holds the pointer of ITS lr scalar, so that tensor comes back with it)
         import weakref
@@ -89,8 +92,14 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch, num_classes, l
     for image, target in metric_logger.log_every(data_loader, print_freq, header):
         image, target = image.to(device, non_blocking=True), target.to(device, non_blocking=True)
         if use_graph:
-            lr_pinned[0] = optimizer.param_groups[0]["lr"]
-            optimizer.lr_dev.copy_(lr_pinned, non_blocking=True)
+            k = it & 1
+            if lr_events[k] is not None:
+                lr_events[k].synchronize()
+            lr_pinned[k][0] = optimizer.param_groups[0]["lr"]
+            optimizer.lr_dev.copy_(lr_pinned[k], non_blocking=True)
+            if lr_events[k] is None:
+                lr_events[k] = torch.cuda.Event()
+            lr_events[k].record()
         shape = (tuple(image.shape), tuple(target.shape), image.dtype, target.dtype)
         if use_graph and step is not None and shape == step_shape:
             loss = step(image, target)                            # one hipGraph launch

@@ -274,6 +274,13 @@ int egm_global_avgmax_fwd(int dtype, const void* x, int ldx, void* out, int* arg
                           int C, egm_stream_t s);
 int egm_global_avgmax_bwd(int dtype, const void* gout, const int* argidx, void* dx, int lddx, int N, long long HW, int C,
                           egm_stream_t s);
+/* ChannelAttentionModule.fc (src/EGM-UNet.py:1171-1190) on the R = 2N pooled rows: logits = W2 . relu(W0 . pooled).  w0 fp32 [Cr][C],
+ * w2 fp32 [C][Cr] (the 1x1 conv weights as stored), h fp32 [R][Cr] = the hidden activation kept for backward.  One workgroup each;
+ * (R*C + R*Cr) floats (forward) / twice that (backward) must fit 64 KB of LDS.  Backward OVERWRITES dw0 / dw2. */
+int egm_ca_mlp_fwd(int dtype, const void* pooled, int ldp, const float* w0, const float* w2, float* h, void* logits, int ldo, int R,
+                   int C, int Cr, egm_stream_t s);
+int egm_ca_mlp_bwd(int dtype, const void* dlogits, int ldd, const void* pooled, int ldp, const float* h, const float* w0,
+                   const float* w2, float* dw0, float* dw2, void* dpooled, int lddp, int R, int C, int Cr, egm_stream_t s);
 /* out = f + s*sigmoid(sa[..,0])*sigmoid(ca[n][c] + ca[N+n][c])   (x_out = up(res + x_fused_s * x_fused_c), :1232-1235).
  * backward: ds, dsa (8-channel map) and per-image partial tiles [N][nblk][2][C] of dca (row 0; reduce with
  * egm_reduce_tiles per image); nblk = egm_fusion_combine_blocks(HW, C).  df is g itself. */
