@@ -14,6 +14,8 @@
 #include <type_traits>
 #include "common.h"
 #include "prologue.h"
+#include "group.h"
+#include <string.h>
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -35,10 +37,10 @@ __device__ __forceinline__ bf16x8_t as_frag(uint4 v) { return __builtin_bit_cast
 // that fall outside the image stay exactly zero.
 // K1: the 1x1 instantiation (no tap groups: its register count, and with it the occupancy the streaming layers live on, stays low)
 template <int NT, int PRE, bool K1>
-__global__ __launch_bounds__(256) void conv_direct_kernel(DirectParams p) {
+__device__ __forceinline__ void conv_direct_body(const DirectParams& p, const int b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int OROW = NT * 64 + 16, NV = NT * 4;
-    const int b = blockIdx.x, q = b >> 3;
+    const int q = b >> 3;
     const int ct = q % p.nct;
     const int grp = (q / p.nct) * 8 + (b & 7);                              // b % 8 == grp % 8: cout tiles of a group share an XCD
     if (grp >= p.G) return;
@@ -239,6 +241,48 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(DirectParams p) {
 }
 
 template <int NT, int PRE, bool K1>
+__global__ __launch_bounds__(256) void conv_direct_kernel(DirectParams p) {
+    conv_direct_body<NT, PRE, K1>(p, blockIdx.x);
+}
+// merged launch of up to EGM_GROUP_MAX independent convolutions (group.h): member i owns blocks [blk0[i], blk0[i+1])
+struct DirectMulti { DirectParams p[EGM_GROUP_MAX]; int blk0[EGM_GROUP_MAX + 1]; int n; };
+template <int NT, bool K1>
+__global__ __launch_bounds__(256) void conv_direct_multi_kernel(DirectMulti m) {
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.blk0[i + 1]) ++i;
+    conv_direct_body<NT, EGM_PRE_NONE, K1>(m.p[i], (int)blockIdx.x - m.blk0[i]);
+}
+
+template <int NT, bool K1>
+int launch_direct_group(const EgmGroupRec* recs, int n, hipStream_t st) {
+    if (n == 1) {
+        DirectParams first;
+        memcpy(&first, recs[0].params, sizeof(DirectParams));
+        hipLaunchKernelGGL((conv_direct_kernel<NT, EGM_PRE_NONE, K1>), dim3(recs[0].grid), dim3(256), recs[0].smem, st, first);
+        EGM_CHECK_LAUNCH("conv_direct");
+        return EGM_OK;
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct_multi_kernel<NT, K1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_direct_multi: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    DirectMulti m;
+    size_t smem = 0;
+    m.n = n; m.blk0[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        memcpy(&m.p[i], recs[i].params, sizeof(DirectParams));
+        m.blk0[i + 1] = m.blk0[i] + recs[i].grid;                      // grids are multiples of 8: every member starts on XCD 0
+        if (recs[i].smem > smem) smem = recs[i].smem;
+    }
+    for (int i = n; i < EGM_GROUP_MAX; ++i) { m.p[i] = m.p[0]; m.blk0[i + 1] = m.blk0[n]; }
+    hipLaunchKernelGGL((conv_direct_multi_kernel<NT, K1>), dim3(m.blk0[n]), dim3(256), smem, st, m);
+    EGM_CHECK_LAUNCH("conv_direct_multi");
+    return EGM_OK;
+}
+template <int NT, int PRE, bool K1>
 int launch_direct_pre(const DirectParams& p, size_t smem, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
@@ -250,6 +294,17 @@ int launch_direct_pre(const DirectParams& p, size_t smem, hipStream_t st) {
     if (PRE != EGM_PRE_NONE) smem += (size_t)2 * ((p.Cin + 15) / 16 * 16) * sizeof(float);
     EGM_REQUIRE(smem <= 160 * 1024, "conv_direct: LDS budget exceeded (%zu)", smem);
     const int grid = ((p.G + 7) / 8) * 8 * p.nct;
+    if constexpr (PRE == EGM_PRE_NONE) {
+        if (egm_group_recording()) {                                   // launched by egm_group_end(), merged with its siblings
+            static_assert(sizeof(DirectParams) <= sizeof(EgmGroupRec::params), "group record too small");
+            EgmGroupRec r;
+            r.launch = &launch_direct_group<NT, K1>;
+            memcpy(r.params, &p, sizeof(DirectParams));
+            r.G = p.G; r.grid = grid; r.smem = smem;
+            egm_group_push(r);
+            return EGM_OK;
+        }
+    }
     hipLaunchKernelGGL((conv_direct_kernel<NT, PRE, K1>), dim3(grid), dim3(256), smem, st, p);
     EGM_CHECK_LAUNCH("conv_direct");
     return EGM_OK;

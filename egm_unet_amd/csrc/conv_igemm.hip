@@ -24,6 +24,8 @@
 // f32 : v_mfma_f32_32x32x2_f32   (exact fp32 FMA chain; the parity path)
 #include "common.h"
 #include "prologue.h"
+#include "group.h"
+#include <string.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -279,8 +281,10 @@ template <int WH, int WW, int R> struct PipeGeom {
 //     LDS write -- BatchNorm apply + activation of the producing layer -- so the producer's apply pass and its tensor never exist;
 //     the per-channel coefficient rows sit in LDS behind the weights.  (The BatchNorm-backward form is not built here: a data
 //     gradient reads the dy its weight-gradient kernel materialises as a by-product, conv_wgrad.hip.)
+// The kernel body; `b` = the workgroup's index within THIS convolution (blockIdx.x, or blockIdx.x minus the member's first block in a
+// merged launch, group.h).
 template <int NT, int WH, int WW, int R, int PRE>
-__global__ __launch_bounds__(256, (R * NT >= 8) ? 1 : 2) void conv_igemm_pipe_kernel(ConvParams p, int G) {
+__device__ __forceinline__ void conv_igemm_pipe_body(const ConvParams& p, const int G, const int b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using Gm = PipeGeom<WH, WW, R>;
     using M = Mma<bf16_t>;
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(256, (R * NT >= 8) ? 1 : 2) void conv_igemm_pipe_ke
     constexpr int OROW = NT * 64 + 16;                                        // out-tile row bytes (NT*32 bf16 + pad)
     constexpr int NV = NT * 4;                                                // 16-byte vectors per output pixel
 
-    const int b = blockIdx.x, q = b >> 3;
+    const int q = b >> 3;
     const int ct = q % p.nct;
     const int grp = (q / p.nct) * 8 + (b & 7);                                // pixel group; b % 8 == grp % 8 (same XCD)
     if (grp >= G) return;
@@ -618,6 +622,19 @@ __global__ __launch_bounds__(256, (R * NT >= 8) ? 1 : 2) void conv_igemm_pipe_ke
     }
 }
 
+template <int NT, int WH, int WW, int R, int PRE>
+__global__ __launch_bounds__(256, (R * NT >= 8) ? 1 : 2) void conv_igemm_pipe_kernel(ConvParams p, int G) {
+    conv_igemm_pipe_body<NT, WH, WW, R, PRE>(p, G, blockIdx.x);
+}
+// merged launch of up to EGM_GROUP_MAX independent convolutions of one instantiation (group.h): member i owns blocks [blk0[i], blk0[i+1])
+struct PipeMulti { ConvParams p[EGM_GROUP_MAX]; int G[EGM_GROUP_MAX]; int blk0[EGM_GROUP_MAX + 1]; int n; };
+template <int NT, int WH, int WW, int R>
+__global__ __launch_bounds__(256, (R * NT >= 8) ? 1 : 2) void conv_igemm_pipe_multi_kernel(PipeMulti m) {
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.blk0[i + 1]) ++i;
+    conv_igemm_pipe_body<NT, WH, WW, R, EGM_PRE_NONE>(m.p[i], m.G[i], (int)blockIdx.x - m.blk0[i]);
+}
+
 // -------------------------------------------------------------------------------------------------
 // weight packing: fp32 OIHW (grouped) -> dense T [taps][CoutP][CinP] (fwd) and [taps flipped][CinP][CoutP] (dgrad)
 template <typename T>
@@ -712,6 +729,36 @@ template <int WH, int WW, int R> size_t pipe_base_bytes(int NT) {
     return (size_t)((Gm::PH * Gm::PW * 80 + 15) / 16 * 16) + (size_t)Gm::NTAPS * NT * 32 * 80 + 64 * 16;
 }
 
+template <int NT, int WH, int WW, int R>
+int launch_pipe_group(const EgmGroupRec* recs, int n, hipStream_t st) {
+    ConvParams first;
+    memcpy(&first, recs[0].params, sizeof(ConvParams));
+    if (n == 1) {
+        hipLaunchKernelGGL((conv_igemm_pipe_kernel<NT, WH, WW, R, EGM_PRE_NONE>), dim3(recs[0].grid), dim3(256), recs[0].smem, st, first, recs[0].G);
+        EGM_CHECK_LAUNCH("conv_igemm_pipe");
+        return EGM_OK;
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_pipe_multi_kernel<NT, WH, WW, R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_igemm_pipe_multi: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    PipeMulti m;
+    size_t smem = 0;
+    m.n = n; m.blk0[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        memcpy(&m.p[i], recs[i].params, sizeof(ConvParams));
+        m.G[i] = recs[i].G;
+        m.blk0[i + 1] = m.blk0[i] + recs[i].grid;                      // grids are multiples of 8: every member starts on XCD 0
+        if (recs[i].smem > smem) smem = recs[i].smem;
+    }
+    for (int i = n; i < EGM_GROUP_MAX; ++i) { m.p[i] = m.p[0]; m.G[i] = 0; m.blk0[i + 1] = m.blk0[n]; }
+    hipLaunchKernelGGL((conv_igemm_pipe_multi_kernel<NT, WH, WW, R>), dim3(m.blk0[n]), dim3(256), smem, st, m);
+    EGM_CHECK_LAUNCH("conv_igemm_pipe_multi");
+    return EGM_OK;
+}
 template <int NT, int WH, int WW, int R, int PRE>
 int launch_pipe_pre(ConvParams& p, int G, hipStream_t st) {
     using Gm = PipeGeom<WH, WW, R>;
@@ -728,6 +775,17 @@ int launch_pipe_pre(ConvParams& p, int G, hipStream_t st) {
     static_assert((size_t)Gm::PH * Gm::PW * 80 + 16 + (size_t)Gm::NTAPS * NT * 32 * 80 + 1024 <= 160 * 1024, "LDS budget");
     EGM_REQUIRE(smem <= 160 * 1024, "conv_igemm_pipe: LDS budget exceeded (%zu)", smem);
     const int grid = ((G + 7) / 8) * 8 * p.nct;
+    if constexpr (PRE == EGM_PRE_NONE) {
+        if (egm_group_recording()) {                                   // launched by egm_group_end(), merged with its siblings
+            static_assert(sizeof(ConvParams) <= sizeof(EgmGroupRec::params), "group record too small");
+            EgmGroupRec r;
+            r.launch = &launch_pipe_group<NT, WH, WW, R>;
+            memcpy(r.params, &p, sizeof(ConvParams));
+            r.G = G; r.grid = grid; r.smem = smem;
+            egm_group_push(r);
+            return EGM_OK;
+        }
+    }
     hipLaunchKernelGGL((conv_igemm_pipe_kernel<NT, WH, WW, R, PRE>), dim3(grid), dim3(256), smem, st, p, G);
     EGM_CHECK_LAUNCH("conv_igemm_pipe");
     return EGM_OK;

@@ -1,0 +1,42 @@
+// Launch-group recorder (group.h).  State is per host thread; nothing here touches the device until egm_group_end().
+#include "common.h"
+#include "group.h"
+#include <vector>
+
+namespace {
+thread_local bool g_recording = false;
+thread_local std::vector<EgmGroupRec> g_recs;
+}  // namespace
+
+bool egm_group_recording() { return g_recording; }
+void egm_group_push(const EgmGroupRec& r) { g_recs.push_back(r); }
+
+extern "C" int egm_group_begin(void) {
+    EGM_REQUIRE(!g_recording, "group_begin: a group is already open on this thread");
+    g_recs.clear();
+    g_recording = true;
+    return EGM_OK;
+}
+extern "C" int egm_group_abort(void) {
+    g_recs.clear();
+    g_recording = false;
+    return EGM_OK;
+}
+extern "C" int egm_group_end(egm_stream_t s) {
+    EGM_REQUIRE(g_recording, "group_end: no open group");
+    g_recording = false;
+    std::vector<EgmGroupRec> recs;
+    recs.swap(g_recs);
+    std::vector<char> done(recs.size(), 0);
+    for (size_t i = 0; i < recs.size(); ++i) {
+        if (done[i]) continue;
+        EgmGroupRec batch[EGM_GROUP_MAX];
+        int n = 0;
+        for (size_t j = i; j < recs.size() && n < EGM_GROUP_MAX; ++j) {
+            if (!done[j] && recs[j].launch == recs[i].launch) { batch[n++] = recs[j]; done[j] = 1; }
+        }
+        const int rc = recs[i].launch(batch, n, (hipStream_t)s);
+        if (rc != EGM_OK) return rc;
+    }
+    return EGM_OK;
+}

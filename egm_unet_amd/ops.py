@@ -404,6 +404,37 @@ def _unlazy(x):
     return x, None, ACT_NONE
 
 
+_GROUP_CONVS = os.environ.get("EGM_GROUP_CONVS", "1") != "0"
+
+
+def group_convs(enabled=None):
+    """Get / set whether conv_group() merges launches (tests compare both ways)."""
+    global _GROUP_CONVS
+    if enabled is not None:
+        _GROUP_CONVS = bool(enabled)
+    return _GROUP_CONVS
+
+
+class conv_group:
+    """`with conv_group():` -- the egm_conv_fwd* launches issued inside are recorded by the library and launched together on exit, those
+    of one kernel instantiation as ONE launch (csrc/group.h).  Only for convolutions that are independent of each other and whose
+    outputs are first used after the block.  EGM_GROUP_CONVS=0 turns it into a no-op."""
+
+    def __enter__(self):
+        self.on = _GROUP_CONVS
+        if self.on:
+            lib().call("egm_group_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.on:
+            if et is None:
+                lib().call("egm_group_end", stream())
+            else:
+                lib().cdll.egm_group_abort()
+        return False
+
+
 def _conv_forward(x, ldx, x_coef, x_act, weight, bias, dil, groups, want_stats):
     """The conv launch shared by _Conv2d and _ConvBN: y = conv(prologue(x), weight) (+bias), optional BN partial statistics."""
     N, H, W, CinP = x.shape
@@ -664,12 +695,17 @@ class _MultiConvBN(Function):
         L, st = lib(), stream()
         saved, descs_fin, descs_fwd, outs, keep = [], b"", b"", [], []
         ctx.meta = []
+        convs = []
+        with conv_group():                                    # the K convolutions: one launch per kernel instantiation
+            for k, mk in enumerate(meta):
+                x, weight, bias = flat[5 * k:5 * k + 3]
+                x, ldx = _nhwc(x)
+                convs.append((x, ldx) + _conv_forward(x, ldx, None, ACT_NONE, weight, bias, mk[6], mk[7], mk[5]))
         for k, mk in enumerate(meta):
             x, weight, bias, gamma, beta = flat[5 * k:5 * k + 5]
             rm, rv, eps, momentum, act, training, dil, groups, out_slot = mk
-            x, ldx = _nhwc(x)
             Cout, Cin_g = weight.shape[0], weight.shape[1]
-            y, stats, wd = _conv_forward(x, ldx, None, ACT_NONE, weight, bias, dil, groups, training)
+            x, ldx, y, stats, wd = convs[k]
             CoutP, npix, dev = y.shape[3], _npix(y), y.device
             coef = _f32((4, CoutP), dev)
             if training:
@@ -722,15 +758,21 @@ class _MultiConvBN(Function):
         L.call("egm_bn_multi", dt, _BN_BWD_COEFS, d_coef, K, st)
         L.call("egm_bn_multi", dt, _BN_BWD_APPLY, d_app, K, st)
         grads = [None]
+        gxs = [None] * K
+        with conv_group():                                    # the K data gradients: one launch per kernel instantiation
+            for k in range(K):
+                x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP = per[k][:12]
+                dil = ctx.meta[k][0]
+                KH, KW = weight.shape[2], weight.shape[3]
+                if ctx.needs_input_grad[1 + 5 * k]:
+                    gxs[k] = torch.empty((N, H, W, CinP), dtype=x.dtype, device=x.device)
+                    L.call("egm_conv_fwd", dt, ptr(dy), CoutP, ptr(wd), None, 0, ptr(gxs[k]), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
         for k in range(K):
             x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP = per[k][:12]
             dil, groups, has_bias, Cin, Cout, act, training = ctx.meta[k]
             KH, KW = weight.shape[2], weight.shape[3]
             base = 1 + 5 * k
-            gx = gw = gb = None
-            if ctx.needs_input_grad[base]:
-                gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=x.device)
-                L.call("egm_conv_fwd", dt, ptr(dy), CoutP, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
+            gx, gw, gb = gxs[k], None, None
             if ctx.needs_input_grad[base + 1]:
                 gw = _conv_wgrad(x, ldx, None, ACT_NONE, dy, CoutP, None, None, weight, dil, groups, Cin, Cout)
             if has_bias and ctx.needs_input_grad[base + 2]:

@@ -69,6 +69,14 @@ int egm_conv_pack(int dtype, const void* w_oihw_f32, void* wf, void* wd, int Cou
  * it (the kernels of all *_multi entry points find their entry by binary search on chunk0), total_chunks = the sum over all. */
 int egm_conv_pack_chunk(void);
 int egm_conv_pack_multi(int dtype, const void* table_dev, int n, long long total_chunks, egm_stream_t s);
+/* Launch groups: between egm_group_begin() and egm_group_end(s) the egm_conv_fwd* calls of THIS host thread are recorded instead of
+ * launched; egm_group_end launches them, merging those that run the same kernel instantiation into one launch (up to 4 members; the
+ * parallel branches of EdgeEnhancedGRFB, src/EGM-UNet.py:1256-1278).  The recorded convolutions must be independent of each other
+ * and their outputs must not be used before egm_group_end.  Convolutions taking a kernel without a merged form are launched at once.
+ * egm_group_abort() drops an open group (error paths). */
+int egm_group_begin(void);
+int egm_group_end(egm_stream_t s);
+int egm_group_abort(void);
 /* y = conv(x, wf) (+bias).  Cin/Cout are the PADDED counts of wf.  bias (fp32, bias_n <= Cout valid entries; the rest count as 0) may be NULL.
  * stats, when non-NULL, receives per-pixel-tile partial sums [ntiles][2][Cout] of y and y*y
  * (consumed by egm_bn_finalize); egm_conv_stats_tiles() gives ntiles for the same dtype/shape/kernel.

@@ -224,14 +224,15 @@ def test_chain_fused_equals_materialised_and_torch(dtype):
             close(st_f[n], b, n)
 
 
-@pytest.mark.parametrize("which", ["prologue", "elementwise", "multi"])
+@pytest.mark.parametrize("which", ["prologue", "elementwise", "multi", "grouped"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_model_fused_equals_materialised(dtype, which):
     """EGM-UNet train step: logits, loss and all 333 parameter gradients identical with and without (a) the Lazy / operand-prologue
     path, (b) the BatchNorm + element-wise fusions of csrc/bn_fused.hip (EdgeAwareFeatureEnhancer gate, GRFB residual tail) and (c) the
-    multi-tensor BatchNorm passes shared by the lockstep GRFB branches (ops.multi_conv_bn_act)."""
+    multi-tensor BatchNorm passes shared by the lockstep GRFB branches (ops.multi_conv_bn_act) and (d) the merged launches of the
+    branches' convolutions and data gradients (ops.conv_group, csrc/group.h)."""
     from egm_unet_amd import GRFBUNet, ops
-    toggle = {"prologue": ops.fuse_bn, "elementwise": ops.fuse_bn_ew, "multi": ops.fuse_bn_multi}[which]
+    toggle = {"prologue": ops.fuse_bn, "elementwise": ops.fuse_bn_ew, "multi": ops.fuse_bn_multi, "grouped": ops.group_convs}[which]
     default = toggle()
     from egm_unet_amd.train_utils import criterion
     torch.manual_seed(11)
