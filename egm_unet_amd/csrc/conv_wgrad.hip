@@ -22,6 +22,8 @@
 //     fixed order (bitwise reproducible) and scatters into the fp32 OIHW gradient.
 #include "common.h"
 #include "prologue.h"
+#include "group.h"
+#include <string.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -93,8 +95,10 @@ template <> struct Window<1> { static constexpr int WH = 1, WW = 1; };
 // a by-product (dy_out: by the workgroups of input-channel block 0 and of the centre tap group, which between them stage every dy
 // element exactly once), for the data-gradient kernel that runs next -- the stand-alone BatchNorm-backward apply pass
 // (bn_act_bwd_apply_kernel: read dz, read y, write dy) and one of the two reads of dy disappear.
+// (bx, by, bz) = the workgroup's index within THIS convolution: blockIdx of a plain launch, or decoded from the flat block index of a
+// merged launch (group.h)
 template <typename T, int NTAPS, bool PRE>
-__global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2 && !PRE) ? 2 : 1) void conv_wgrad_kernel(WgradParams p) {
+__device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using M = WMma<T>;
     constexpr int WH = Window<NTAPS>::WH, WW = Window<NTAPS>::WW;
@@ -111,9 +115,9 @@ __global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2 && !PRE) ? 2 : 1
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wa = wv % p.A, wb = (wv / p.A) % p.B, wc = wv / (p.A * p.B);
-    const int split = blockIdx.x;
-    const int cot = blockIdx.y / p.nci_tiles, cit = blockIdx.y % p.nci_tiles;
-    const int grp = blockIdx.z;
+    const int split = bx;
+    const int cot = by / p.nci_tiles, cit = by % p.nci_tiles;
+    const int grp = bz;
     const int co_base = cot * 32 * p.A, ci_base = cit * 32 * p.B;
 
     // tap group geometry: offset of the staged window relative to the output pixel, first tap index
@@ -427,11 +431,34 @@ __global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2 && !PRE) ? 2 : 1
     }
 #ifdef EGM_CONV_TIMING
     __syncthreads();
-    if (tid == 0 && blockIdx.y == 0 && blockIdx.z == 0) {       // debug build: phase totals of wave 0 overwrite the first slab floats
+    if (tid == 0 && by == 0 && bz == 0) {       // debug build: phase totals of wave 0 overwrite the first slab floats
         for (int i = 0; i < 4; ++i) p.slab[(long long)split * 8 + i] = (float)tph[i];
         p.slab[(long long)split * 8 + 4] = (float)nstages;
     }
 #endif
+}
+
+template <typename T, int NTAPS, bool PRE>
+__global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2 && !PRE) ? 2 : 1) void conv_wgrad_kernel(WgradParams p) {
+    conv_wgrad_body<T, NTAPS, PRE>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// merged launch of up to EGM_GROUP_MAX independent weight gradients of one instantiation (group.h): member i owns the flat blocks
+// [blk0[i], blk0[i+1]) = its (nx, ny, nz) grid in x-fastest order
+struct WgradMulti { WgradParams p[EGM_GROUP_MAX]; int blk0[EGM_GROUP_MAX + 1]; int nx[EGM_GROUP_MAX], ny[EGM_GROUP_MAX]; int n; };
+__device__ __forceinline__ int wgrad_multi_member(const WgradMulti& m, int& bx, int& by, int& bz) {
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.blk0[i + 1]) ++i;
+    const int b = (int)blockIdx.x - m.blk0[i];
+    bx = b % m.nx[i];
+    const int r = b / m.nx[i];
+    by = r % m.ny[i]; bz = r / m.ny[i];
+    return i;
+}
+template <typename T, int NTAPS>
+__global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2) ? 2 : 1) void conv_wgrad_multi_kernel(WgradMulti m) {
+    int bx, by, bz;
+    const int i = wgrad_multi_member(m, bx, by, bz);
+    conv_wgrad_body<T, NTAPS, false>(m.p[i], bx, by, bz);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -446,7 +473,7 @@ __global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2 && !PRE) ? 2 : 1
 //   BatchNorm backward) runs beside the consumers' MFMAs instead of in front of them -- in the one-wave-per-SIMD kernel above the
 //   same prologue work is serialised with the matrix work and doubles the kernel.  One barrier per tile.
 template <int NTAPS, bool PRE>
-__global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(WgradParams p) {
+__device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using M = WMma<bf16_t>;
     constexpr int WH = Window<NTAPS>::WH, WW = Window<NTAPS>::WW;
@@ -462,9 +489,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(WgradParams p) {
     const int cw = wv & 3;                                             // consumer index (producers: unused role split)
     const int wa = cw % p.A, wb = (cw / p.A) % p.B, wc = cw / (p.A * p.B);
     const int ptid = tid & 255;                                        // producer thread index
-    const int split = blockIdx.x;
-    const int cot = blockIdx.y / p.nci_tiles, cit = blockIdx.y % p.nci_tiles;
-    const int grp = blockIdx.z;
+    const int split = bx;
+    const int cot = by / p.nci_tiles, cit = by % p.nci_tiles;
+    const int grp = bz;
     const int co_base = cot * 32 * p.A, ci_base = cit * 32 * p.B;
 
     int offy, offx, tap0;
@@ -749,6 +776,17 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(WgradParams p) {
     }
 }
 
+template <int NTAPS, bool PRE>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(WgradParams p) {
+    conv_wgrad_ws_body<NTAPS, PRE>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+template <int NTAPS>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_ws_multi_kernel(WgradMulti m) {
+    int bx, by, bz;
+    const int i = wgrad_multi_member(m, bx, by, bz);
+    conv_wgrad_ws_body<NTAPS, false>(m.p[i], bx, by, bz);
+}
+
 // sum slabs in fixed order and scatter to fp32 OIHW (real, possibly grouped, shape).
 // block = 64 consecutive packed elements (tap, co, ci) x 4 slab lanes: every slab row read is a 256-byte segment.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslab, int taps,
@@ -881,6 +919,67 @@ int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW
     return EGM_OK;
 }
 
+// group.h: launch recs[0..n) of one instantiation; KERNEL / MULTI = the plain and the merged kernel, THREADS per workgroup
+template <typename Single, typename Multi>
+int launch_wgrad_group_impl(const EgmGroupRec* recs, int n, hipStream_t st, Single single, Multi multi, int threads, const char* what) {
+    if (n == 1) {
+        WgradParams first;
+        memcpy(&first, recs[0].params, sizeof(WgradParams));
+        const int* g3 = reinterpret_cast<const int*>(recs[0].params + sizeof(WgradParams));
+        hipLaunchKernelGGL(single, dim3(g3[0], g3[1], g3[2]), dim3(threads), recs[0].smem, st, first);
+        EGM_CHECK_LAUNCH(what);
+        return EGM_OK;
+    }
+    WgradMulti m;
+    size_t smem = 0;
+    m.n = n; m.blk0[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        memcpy(&m.p[i], recs[i].params, sizeof(WgradParams));
+        const int* g3 = reinterpret_cast<const int*>(recs[i].params + sizeof(WgradParams));
+        m.nx[i] = g3[0]; m.ny[i] = g3[1];
+        m.blk0[i + 1] = m.blk0[i] + g3[0] * g3[1] * g3[2];
+        if (recs[i].smem > smem) smem = recs[i].smem;
+    }
+    for (int i = n; i < EGM_GROUP_MAX; ++i) { m.p[i] = m.p[0]; m.nx[i] = m.ny[i] = 1; m.blk0[i + 1] = m.blk0[n]; }
+    hipLaunchKernelGGL(multi, dim3(m.blk0[n]), dim3(threads), smem, st, m);
+    EGM_CHECK_LAUNCH(what);
+    return EGM_OK;
+}
+template <typename T, int NTAPS>
+int launch_wgrad_group(const EgmGroupRec* recs, int n, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_multi_kernel<T, NTAPS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_wgrad_multi: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    return launch_wgrad_group_impl(recs, n, st, conv_wgrad_kernel<T, NTAPS, false>, conv_wgrad_multi_kernel<T, NTAPS>, 256, "conv_wgrad (group)");
+}
+template <int NTAPS>
+int launch_wgrad_ws_group(const EgmGroupRec* recs, int n, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ws_multi_kernel<NTAPS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_wgrad_ws_multi: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    return launch_wgrad_group_impl(recs, n, st, conv_wgrad_ws_kernel<NTAPS, false>, conv_wgrad_ws_multi_kernel<NTAPS>, 512, "conv_wgrad_ws (group)");
+}
+// records the launch when a group is open on this thread (only the prologue-free kernels have a merged form)
+inline bool wgrad_record(int (*fn)(const EgmGroupRec*, int, hipStream_t), const WgradParams& p, dim3 grid, size_t smem) {
+    if (!egm_group_recording()) return false;
+    static_assert(sizeof(WgradParams) + 3 * sizeof(int) <= sizeof(EgmGroupRec::params), "group record too small");
+    EgmGroupRec r;
+    r.launch = fn;
+    memcpy(r.params, &p, sizeof(WgradParams));
+    const int g3[3] = {(int)grid.x, (int)grid.y, (int)grid.z};
+    memcpy(r.params + sizeof(WgradParams), g3, sizeof(g3));
+    r.G = 0; r.grid = (int)(grid.x * grid.y * grid.z); r.smem = smem;
+    egm_group_push(r);
+    return true;
+}
 template <typename T, int NTAPS, bool PRE>
 int launch_wgrad_pre(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     static bool attr_done = false;
@@ -891,6 +990,9 @@ int launch_wgrad_pre(const WgradParams& p, const WgradPlan& pl, hipStream_t st) 
         attr_done = true;
     }
     dim3 grid(pl.nsplit, pl.nco_tiles * pl.nci_tiles, pl.ngroups);
+    if constexpr (!PRE) {
+        if (wgrad_record(&launch_wgrad_group<T, NTAPS>, p, grid, pl.smem)) return EGM_OK;
+    }
     hipLaunchKernelGGL((conv_wgrad_kernel<T, NTAPS, PRE>), grid, dim3(256), pl.smem, st, p);
     EGM_CHECK_LAUNCH("conv_wgrad");
     return EGM_OK;
@@ -905,6 +1007,9 @@ int launch_wgrad_ws(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
         attr_done = true;
     }
     dim3 grid(pl.nsplit, pl.nco_tiles * pl.nci_tiles, pl.ngroups);
+    if constexpr (!PRE) {
+        if (wgrad_record(&launch_wgrad_ws_group<NTAPS>, p, grid, pl.smem)) return EGM_OK;
+    }
     hipLaunchKernelGGL((conv_wgrad_ws_kernel<NTAPS, PRE>), grid, dim3(512), pl.smem, st, p);
     EGM_CHECK_LAUNCH("conv_wgrad_ws");
     return EGM_OK;
@@ -1013,9 +1118,14 @@ extern "C" int egm_conv_wgrad_pre(int dtype, const void* x, int ldx, int xpre_mo
     p.dma = pl.dma;
     hipStream_t st = (hipStream_t)s;
     int rc;
+    // inside a launch group only the slab-only form is recorded: with dw the reduction below needs the slabs at once
+    const bool paused = dw != nullptr && egm_group_recording();
+    if (paused) egm_group_set_recording(false);
     if (dtype == EGM_BF16) rc = dispatch_wgrad<bf16_t>(p, pl, st);
     else if (dtype == EGM_F32) rc = dispatch_wgrad<float>(p, pl, st);
-    else EGM_FAIL(EGM_ERR_ARG, "conv_wgrad: unknown dtype %d", dtype);
+    else rc = EGM_ERR_ARG;
+    if (paused) egm_group_set_recording(true);
+    if (rc == EGM_ERR_ARG && dtype != EGM_BF16 && dtype != EGM_F32) EGM_FAIL(EGM_ERR_ARG, "conv_wgrad: unknown dtype %d", dtype);
     if (rc != EGM_OK) return rc;
     if (dw == nullptr) return EGM_OK;                  // slabs only: the caller reduces later with egm_wgrad_reduce_multi
     const long long total = (long long)KH * KW * Cout * Cin;

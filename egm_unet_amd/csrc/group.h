@@ -21,4 +21,5 @@ struct EgmGroupRec {
 };
 
 bool egm_group_recording();
+void egm_group_set_recording(bool on);      // pause / resume an open group (a launch whose result is consumed at once)
 void egm_group_push(const EgmGroupRec& r);

@@ -9,6 +9,7 @@ thread_local std::vector<EgmGroupRec> g_recs;
 }  // namespace
 
 bool egm_group_recording() { return g_recording; }
+void egm_group_set_recording(bool on) { g_recording = on; }
 void egm_group_push(const EgmGroupRec& r) { g_recs.push_back(r); }
 
 extern "C" int egm_group_begin(void) {

@@ -767,14 +767,19 @@ class _MultiConvBN(Function):
                 if ctx.needs_input_grad[1 + 5 * k]:
                     gxs[k] = torch.empty((N, H, W, CinP), dtype=x.dtype, device=x.device)
                     L.call("egm_conv_fwd", dt, ptr(dy), CoutP, ptr(wd), None, 0, ptr(gxs[k]), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
+        gws = [None] * K
+        with conv_group():                                    # ... and the K weight gradients (slab kernels)
+            for k in range(K):
+                x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP = per[k][:12]
+                dil, groups, has_bias, Cin, Cout, act, training = ctx.meta[k]
+                if ctx.needs_input_grad[1 + 5 * k + 1]:
+                    gws[k] = _conv_wgrad(x, ldx, None, ACT_NONE, dy, CoutP, None, None, weight, dil, groups, Cin, Cout)
         for k in range(K):
             x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP = per[k][:12]
             dil, groups, has_bias, Cin, Cout, act, training = ctx.meta[k]
             KH, KW = weight.shape[2], weight.shape[3]
             base = 1 + 5 * k
-            gx, gw, gb = gxs[k], None, None
-            if ctx.needs_input_grad[base + 1]:
-                gw = _conv_wgrad(x, ldx, None, ACT_NONE, dy, CoutP, None, None, weight, dil, groups, Cin, Cout)
+            gx, gw, gb = gxs[k], gws[k], None
             if has_bias and ctx.needs_input_grad[base + 2]:
                 gb = _f32(Cout, x.device, zero=True)
             ggamma = sums[1, :Cout] if ctx.needs_input_grad[base + 3] else None
