@@ -682,6 +682,57 @@ __global__ __launch_bounds__(256) void ca_mlp_bwd_kernel(const T* __restrict__ d
     }
 }
 
+// dca of fusion_combine: red fp32 [N][2][C] (row 0 of each image) -> dst[n][c] and dst[N+n][c] in the storage type (the gradient of
+// ca_avg and of ca_max is the same number).  One launch instead of a contiguous copy and two layout conversions.
+template <typename T>
+__global__ __launch_bounds__(256) void rows_dup_kernel(const float* __restrict__ red, T* __restrict__ dst, int ldd, int N, int C) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N * C; i += gridDim.x * 256) {
+        const int n = i / C, c = i - n * C;
+        const T v = from_f32<T>(red[((long long)n * 2) * C + c]);
+        dst[(long long)n * ldd + c] = v;
+        dst[(long long)(N + n) * ldd + c] = v;
+    }
+}
+
+// fold2 / merge357 with the operand packs of the derived weight written by the same launch (layouts of egm_conv_pack: wf [tap][CoutP][CinP],
+// wd [tap flipped][CinP][CoutP], zeros in the padding): the derived weights of FusionConv are rebuilt every step, and as separate
+// launches (derive, then pack) they were four tiny kernels per block in front of its two convolutions.
+template <typename T>
+__global__ void fold2_pack_kernel(const float* __restrict__ w, float* __restrict__ out, T* __restrict__ wf, T* __restrict__ wd, int rows, int K,
+                                  int CoutP, int CinP) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < CoutP * CinP; i += gridDim.x * blockDim.x) {
+        const int co = i / CinP, ci = i - co * CinP;
+        float v = 0.f;
+        if (co < rows && ci < K) {
+            v = w[(long long)co * 2 * K + ci] + w[(long long)co * 2 * K + K + ci];
+            out[co * K + ci] = v;
+        }
+        wf[i] = from_f32<T>(v);
+        wd[(long long)ci * CoutP + co] = from_f32<T>(v);
+    }
+}
+template <typename T>
+__global__ void merge357_pack_kernel(const float* __restrict__ w3, const float* __restrict__ w5, const float* __restrict__ w7,
+                                     const float* __restrict__ b3, const float* __restrict__ b5, const float* __restrict__ b7,
+                                     float* __restrict__ w, float* __restrict__ b, T* __restrict__ wf, T* __restrict__ wd, int Co, int Ci,
+                                     int CoutP, int CinP) {
+    const int total = 49 * CoutP * CinP;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ci = i % CinP, co = (i / CinP) % CoutP, t = i / (CinP * CoutP), r = t / 7, sx = t % 7;
+        float v = 0.f;
+        if (co < Co && ci < Ci) {
+            const int oc = co * Ci + ci;
+            v = w7[oc * 49 + t];
+            if (r >= 1 && r <= 5 && sx >= 1 && sx <= 5) v += w5[oc * 25 + (r - 1) * 5 + (sx - 1)];
+            if (r >= 2 && r <= 4 && sx >= 2 && sx <= 4) v += w3[oc * 9 + (r - 2) * 3 + (sx - 2)];
+            w[oc * 49 + t] = v;
+        }
+        wf[i] = from_f32<T>(v);
+        wd[((long long)(48 - t) * CinP + ci) * CoutP + co] = from_f32<T>(v);
+        if (i < Co) b[i] = b3[i] + b5[i] + b7[i];
+    }
+}
+
 }  // namespace
 
 #define EGM_REQ_VEC(name, ptr, ld, C)                                                                      \
@@ -847,6 +898,13 @@ extern "C" int egm_global_avgmax_bwd(int dtype, const void* gout, const int* arg
     return EGM_OK;
 }
 
+extern "C" int egm_rows_dup(int dtype, const float* red, void* dst, int ldd, int N, int C, egm_stream_t s) {
+    EGM_REQUIRE(red && dst && N > 0 && C > 0 && ldd >= C, "rows_dup: bad args");
+    int grid = (N * C + 255) / 256; if (grid > 64) grid = 64;
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((rows_dup_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)s, red, (T*)dst, ldd, N, C));
+    EGM_CHECK_LAUNCH("rows_dup");
+    return EGM_OK;
+}
 extern "C" int egm_ca_mlp_fwd(int dtype, const void* pooled, int ldp, const float* w0, const float* w2, float* h, void* logits, int ldo, int R,
                               int C, int Cr, egm_stream_t s) {
     EGM_REQUIRE(pooled && w0 && w2 && h && logits, "ca_mlp_fwd: null pointer");
@@ -919,6 +977,23 @@ extern "C" int egm_merge357_fwd(const float* w3, const float* w5, const float* w
     EGM_REQUIRE(w3 && w5 && w7 && b3 && b5 && b7 && w && b && Co > 0 && Ci > 0, "merge357_fwd: bad args");
     hipLaunchKernelGGL(merge357_fwd_kernel, dim3((Co * Ci * 49 + 255) / 256), dim3(256), 0, (hipStream_t)s, w3, w5, w7, b3, b5, b7, w, b, Co, Ci);
     EGM_CHECK_LAUNCH("merge357_fwd");
+    return EGM_OK;
+}
+extern "C" int egm_fold2_pack(int dtype, const float* w, float* out, void* wf, void* wd, int rows, int K, egm_stream_t s) {
+    EGM_REQUIRE(w && out && wf && wd && rows > 0 && K > 0, "fold2_pack: bad args");
+    const int CoutP = (rows + 7) / 8 * 8, CinP = (K + 7) / 8 * 8;
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((fold2_pack_kernel<T>), dim3((CoutP * CinP + 255) / 256), dim3(256), 0, (hipStream_t)s, w, out,
+                                                 (T*)wf, (T*)wd, rows, K, CoutP, CinP));
+    EGM_CHECK_LAUNCH("fold2_pack");
+    return EGM_OK;
+}
+extern "C" int egm_merge357_pack(int dtype, const float* w3, const float* w5, const float* w7, const float* b3, const float* b5, const float* b7,
+                                 float* w, float* b, void* wf, void* wd, int Co, int Ci, egm_stream_t s) {
+    EGM_REQUIRE(w3 && w5 && w7 && b3 && b5 && b7 && w && b && wf && wd && Co > 0 && Ci > 0, "merge357_pack: bad args");
+    const int CoutP = (Co + 7) / 8 * 8, CinP = (Ci + 7) / 8 * 8;
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((merge357_pack_kernel<T>), dim3((49 * CoutP * CinP + 255) / 256), dim3(256), 0, (hipStream_t)s,
+                                                 w3, w5, w7, b3, b5, b7, w, b, (T*)wf, (T*)wd, Co, Ci, CoutP, CinP));
+    EGM_CHECK_LAUNCH("merge357_pack");
     return EGM_OK;
 }
 extern "C" int egm_merge357_bwd(const float* gw, float* d3, float* d5, float* d7, int Co, int Ci, egm_stream_t s) {

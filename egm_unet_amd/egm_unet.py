@@ -148,11 +148,11 @@ class FusionConv(nn.Module):
             x1 = ops.cat_channels([x1, x2])
             wdown = self.down.weight if k % 8 == 0 else ops.spread_cols(self.down.weight, (k, k))
         else:
-            wdown = ops.fold2(self.down.weight)
+            wdown = ops.fold2(self.down.weight, pack_dtype=x1.dtype)
         f = ops.conv2d(x1, wdown, self.down.bias)
         f_res, f_ms, f_ca = ops.fork(f, 3)
         w7, b7 = ops.merge357(self.conv_3x3.weight, self.conv_5x5.weight, self.conv_7x7.weight, self.conv_3x3.bias,
-                              self.conv_5x5.bias, self.conv_7x7.bias)
+                              self.conv_5x5.bias, self.conv_7x7.bias, pack_dtype=f.dtype)
         s = ops.conv2d(f_ms, w7, b7)
         s_a, s_b = ops.fork(s, 2)
         sa = self.spatial_attention.logits(s_a, self._dim)

@@ -1473,23 +1473,34 @@ class _FusionCombine(Function):
 
 
 def _f32_rows_to_act(red, dca, N, C):
-    """red fp32 [N][2][C] (row 0 = dca) -> dca[n] and dca[N+n] in the activation dtype (layout conversion kernel)."""
-    L, st = lib(), stream()
-    src = red[:, 0, :].contiguous()                       # [N, C] fp32 viewed as NCHW [N, C, 1, 1]
-    for half in (dca[:N], dca[N:]):
-        L.call("egm_nchw_to_nhwc", dtype_code(dca.dtype), ptr(src), ptr(half), C, N, C, 1, 1, st)
+    """red fp32 [N][2][C] (row 0 = dca) -> dca[n] and dca[N+n] in the activation dtype (one launch)."""
+    lib().call("egm_rows_dup", dtype_code(dca.dtype), ptr(red), ptr(dca), C, N, C, stream())
 
 
 def fusion_combine(f, s, sa, ca):
     return _FusionCombine.apply(f, s, sa, ca)
 
 
+def _register_pack(weight, dtype, wf, wd):
+    """Operand packs produced together with a derived weight (fold2 / merge357): what _packed_weights would build for it."""
+    key = (weight.data_ptr(), weight._version, _weight_generation[0], dtype, 1, tuple(weight.shape))
+    _pack_cache[id(weight)] = (key, wf, wd, weakref.ref(weight))
+
+
 class _Fold2(Function):
     @staticmethod
-    def forward(ctx, w):                                   # [rows, 2K, 1, 1] -> [rows, K, 1, 1]
+    def forward(ctx, w, pack_dtype):                       # [rows, 2K, 1, 1] -> [rows, K, 1, 1]
         rows, K2 = w.shape[0], w.shape[1]
-        out = torch.empty((rows, K2 // 2, 1, 1), dtype=torch.float32, device=w.device)
-        lib().call("egm_fold2_fwd", ptr(w.detach().contiguous()), ptr(out), rows, K2 // 2, stream())
+        K = K2 // 2
+        out = torch.empty((rows, K, 1, 1), dtype=torch.float32, device=w.device)
+        if pack_dtype is None:
+            lib().call("egm_fold2_fwd", ptr(w.detach().contiguous()), ptr(out), rows, K, stream())
+            _Fold2.packs = None
+        else:                                              # the conv operand packs of the folded weight from the same launch
+            wf = torch.empty((1, pad8(rows), pad8(K)), dtype=pack_dtype, device=w.device)
+            wd = torch.empty((1, pad8(K), pad8(rows)), dtype=pack_dtype, device=w.device)
+            lib().call("egm_fold2_pack", dtype_code(pack_dtype), ptr(w.detach().contiguous()), ptr(out), ptr(wf), ptr(wd), rows, K, stream())
+            _Fold2.packs = (wf, wd)
         return out
 
     @staticmethod
@@ -1497,11 +1508,16 @@ class _Fold2(Function):
         rows, K = g.shape[0], g.shape[1]
         dw = torch.empty((rows, 2 * K, 1, 1), dtype=torch.float32, device=g.device)
         lib().call("egm_fold2_bwd", ptr(g.contiguous()), ptr(dw), rows, K, stream())
-        return dw
+        return dw, None
 
 
-def fold2(w):
-    return _Fold2.apply(w)
+def fold2(w, pack_dtype=None):
+    """w[:, :K] + w[:, K:]; pack_dtype: also build the conv operand packs of the result for that activation dtype (one launch)."""
+    out = _Fold2.apply(w, pack_dtype)
+    if pack_dtype is not None and _Fold2.packs is not None:
+        _register_pack(out, pack_dtype, *_Fold2.packs)
+        _Fold2.packs = None
+    return out
 
 
 class _SpreadCols(Function):
@@ -1541,12 +1557,20 @@ def spread_cols(w, real):
 
 class _Merge357(Function):
     @staticmethod
-    def forward(ctx, w3, w5, w7, b3, b5, b7):
+    def forward(ctx, w3, w5, w7, b3, b5, b7, pack_dtype):
         Co, Ci = w7.shape[0], w7.shape[1]
         w = torch.empty((Co, Ci, 7, 7), dtype=torch.float32, device=w7.device)
         b = torch.empty((Co,), dtype=torch.float32, device=w7.device)
-        lib().call("egm_merge357_fwd", ptr(w3.detach().contiguous()), ptr(w5.detach().contiguous()), ptr(w7.detach().contiguous()),
-                   ptr(b3.detach()), ptr(b5.detach()), ptr(b7.detach()), ptr(w), ptr(b), Co, Ci, stream())
+        args = (ptr(w3.detach().contiguous()), ptr(w5.detach().contiguous()), ptr(w7.detach().contiguous()), ptr(b3.detach()),
+                ptr(b5.detach()), ptr(b7.detach()), ptr(w), ptr(b))
+        if pack_dtype is None:
+            lib().call("egm_merge357_fwd", *args, Co, Ci, stream())
+            _Merge357.packs = None
+        else:
+            wf = torch.empty((49, pad8(Co), pad8(Ci)), dtype=pack_dtype, device=w7.device)
+            wd = torch.empty((49, pad8(Ci), pad8(Co)), dtype=pack_dtype, device=w7.device)
+            lib().call("egm_merge357_pack", dtype_code(pack_dtype), *args, ptr(wf), ptr(wd), Co, Ci, stream())
+            _Merge357.packs = (wf, wd)
         ctx.shape = (Co, Ci)
         return w, b
 
@@ -1558,11 +1582,15 @@ class _Merge357(Function):
         d5 = torch.empty((Co, Ci, 5, 5), dtype=torch.float32, device=dev)
         d7 = torch.empty((Co, Ci, 7, 7), dtype=torch.float32, device=dev)
         lib().call("egm_merge357_bwd", ptr(gw.contiguous()), ptr(d3), ptr(d5), ptr(d7), Co, Ci, stream())
-        return d3, d5, d7, gb, gb, gb
+        return d3, d5, d7, gb, gb, gb, None
 
 
-def merge357(w3, w5, w7, b3, b5, b7):
-    return _Merge357.apply(w3, w5, w7, b3, b5, b7)
+def merge357(w3, w5, w7, b3, b5, b7, pack_dtype=None):
+    w, b = _Merge357.apply(w3, w5, w7, b3, b5, b7, pack_dtype)
+    if pack_dtype is not None and _Merge357.packs is not None:
+        _register_pack(w, pack_dtype, *_Merge357.packs)
+        _Merge357.packs = None
+    return w, b
 
 
 class _DwConv3(Function):

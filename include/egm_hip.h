@@ -282,6 +282,9 @@ int egm_global_avgmax_fwd(int dtype, const void* x, int ldx, void* out, int* arg
                           int C, egm_stream_t s);
 int egm_global_avgmax_bwd(int dtype, const void* gout, const int* argidx, void* dx, int lddx, int N, long long HW, int C,
                           egm_stream_t s);
+/* dst[n][c] = dst[N+n][c] = red[n][0][c] (red fp32 [N][2][C]): the channel-attention gradient of egm_fusion_combine_bwd, reduced by
+ * egm_reduce_tiles_batched, as the [2N][C] rows the attention's backward takes. */
+int egm_rows_dup(int dtype, const float* red, void* dst, int ldd, int N, int C, egm_stream_t s);
 /* ChannelAttentionModule.fc (src/EGM-UNet.py:1171-1190) on the R = 2N pooled rows: logits = W2 . relu(W0 . pooled).  w0 fp32 [Cr][C],
  * w2 fp32 [C][Cr] (the 1x1 conv weights as stored), h fp32 [R][Cr] = the hidden activation kept for backward.  One workgroup each;
  * (R*C + R*Cr) floats (forward) / twice that (backward) must fit 64 KB of LDS.  Backward OVERWRITES dw0 / dw2. */
@@ -304,6 +307,11 @@ int egm_fold2_bwd(const float* g, float* dw, int rows, int K, egm_stream_t s);
 int egm_merge357_fwd(const float* w3, const float* w5, const float* w7, const float* b3, const float* b5, const float* b7,
                      float* w, float* b, int Co, int Ci, egm_stream_t s);
 int egm_merge357_bwd(const float* gw, float* d3, float* d5, float* d7, int Co, int Ci, egm_stream_t s);
+/* egm_fold2_fwd / egm_merge357_fwd that ALSO write the operand packs (egm_conv_pack layouts, groups = 1) of the derived weight:
+ * wf [taps][CoutP][CinP], wd [taps flipped][CinP][CoutP] in `dtype`, CoutP/CinP = the counts rounded up to 8. */
+int egm_fold2_pack(int dtype, const float* w, float* out, void* wf, void* wd, int rows, int K, egm_stream_t s);
+int egm_merge357_pack(int dtype, const float* w3, const float* w5, const float* w7, const float* b3, const float* b5, const float* b7,
+                      float* w, float* b, void* wf, void* wd, int Co, int Ci, egm_stream_t s);
 
 /* ---- MCALayer (src/EGM-UNet.py:686-791, MCAGate :836-869, StdPool :827-834) ---------------------------------------- */
 /* Three-axis sums in one pass: sums fp32 [N][H+W+C][2] laid out per image as [H rows | W columns | C channels];
