@@ -4,7 +4,7 @@ tag=${1:-r02}; out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"; tail -c 600 $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o p -- python bench.py --steps 12 --warmup 3 --no-cpu-baseline > $out/prof.log 2>&1
 f=$(find $out/prof -name "*kernel_trace.csv" | head -1); st=$(find $out/prof -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && PROF_TOP=60 python tools/prof_summary.py $f 0 $out/kernel_trace_summary.md > /dev/null && head -12 $out/kernel_trace_summary.md
+[ -n "$f" ] && PROF_TOP=60 python tools/prof_summary.py $f 0 $out/kernel_trace_summary.md $out/timeline.tsv > /dev/null && head -12 $out/kernel_trace_summary.md
 [ -n "$st" ] && cp $st $out/kernel_stats.csv
 rm -rf $out/prof
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf -o f -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > $out/pmc_f.log 2>&1
