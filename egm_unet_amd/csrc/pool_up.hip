@@ -66,9 +66,10 @@ __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int ldx, T* __restr
     }
 }
 // gradient goes to the FIRST maximum in window scan order (torch max_pool2d semantics)
+// add (optional): a second gradient of x (the skip connection's), summed in the same pass: dx = scatter(dy) + add
 template <typename T>
-__global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy, T* __restrict__ dx,
-                                    int lddx, int N, int H, int W, int C) {
+__global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ dy, int lddy, const T* __restrict__ add, int ldadd,
+                                    T* __restrict__ dx, int lddx, int N, int H, int W, int C) {
     const int ncv = C >> 3, Ho = H >> 1, Wo = W >> 1;
     const long long total = (long long)N * Ho * Wo * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -88,6 +89,16 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int ldx, const T* _
             for (int k = 1; k < 4; ++k) if (v[k][j] > m) { m = v[k][j]; best = k; }
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k][j] = (k == best) ? g[j] : 0.f;
+        }
+        if (add != nullptr) {
+            const long long off[4] = {base, base + 1, base + W, base + W + 1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a[8];
+                load8(add + off[k] * ldadd + cv * 8, a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[k][j] += a[j];
+            }
         }
         store8(dx + base * lddx + cv * 8, o[0]);
         store8(dx + (base + 1) * lddx + cv * 8, o[1]);
@@ -435,12 +446,26 @@ extern "C" int egm_maxpool2_bwd(int dtype, const void* x, int ldx, const void* d
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / 8);
     EGM_DISPATCH_DTYPE(dtype, {
         hipLaunchKernelGGL((maxpool2_bwd_kernel<T>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx,
-                           (const T*)dy, lddy, (T*)dx, lddx, N, H, W, C);
+                           (const T*)dy, lddy, (const T*)nullptr, 0, (T*)dx, lddx, N, H, W, C);
         if ((H & 1) || (W & 1))
             hipLaunchKernelGGL((zero_tail_kernel<T>), dim3(stream_grid((long long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)s,
                                (T*)dx, lddx, N, H, W, C);
     });
     EGM_CHECK_LAUNCH("maxpool2_bwd");
+    return EGM_OK;
+}
+
+/* dx = maxpool2 backward of dy (first maximum of each 2x2 window) + add: the skip connection's gradient of the same tensor summed in
+ * the same pass (one read and one write of the tensor less than egm_maxpool2_bwd followed by egm_axpby).  H and W must be even. */
+extern "C" int egm_maxpool2_bwd_add(int dtype, const void* x, int ldx, const void* dy, int lddy, const void* add, int ldadd, void* dx, int lddx,
+                                    int N, int H, int W, int C, egm_stream_t s) {
+    EGM_REQ_VEC("maxpool2_bwd_add", x, ldx, C); EGM_REQ_VEC("maxpool2_bwd_add", dy, lddy, C); EGM_REQ_VEC("maxpool2_bwd_add", add, ldadd, C);
+    EGM_REQ_VEC("maxpool2_bwd_add", dx, lddx, C);
+    EGM_REQUIRE(N > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1), "maxpool2_bwd_add: H and W must be even (got %d x %d)", H, W);
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 8);
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((maxpool2_bwd_kernel<T>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx,
+                                                 (const T*)dy, lddy, (const T*)add, ldadd, (T*)dx, lddx, N, H, W, C));
+    EGM_CHECK_LAUNCH("maxpool2_bwd_add");
     return EGM_OK;
 }
 

@@ -457,8 +457,9 @@ class Down(nn.Sequential):
     def __init__(self, in_channels, out_channels, use_mca=True):
         super().__init__(nn.MaxPool2d(2, stride=2), DoubleConv1(in_channels, out_channels, use_mca=use_mca))
 
-    def forward(self, x, out=None):
-        return self[1](ops.maxpool2(x), out)
+    def forward(self, x, out=None, pooled=None):
+        """pooled: maxpool2(x) when the caller already has it (ops.fork_maxpool2 at the skip connection)."""
+        return self[1](ops.maxpool2(x) if pooled is None else pooled, out)
 
 
 class GRFBUNet(_SegNetBase):
@@ -494,11 +495,13 @@ class GRFBUNet(_SegNetBase):
                 h, w = H >> k, W >> k
                 if cs % 8 == 0 and cin % 8 == 0 and (h << k) == H and (w << k) == W:
                     bufs[k], (slots[k], _) = ops.cat_slots(N, h, w, [cs, cin - cs], x.dtype, x.device)
-        x1, x1s = ops.fork(self.in_conv(x, slots[0]), 2)
-        x2, x2s = ops.fork(self.down1(x1, slots[1]), 2)
-        x3, x3s = ops.fork(self.down2(x2, slots[2]), 2)
-        x4, x4s = ops.fork(self.down3(x3, slots[3]), 2)
-        d4 = self.down4(x4)
+        # each encoder output feeds the skip connection and the next level's max pool: one node, whose backward sums the two gradients
+        # while it scatters the pooled one
+        x1s, p1 = ops.fork_maxpool2(self.in_conv(x, slots[0]))
+        x2s, p2 = ops.fork_maxpool2(self.down1(None, slots[1], pooled=p1))
+        x3s, p3 = ops.fork_maxpool2(self.down2(None, slots[2], pooled=p2))
+        x4s, p4 = ops.fork_maxpool2(self.down3(None, slots[3], pooled=p3))
+        d4 = self.down4(None, pooled=p4)
         if self.ddp_boundary is not None:                 # graph.GraphedTrainStep splits backward at the encoder -> decoder tensors
             self.ddp_boundary.extend([x1s, x2s, x3s, x4s, d4])
         x5 = self.attn1(d4)

@@ -989,6 +989,45 @@ def maxpool2(x):
     return _MaxPool2.apply(x)
 
 
+class _ForkMaxPool2(Function):
+    """x -> (alias of x for the skip connection, maxpool2(x)): one autograd node, so that backward adds the skip gradient while it
+    scatters the pooled one (egm_maxpool2_bwd_add) instead of a scatter pass followed by an axpby pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xk, ldx = _nhwc(x)
+        N, H, W, C = xk.shape
+        y = torch.empty((N, H // 2, W // 2, C), dtype=xk.dtype, device=xk.device)
+        lib().call("egm_maxpool2_fwd", dtype_code(xk.dtype), ptr(xk), ldx, ptr(y), C, N, H, W, C, stream())
+        ctx.save_for_backward(xk)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, gskip, gy):
+        (x,) = ctx.saved_tensors
+        x, ldx = _nhwc(x)
+        N, H, W, C = x.shape
+        if gy is None:
+            return gskip
+        gy, ldg = _nhwc(gy)
+        gx = torch.empty((N, H, W, C), dtype=x.dtype, device=x.device)
+        dt = dtype_code(x.dtype)
+        if gskip is None:
+            lib().call("egm_maxpool2_bwd", dt, ptr(x), ldx, ptr(gy), ldg, ptr(gx), C, N, H, W, C, stream())
+        elif (H | W) & 1:                                       # odd sizes: the zero-tail pass, then the sum
+            lib().call("egm_maxpool2_bwd", dt, ptr(x), ldx, ptr(gy), ldg, ptr(gx), C, N, H, W, C, stream())
+            gx = _axpby(gx, 1.0, gskip, 1.0)
+        else:
+            gs, lds = _nhwc(gskip)
+            lib().call("egm_maxpool2_bwd_add", dt, ptr(x), ldx, ptr(gy), ldg, ptr(gs), lds, ptr(gx), C, N, H, W, C, stream())
+        return gx
+
+
+def fork_maxpool2(x):
+    """(x for the skip connection, maxpool2(x)) with the two gradients of x summed inside the pooling backward."""
+    return _ForkMaxPool2.apply(x)
+
+
 class _UpCat(Function):
     """cat([skip, pad(bilinear_x2(low))], channel)"""
 

@@ -39,8 +39,9 @@ class Down(nn.Sequential):
     def __init__(self, in_channels, out_channels):
         super().__init__(nn.MaxPool2d(2, stride=2), DoubleConv(in_channels, out_channels))
 
-    def forward(self, x):
-        return self[1](ops.maxpool2(x))
+    def forward(self, x, pooled=None):
+        """pooled: maxpool2(x) when the caller already has it (ops.fork_maxpool2 at the skip connection)."""
+        return self[1](ops.maxpool2(x) if pooled is None else pooled)
 
 
 class Up(nn.Module):
@@ -134,11 +135,11 @@ class UNet(_SegNetBase):
 
     def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         x = self._enter(x)
-        x1, x1s = ops.fork2(self.in_conv(x))
-        x2, x2s = ops.fork2(self.down1(x1))
-        x3, x3s = ops.fork2(self.down2(x2))
-        x4, x4s = ops.fork2(self.down3(x3))
-        x5 = self.down4(x4)
+        x1s, p1 = ops.fork_maxpool2(self.in_conv(x))             # skip alias + pooled tensor: the two gradients are summed in the pool's backward
+        x2s, p2 = ops.fork_maxpool2(self.down1(None, pooled=p1))
+        x3s, p3 = ops.fork_maxpool2(self.down2(None, pooled=p2))
+        x4s, p4 = ops.fork_maxpool2(self.down3(None, pooled=p3))
+        x5 = self.down4(None, pooled=p4)
         if self.ddp_boundary is not None:
             x5, x5d = ops.fork2(x5)                              # the decoder-side alias is the boundary tensor
             self.ddp_boundary.extend([x1s, x2s, x3s, x4s, x5d])

@@ -208,6 +208,9 @@ int egm_bn_ew_bwd_apply(int dtype, int mode, const void* g, int ldg, const void*
 int egm_maxpool2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, egm_stream_t s);
 int egm_maxpool2_bwd(int dtype, const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int N, int H, int W,
                      int C, egm_stream_t s);
+/* egm_maxpool2_bwd with a second gradient of x summed in the same pass: dx = scatter(dy) + add (even H, W). */
+int egm_maxpool2_bwd_add(int dtype, const void* x, int ldx, const void* dy, int lddy, const void* add, int ldadd, void* dx, int lddx,
+                         int N, int H, int W, int C, egm_stream_t s);
 /* Up.forward front half (src/EGM-UNet.py:937-947): out = cat([skip, pad(bilinear_x2_align_corners(low))], C).
  * Writes BOTH halves of `out` (ld = ldo >= Cs + Cl): skip [N,Hs,Ws,Cs], low [N,Hl,Wl,Cl].
  * skip == NULL: the skip channels were produced straight into out[..., :Cs] by their own kernel; only the Cl upsampled channels are written. */
