@@ -411,6 +411,47 @@ __global__ void sum4_kernel(const T* __restrict__ a, int lda, const T* __restric
         store8(out + p * ldo + cv * 8, v);
     }
 }
+// out = highpass3(a) + b (+ c) (+ d), highpass3(a) = a - avgpool3x3(a) (zero pad, divisor 9; self-adjoint, so this is also its gradient):
+// the gradient fan-in of a tensor one of whose consumers is EdgeAwareFeatureEnhancer's edge extractor (src/EGM-UNet.py:872-886).
+// The stencil result is rounded to the storage type before the sum, exactly as the separate highpass pass stored it.
+template <typename T>
+__global__ void sum4_hp_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b, int ldb, const T* __restrict__ c, int ldc,
+                               const T* __restrict__ d, int ldd, T* __restrict__ out, int ldo, int N, int H, int W, int C) {
+    const int ncv = C >> 3;
+    const long long total = (long long)N * H * W * ncv;
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        float v[8], u[8], s8[8];
+        zero8(s8);
+        load8(a + p * lda + cv * 8, v);
+#pragma unroll
+        for (int r = -1; r <= 1; ++r)
+#pragma unroll
+            for (int q = -1; q <= 1; ++q) {
+                if (yy + r < 0 || yy + r >= H || xx + q < 0 || xx + q >= W) continue;
+                load8(a + (p + (long long)r * W + q) * lda + cv * 8, u);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s8[j] += u[j];
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<T>(v[j] - s8[j] * (1.f / 9.f)));
+        load8(b + p * ldb + cv * 8, u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += u[j];
+        if (c != nullptr) {
+            load8(c + p * ldc + cv * 8, u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += u[j];
+        }
+        if (d != nullptr) {
+            load8(d + p * ldd + cv * 8, u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += u[j];
+        }
+        store8(out + p * ldo + cv * 8, v);
+    }
+}
 __global__ void vec_add_f32_kernel(float* __restrict__ y, const float* __restrict__ x, long long n) {
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] += x[i];
 }
@@ -483,6 +524,17 @@ extern "C" int egm_maxpool2_bwd_add(int dtype, const void* x, int ldx, const voi
     return EGM_OK;
 }
 
+extern "C" int egm_sum4_hp(int dtype, const void* a, int lda, const void* b, int ldb, const void* c, int ldc, const void* d, int ldd, void* out,
+                           int ldo, int N, int H, int W, int C, egm_stream_t s) {
+    EGM_REQ_VEC("sum4_hp", a, lda, C); EGM_REQ_VEC("sum4_hp", b, ldb, C); EGM_REQ_VEC("sum4_hp", out, ldo, C);
+    if (c != nullptr) EGM_REQ_VEC("sum4_hp", c, ldc, C);
+    if (d != nullptr) EGM_REQ_VEC("sum4_hp", d, ldd, C);
+    EGM_REQUIRE(N > 0 && H > 0 && W > 0, "sum4_hp: bad shape");
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sum4_hp_kernel<T>), dim3(stream_grid((long long)N * H * W * (C / 8))), dim3(256), 0, (hipStream_t)s,
+                                                 (const T*)a, lda, (const T*)b, ldb, (const T*)c, ldc, (const T*)d, ldd, (T*)out, ldo, N, H, W, C));
+    EGM_CHECK_LAUNCH("sum4_hp");
+    return EGM_OK;
+}
 extern "C" int egm_upcat_fwd(int dtype, const void* skip, int lds, const void* low, int ldl, void* out, int ldo, int N, int Hs, int Ws,
                              int Cs, int Hl, int Wl, int Cl, egm_stream_t s) {
     if (skip != nullptr) EGM_REQ_VEC("upcat_fwd", skip, lds, Cs);

@@ -61,10 +61,15 @@ class EdgeAwareFeatureEnhancer(nn.Module):
         self.weight_generator = nn.Sequential(nn.Conv2d(in_channels, in_channels, kernel_size=1), nn.BatchNorm2d(in_channels),
                                               nn.Sigmoid())
 
-    def forward(self, x, x_alias=None):
-        """x_alias: a second autograd alias of x supplied by the caller (so the caller can sum all of x's gradients in one pass)."""
-        xa, xb = (x, x_alias) if x_alias is not None else ops.fork(x, 2)
-        e = ops.highpass3(xa)                                                   # x - avgpool3(x)
+    def forward(self, x, x_alias=None, edge=None):
+        """x_alias: a second autograd alias of x supplied by the caller (so the caller can sum all of x's gradients in one pass);
+        edge: highpass3(x) when the caller produced it together with its aliases (ops.fork_highpass3)."""
+        if edge is not None:
+            e, xb = edge, x_alias
+        elif x_alias is not None:
+            e, xb = ops.highpass3(x), x_alias                                   # x - avgpool3(x)
+        else:
+            e, xb = ops.fork_highpass3(x, 1)                                    # the gate's alias: both gradients of x in one pass
         # x * (1 + sigmoid(BN(conv1x1(e)))): the BatchNorm apply and the gate are one pass (csrc/bn_fused.hip)
         return ops.conv_bn_ew(e, self.weight_generator[0], self.weight_generator[1], ACT_SIGMOID, xb, ops.EW_GATE)
 
@@ -213,8 +218,8 @@ class EdgeEnhancedGRFB(nn.Module):
         return ops.cat_slots(N, H, W, [C, i2, i2, i2], dtype, device)
 
     def forward(self, x, out=None, cat=None):
-        x_e, x_e2, x_cat, x_sc = ops.fork(x, 4)
-        xe = self.edge_enhancer(x_e, x_e2)
+        edge, x_e2, x_cat, x_sc = ops.fork_highpass3(x, 3)       # highpass3(x) + three aliases: backward sums all four gradients in one pass
+        xe = self.edge_enhancer(None, x_e2, edge=edge)
         xe_d, xe_e, xe_c = ops.fork(xe, 3)
         # the three branch tails write straight into their slots of the concat destination (no copy, one tensor write less each)
         N, H, W, C = x.shape

@@ -1234,6 +1234,37 @@ def highpass3(x):
     return _Highpass3.apply(x)
 
 
+class _ForkHighpass(Function):
+    """x -> (highpass3(x), n aliases of x) as one node: backward computes highpass3(g_hp) + sum of the other gradients in ONE pass
+    (egm_sum4_hp) instead of a stencil pass that writes its result and a fan-in pass that reads it back."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return (_hp(x),) + tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, ghp, *gs):
+        gs = [g for g in gs if g is not None]
+        if ghp is None:
+            return (_Fork.backward(ctx, *gs)[0] if gs else None), None
+        if not gs:
+            return _hp(ghp), None
+        while len(gs) > 3:                                    # more than three other consumers: pre-sum the tail
+            gs = gs[:2] + [_Fork.backward(ctx, *gs[2:])[0]]
+        a, lda = _nhwc(ghp)
+        N, H, W, C = a.shape
+        ts = [_nhwc(t) for t in gs] + [(None, 0)] * (3 - len(gs))
+        out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+        lib().call("egm_sum4_hp", dtype_code(a.dtype), ptr(a), lda, ptr(ts[0][0]), ts[0][1], ptr(ts[1][0]), ts[1][1], ptr(ts[2][0]), ts[2][1],
+                   ptr(out), C, N, H, W, C, stream())
+        return out, None
+
+
+def fork_highpass3(x, n):
+    """(highpass3(x), alias_1, ..., alias_n): the edge extractor of EdgeAwareFeatureEnhancer together with x's other consumers."""
+    return _ForkHighpass.apply(x, n)
+
+
 class _GateMul(Function):
     @staticmethod
     def forward(ctx, x, w):

@@ -227,6 +227,10 @@ int egm_axpby(int dtype, const void* a, int lda, float alpha, const void* b, int
 /* out = a + b + c (+ d when non-NULL): gradient fan-in of a tensor with 3-4 consumers in one pass */
 int egm_sum4(int dtype, const void* a, int lda, const void* b, int ldb, const void* c, int ldc, const void* d, int ldd, void* out,
              int ldo, long long npix, int C, egm_stream_t s);
+/* out = highpass3(a) + b (+ c) (+ d) in one pass (c, d may be NULL): gradient fan-in when one consumer of the tensor was egm_highpass3
+ * (the stencil is self-adjoint); highpass3(a) is rounded to the storage type before the sum, like the separate pass. */
+int egm_sum4_hp(int dtype, const void* a, int lda, const void* b, int ldb, const void* c, int ldc, const void* d, int ldd, void* out,
+                int ldo, int N, int H, int W, int C, egm_stream_t s);
 /* fp32 vector add: y[i] += x[i] (parameter-gradient accumulation) */
 int egm_vec_add_f32(float* y, const float* x, long long n, egm_stream_t s);
 int egm_fill_f32(float* y, float v, long long n, egm_stream_t s);
