@@ -2,6 +2,7 @@
 #include "common.h"
 #include "group.h"
 #include <vector>
+#include <stdlib.h>
 
 namespace {
 thread_local bool g_recording = false;
@@ -28,13 +29,16 @@ extern "C" int egm_group_end(egm_stream_t s) {
     g_recording = false;
     std::vector<EgmGroupRec> recs;
     recs.swap(g_recs);
+    // a member that fills the chip on its own gains nothing from sharing a launch (EGM_GROUP_MAX_GRID workgroups and up: alone)
+    static const int max_grid = getenv("EGM_GROUP_MAX_GRID") ? atoi(getenv("EGM_GROUP_MAX_GRID")) : (1 << 30);
     std::vector<char> done(recs.size(), 0);
     for (size_t i = 0; i < recs.size(); ++i) {
         if (done[i]) continue;
         EgmGroupRec batch[EGM_GROUP_MAX];
         int n = 0;
-        for (size_t j = i; j < recs.size() && n < EGM_GROUP_MAX; ++j) {
-            if (!done[j] && recs[j].launch == recs[i].launch) { batch[n++] = recs[j]; done[j] = 1; }
+        batch[n++] = recs[i]; done[i] = 1;
+        for (size_t j = i + 1; j < recs.size() && n < EGM_GROUP_MAX && recs[i].grid < max_grid; ++j) {
+            if (!done[j] && recs[j].launch == recs[i].launch && recs[j].grid < max_grid) { batch[n++] = recs[j]; done[j] = 1; }
         }
         const int rc = recs[i].launch(batch, n, (hipStream_t)s);
         if (rc != EGM_OK) return rc;
