@@ -196,3 +196,15 @@ def test_reducer_paths_match_plain_training_bitwise():
     assert not bad_e, ("eager reducer", bad_e[:6])
     assert not bad_g, ("graphed reducer", bad_g[:6])
     assert not bad_s, ("three-graph step with the exchange between the graphs", bad_s[:6])
+
+
+def test_three_graph_step_over_rccl_single_rank():
+    """The three-graph data-parallel step with the REAL RCCL backend (init_process_group("nccl"), one rank -- all this box can host):
+    the all-reduces are enqueued on the side stream between the graph replays and the weights after three steps are bit-identical to
+    the single-graph step (tools/rccl_single_rank_rehearsal.py, own process: it owns the process group)."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29573", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_single_rank_rehearsal.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all-reduce bucket 0 enqueued on the side stream" in r.stdout and "tensors that differ: 0" in r.stdout
