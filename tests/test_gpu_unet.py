@@ -166,19 +166,21 @@ def test_criterion_no_ignore_no_dice():
     assert_close(criterion({"out": x}, t, dice=False).cpu(), fx["loss_nodice"], 2e-5, 1e-6)
 
 
-def test_criterion_multiclass_vs_oracle():
-    """num_classes=3, weights, ignore: against the CPU oracle on the same seeded inputs."""
+@pytest.mark.parametrize("nc", [3, 6])
+def test_criterion_multiclass_vs_oracle(nc):
+    """num_classes = 3 and 6 (the 4- and 16-class instantiations of the criterion kernels; 2 classes are the fixtures above), weights,
+    ignore: against the CPU oracle on the same seeded inputs."""
     from oracle import loss_ref as L
     from egm_unet_amd.train_utils import criterion
     g = torch.Generator().manual_seed(7)
-    x = torch.randn(2, 3, 24, 40, generator=g)
-    t = torch.randint(0, 3, (2, 24, 40), generator=g)
+    x = torch.randn(2, nc, 24, 40, generator=g)
+    t = torch.randint(0, nc, (2, 24, 40), generator=g)
     t[torch.rand(2, 24, 40, generator=g) < 0.05] = 255
-    lw = torch.tensor([0.5, 1.0, 2.0])
+    lw = torch.tensor([0.5, 1.0, 2.0, 1.5, 0.7, 1.2][:nc])
     xr = x.clone().requires_grad_(True)
-    lr_ = L.criterion({"out": xr}, t, lw, num_classes=3, ignore_index=255); lr_.backward()
+    lr_ = L.criterion({"out": xr}, t, lw, num_classes=nc, ignore_index=255); lr_.backward()
     xg = x.to(DEV).requires_grad_(True)
-    lg = criterion({"out": xg}, t.to(DEV), lw.to(DEV), num_classes=3, ignore_index=255); lg.backward()
+    lg = criterion({"out": xg}, t.to(DEV), lw.to(DEV), num_classes=nc, ignore_index=255); lg.backward()
     assert_close(lg.detach().cpu(), lr_.detach(), 2e-5, 1e-5)
     assert_close(xg.grad.cpu(), xr.grad, 2e-4, 2e-7)
 
