@@ -620,12 +620,16 @@ __global__ __launch_bounds__(256) void ca_mlp_fwd_kernel(const T* __restrict__ p
     extern __shared__ float ca_smem[];
     float* sp = ca_smem;                 // [R][C]
     float* sh = ca_smem + R * C;         // [R][Cr]
+    float* s0 = sh + R * Cr;             // [Cr][C + 1]  the two weight matrices, read once, coalesced (rows padded against bank conflicts)
+    float* s2 = s0 + Cr * (C + 1);       // [C][Cr + 1]
     for (int i = threadIdx.x; i < R * C; i += 256) { const int r = i / C, c = i - r * C; sp[i] = to_f32(pooled[(long long)r * ldp + c]); }
+    for (int i = threadIdx.x; i < Cr * C; i += 256) { const int j = i / C, c = i - j * C; s0[j * (C + 1) + c] = w0[i]; }
+    for (int i = threadIdx.x; i < C * Cr; i += 256) { const int c = i / Cr, j = i - c * Cr; s2[c * (Cr + 1) + j] = w2[i]; }
     __syncthreads();
     for (int i = threadIdx.x; i < R * Cr; i += 256) {
         const int r = i / Cr, j = i - r * Cr;
         float a = 0.f;
-        for (int c = 0; c < C; ++c) a = fmaf(w0[j * C + c], sp[r * C + c], a);
+        for (int c = 0; c < C; ++c) a = fmaf(s0[j * (C + 1) + c], sp[r * C + c], a);
         a = to_f32(from_f32<T>(a));
         a = a > 0.f ? a : 0.f;
         sh[i] = a; h_out[i] = a;
@@ -634,7 +638,7 @@ __global__ __launch_bounds__(256) void ca_mlp_fwd_kernel(const T* __restrict__ p
     for (int i = threadIdx.x; i < R * C; i += 256) {
         const int r = i / C, c = i - r * C;
         float a = 0.f;
-        for (int j = 0; j < Cr; ++j) a = fmaf(w2[c * Cr + j], sh[r * Cr + j], a);
+        for (int j = 0; j < Cr; ++j) a = fmaf(s2[c * (Cr + 1) + j], sh[r * Cr + j], a);
         logits[(long long)r * ldo + c] = from_f32<T>(a);
     }
 }
@@ -648,16 +652,20 @@ __global__ __launch_bounds__(256) void ca_mlp_bwd_kernel(const T* __restrict__ d
     float* sp = sdl + R * C;             // [R][C]
     float* sh = sp + R * C;              // [R][Cr]
     float* sdh = sh + R * Cr;            // [R][Cr]
+    float* s0 = sdh + R * Cr;            // [Cr][C + 1]
+    float* s2 = s0 + Cr * (C + 1);       // [C][Cr + 1]
     for (int i = threadIdx.x; i < R * C; i += 256) {
         const int r = i / C, c = i - r * C;
         sdl[i] = to_f32(dl[(long long)r * ldd + c]); sp[i] = to_f32(pooled[(long long)r * ldp + c]);
     }
     for (int i = threadIdx.x; i < R * Cr; i += 256) sh[i] = h[i];
+    for (int i = threadIdx.x; i < Cr * C; i += 256) { const int j = i / C, c = i - j * C; s0[j * (C + 1) + c] = w0[i]; }
+    for (int i = threadIdx.x; i < C * Cr; i += 256) { const int c = i / Cr, j = i - c * Cr; s2[c * (Cr + 1) + j] = w2[i]; }
     __syncthreads();
     for (int i = threadIdx.x; i < R * Cr; i += 256) {                    // dh = (W2^T dl) . relu'(h), rounded like the activation gradient
         const int r = i / Cr, j = i - r * Cr;
         float a = 0.f;
-        for (int c = 0; c < C; ++c) a = fmaf(w2[c * Cr + j], sdl[r * C + c], a);
+        for (int c = 0; c < C; ++c) a = fmaf(s2[c * (Cr + 1) + j], sdl[r * C + c], a);
         a = to_f32(from_f32<T>(a));
         sdh[i] = sh[i] > 0.f ? a : 0.f;
     }
@@ -677,7 +685,7 @@ __global__ __launch_bounds__(256) void ca_mlp_bwd_kernel(const T* __restrict__ d
     for (int i = threadIdx.x; i < R * C; i += 256) {                     // dp = W0^T dh
         const int r = i / C, c = i - r * C;
         float a = 0.f;
-        for (int j = 0; j < Cr; ++j) a = fmaf(w0[j * C + c], sdh[r * Cr + j], a);
+        for (int j = 0; j < Cr; ++j) a = fmaf(s0[j * (C + 1) + c], sdh[r * Cr + j], a);
         dpooled[(long long)r * lddp + c] = from_f32<T>(a);
     }
 }
@@ -909,7 +917,7 @@ extern "C" int egm_ca_mlp_fwd(int dtype, const void* pooled, int ldp, const floa
                               int C, int Cr, egm_stream_t s) {
     EGM_REQUIRE(pooled && w0 && w2 && h && logits, "ca_mlp_fwd: null pointer");
     EGM_REQUIRE(R > 0 && C > 0 && Cr > 0 && ldp >= C && ldo >= C, "ca_mlp_fwd: bad shape R=%d C=%d Cr=%d", R, C, Cr);
-    const size_t smem = (size_t)(R * C + R * Cr) * sizeof(float);
+    const size_t smem = (size_t)(R * C + R * Cr + Cr * (C + 1) + C * (Cr + 1)) * sizeof(float);
     EGM_REQUIRE(smem <= 64 * 1024, "ca_mlp_fwd: %d rows x %d channels do not fit one workgroup's LDS", R, C);
     EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ca_mlp_fwd_kernel<T>), dim3(1), dim3(256), smem, (hipStream_t)s, (const T*)pooled, ldp, w0, w2, h,
                                                  (T*)logits, ldo, R, C, Cr));
@@ -920,7 +928,7 @@ extern "C" int egm_ca_mlp_bwd(int dtype, const void* dlogits, int ldd, const voi
                               const float* w2, float* dw0, float* dw2, void* dpooled, int lddp, int R, int C, int Cr, egm_stream_t s) {
     EGM_REQUIRE(dlogits && pooled && h && w0 && w2 && dw0 && dw2 && dpooled, "ca_mlp_bwd: null pointer");
     EGM_REQUIRE(R > 0 && C > 0 && Cr > 0 && ldd >= C && ldp >= C && lddp >= C, "ca_mlp_bwd: bad shape R=%d C=%d Cr=%d", R, C, Cr);
-    const size_t smem = (size_t)(2 * R * C + 2 * R * Cr) * sizeof(float);
+    const size_t smem = (size_t)(2 * R * C + 2 * R * Cr + Cr * (C + 1) + C * (Cr + 1)) * sizeof(float);
     EGM_REQUIRE(smem <= 64 * 1024, "ca_mlp_bwd: %d rows x %d channels do not fit one workgroup's LDS", R, C);
     EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ca_mlp_bwd_kernel<T>), dim3(1), dim3(256), smem, (hipStream_t)s, (const T*)dlogits, ldd,
                                                  (const T*)pooled, ldp, h, w0, w2, dw0, dw2, (T*)dpooled, lddp, R, C, Cr));

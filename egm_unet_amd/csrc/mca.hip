@@ -115,6 +115,12 @@ __device__ __forceinline__ float axis_count(int ax, int H, int W, int C) {
 __global__ void mca_gates_fwd_kernel(const float* __restrict__ sums, GateParams gp, float* __restrict__ stats, float* __restrict__ o,
                                      float* __restrict__ gates, int N, int H, int W, int C) {
     const int L = H + W + C, total = N * L;
+    // gate parameters once into LDS: read through gp's pointers inside the loops they were two dependent global round trips (and two
+    // expf) per element of a one-workgroup kernel that is pure latency
+    __shared__ float sk[3][8], sab[3][2];
+    if (threadIdx.x < 24) { const int a = threadIdx.x >> 3, t = threadIdx.x & 7; sk[a][t] = t < gp.ks[a] ? gp.k[a][t] : 0.f; }
+    else if (threadIdx.x >= 32 && threadIdx.x < 38) { const int a = (threadIdx.x - 32) >> 1, j = (threadIdx.x - 32) & 1; sab[a][j] = 0.5f + sigm(gp.w[a][j]); }
+    __syncthreads();
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         int ax, idx, len; axis_of(e, H, W, C, ax, idx, len);
         const double cnt = (double)axis_count(ax, H, W, C);
@@ -124,14 +130,14 @@ __global__ void mca_gates_fwd_kernel(const float* __restrict__ sums, GateParams 
         if (var < 0.0) var = 0.0;
         const float sd = (float)sqrt(var);
         stats[e * 2] = (float)mean; stats[e * 2 + 1] = sd;
-        o[e] = (0.5f + sigm(gp.w[ax][0])) * (float)mean + (0.5f + sigm(gp.w[ax][1])) * sd;
+        o[e] = sab[ax][0] * (float)mean + sab[ax][1] * sd;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         int ax, idx, len; axis_of(e, H, W, C, ax, idx, len);
         const int ks = gp.ks[ax], pad = (ks - 1) / 2;
         float z = 0.f;
-        for (int t = 0; t < ks; ++t) { const int j = idx + t - pad; if (j >= 0 && j < len) z += gp.k[ax][t] * o[e - idx + j]; }
+        for (int t = 0; t < ks; ++t) { const int j = idx + t - pad; if (j >= 0 && j < len) z += sk[ax][t] * o[e - idx + j]; }
         gates[e] = sigm(z);
     }
 }
@@ -140,6 +146,9 @@ __global__ void mca_gates_bwd_kernel(const float* __restrict__ dG, const float* 
                                      const float* __restrict__ gates, GateParams gp, float* __restrict__ dz, float* __restrict__ coef,
                                      float* __restrict__ dwts, float* __restrict__ dks, int N, int H, int W, int C) {
     const int L = H + W + C, total = N * L;
+    __shared__ float sk[3][8], sab[3][2];                           // gate parameters once into LDS (see mca_gates_fwd_kernel)
+    if (threadIdx.x < 24) { const int a = threadIdx.x >> 3, t = threadIdx.x & 7; sk[a][t] = t < gp.ks[a] ? gp.k[a][t] : 0.f; }
+    else if (threadIdx.x >= 32 && threadIdx.x < 38) { const int a = (threadIdx.x - 32) >> 1, j = (threadIdx.x - 32) & 1; sab[a][j] = 0.5f + sigm(gp.w[a][j]); }
     for (int e = threadIdx.x; e < total; e += blockDim.x) dz[e] = dG[e * 2] * (1.f / 3.f) * gates[e] * (1.f - gates[e]);
     __syncthreads();
     // per-thread partials of everything that is summed over the entries: d(alpha), d(beta) per axis and the <= 7 kernel taps
@@ -151,8 +160,8 @@ __global__ void mca_gates_bwd_kernel(const float* __restrict__ dG, const float* 
         int ax, idx, len; axis_of(e, H, W, C, ax, idx, len);
         const int ks = gp.ks[ax], pad = (ks - 1) / 2;
         float d_o = 0.f;                                           // do_j = sum_t k[t] * dz[j - t + pad]
-        for (int t = 0; t < ks; ++t) { const int i = idx - t + pad; if (i >= 0 && i < len) d_o += gp.k[ax][t] * dz[e - idx + i]; }
-        const float alpha = 0.5f + sigm(gp.w[ax][0]), beta = 0.5f + sigm(gp.w[ax][1]);
+        for (int t = 0; t < ks; ++t) { const int i = idx - t + pad; if (i >= 0 && i < len) d_o += sk[ax][t] * dz[e - idx + i]; }
+        const float alpha = sab[ax][0], beta = sab[ax][1];
         const float mean = stats[e * 2], sd = stats[e * 2 + 1];
         const float cnt = axis_count(ax, H, W, C);
         const float dmean = alpha * d_o, dsd = beta * d_o;

@@ -294,7 +294,7 @@ int egm_global_avgmax_bwd(int dtype, const void* gout, const int* argidx, void* 
 int egm_rows_dup(int dtype, const float* red, void* dst, int ldd, int N, int C, egm_stream_t s);
 /* ChannelAttentionModule.fc (src/EGM-UNet.py:1171-1190) on the R = 2N pooled rows: logits = W2 . relu(W0 . pooled).  w0 fp32 [Cr][C],
  * w2 fp32 [C][Cr] (the 1x1 conv weights as stored), h fp32 [R][Cr] = the hidden activation kept for backward.  One workgroup each;
- * (R*C + R*Cr) floats (forward) / twice that (backward) must fit 64 KB of LDS.  Backward OVERWRITES dw0 / dw2. */
+ * the rows, the hidden activations and both weight matrices must fit 64 KB of LDS (C = 128, Cr = 32, R = 16: 46 KB backward).  Backward OVERWRITES dw0 / dw2. */
 int egm_ca_mlp_fwd(int dtype, const void* pooled, int ldp, const float* w0, const float* w2, float* h, void* logits, int ldo, int R,
                    int C, int Cr, egm_stream_t s);
 int egm_ca_mlp_bwd(int dtype, const void* dlogits, int ldd, const void* pooled, int ldp, const float* h, const float* w0,
