@@ -472,7 +472,9 @@ __global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2) ? 2 : 1) void c
 //   A consumer and a producer wave share each SIMD: the producers' VALU work (50-55 instructions per 16-byte vector for the
 //   BatchNorm backward) runs beside the consumers' MFMAs instead of in front of them -- in the one-wave-per-SIMD kernel above the
 //   same prologue work is serialised with the matrix work and doubles the kernel.  One barrier per tile.
-template <int NTAPS, bool PRE>
+// ROT: the row-rotation consumer loop (9 taps, every wave walks all rows of the tile: p.C == 1); its own instantiation, because a kernel
+// that carries both consumer loops spills (660 bytes per lane)
+template <int NTAPS, bool PRE, bool ROT>
 __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using M = WMma<bf16_t>;
@@ -720,6 +722,49 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) acc[t] = M::mma(fa, fb[t], acc[t]);
         };
+        if constexpr (ROT) {
+            static_assert(NTAPS == 9, "row rotation is the 3x3 form");
+            {
+                // Row rotation (the 64-wide layers: every wave walks ALL rows of the tile).  Tap (r, s) of output row ry reads patch row
+                // ry + r, and that is the row tap (r - 1, s) reads one step later: the three patch rows of a step stay in registers and
+                // only ONE new row (3 fragments, one per kernel column) plus the dy fragment is read per 9 MFMAs -- 0.44 KB of LDS per
+                // MFMA instead of 1.1 KB (10 fragments per 9 MFMAs asked for 142 B/clk of a CU whose LDS delivers 128: the kernel was
+                // LDS-bound at 22 % MFMA-busy, 37 % on its best launches).  The k-step halves of a row run as two passes; the r = 2
+                // taps come last in a step, so the new row's reads have six MFMAs to land.
+                // one step = one output row: reads patch row ry + 2 into `n` and the NEXT row's dy fragment, multiplies with the rows held
+                // in (a, b, n); the callers rotate the three row sets, so no fragment is ever moved between registers
+                auto row_step = [&](int ry, int k0, M::Frag (&ra)[3], M::Frag (&rb)[3], M::Frag (&rn)[3], M::Frag& fa, M::Frag& fan)
+                                    __attribute__((always_inline)) {
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) rn[sx] = M::load(bblk, (ry + 2) * PW + k0 + sx, lane);
+                    if (ry + 1 < TH) fan = M::load(ablk, (ry + 1) * TW + k0, lane);
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) acc[sx] = M::mma(fa, ra[sx], acc[sx]);
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) acc[3 + sx] = M::mma(fa, rb[sx], acc[3 + sx]);
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) acc[6 + sx] = M::mma(fa, rn[sx], acc[6 + sx]);
+                    __builtin_amdgcn_sched_barrier(0);              // keeps the next steps' reads from being hoisted (spills otherwise)
+                };
+#pragma unroll 1
+                for (int k0 = 0; k0 < TW; k0 += M::kStep) {
+                    M::Frag r0[3], r1[3], r2[3], f0, f1;
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) { r0[sx] = M::load(bblk, k0 + sx, lane); r1[sx] = M::load(bblk, PW + k0 + sx, lane); }
+                    f0 = M::load(ablk, k0, lane);
+                    static_assert(TH == 8, "the row rotation below is written out for 8-row tiles");
+                    row_step(0, k0, r0, r1, r2, f0, f1);
+                    row_step(1, k0, r1, r2, r0, f1, f0);
+                    row_step(2, k0, r2, r0, r1, f0, f1);
+                    row_step(3, k0, r0, r1, r2, f1, f0);
+                    row_step(4, k0, r1, r2, r0, f0, f1);
+                    row_step(5, k0, r2, r0, r1, f1, f0);
+                    row_step(6, k0, r0, r1, r2, f0, f1);
+                    row_step(7, k0, r1, r2, r0, f1, f0);
+                }
+                return;
+            }
+        }
         M::Frag fa0, fa1, fb0[NTAPS], fb1[NTAPS];
         if (wc < TH) load_step(wc, 0, fa0, fb0);
         for (int ry = wc; ry < TH; ry += p.C) {
@@ -776,15 +821,15 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
     }
 }
 
-template <int NTAPS, bool PRE>
+template <int NTAPS, bool PRE, bool ROT>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(WgradParams p) {
-    conv_wgrad_ws_body<NTAPS, PRE>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+    conv_wgrad_ws_body<NTAPS, PRE, ROT>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
-template <int NTAPS>
+template <int NTAPS, bool ROT>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_multi_kernel(WgradMulti m) {
     int bx, by, bz;
     const int i = wgrad_multi_member(m, bx, by, bz);
-    conv_wgrad_ws_body<NTAPS, false>(m.p[i], bx, by, bz);
+    conv_wgrad_ws_body<NTAPS, false, ROT>(m.p[i], bx, by, bz);
 }
 
 // sum slabs in fixed order and scatter to fp32 OIHW (real, possibly grouped, shape).
@@ -956,16 +1001,16 @@ int launch_wgrad_group(const EgmGroupRec* recs, int n, hipStream_t st) {
     }
     return launch_wgrad_group_impl(recs, n, st, conv_wgrad_kernel<T, NTAPS, false>, conv_wgrad_multi_kernel<T, NTAPS>, 256, "conv_wgrad (group)");
 }
-template <int NTAPS>
+template <int NTAPS, bool ROT>
 int launch_wgrad_ws_group(const EgmGroupRec* recs, int n, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ws_multi_kernel<NTAPS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ws_multi_kernel<NTAPS, ROT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_wgrad_ws_multi: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    return launch_wgrad_group_impl(recs, n, st, conv_wgrad_ws_kernel<NTAPS, false>, conv_wgrad_ws_multi_kernel<NTAPS>, 512, "conv_wgrad_ws (group)");
+    return launch_wgrad_group_impl(recs, n, st, conv_wgrad_ws_kernel<NTAPS, false, ROT>, conv_wgrad_ws_multi_kernel<NTAPS, ROT>, 512, "conv_wgrad_ws (group)");
 }
 // records the launch when a group is open on this thread (only the prologue-free kernels have a merged form)
 inline bool wgrad_record(int (*fn)(const EgmGroupRec*, int, hipStream_t), const WgradParams& p, dim3 grid, size_t smem) {
@@ -997,22 +1042,30 @@ int launch_wgrad_pre(const WgradParams& p, const WgradPlan& pl, hipStream_t st) 
     EGM_CHECK_LAUNCH("conv_wgrad");
     return EGM_OK;
 }
-template <int NTAPS, bool PRE>
-int launch_wgrad_ws(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
+template <int NTAPS, bool PRE, bool ROT>
+int launch_wgrad_ws_rot(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ws_kernel<NTAPS, PRE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ws_kernel<NTAPS, PRE, ROT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_wgrad_ws: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     dim3 grid(pl.nsplit, pl.nco_tiles * pl.nci_tiles, pl.ngroups);
     if constexpr (!PRE) {
-        if (wgrad_record(&launch_wgrad_ws_group<NTAPS>, p, grid, pl.smem)) return EGM_OK;
+        if (wgrad_record(&launch_wgrad_ws_group<NTAPS, ROT>, p, grid, pl.smem)) return EGM_OK;
     }
-    hipLaunchKernelGGL((conv_wgrad_ws_kernel<NTAPS, PRE>), grid, dim3(512), pl.smem, st, p);
+    hipLaunchKernelGGL((conv_wgrad_ws_kernel<NTAPS, PRE, ROT>), grid, dim3(512), pl.smem, st, p);
     EGM_CHECK_LAUNCH("conv_wgrad_ws");
     return EGM_OK;
+}
+template <int NTAPS, bool PRE>
+int launch_wgrad_ws(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
+    if constexpr (NTAPS == 9) {
+        static const bool rot_on = getenv("EGM_WGRAD_ROT") ? atoi(getenv("EGM_WGRAD_ROT")) != 0 : true;
+        if (pl.C == 1 && rot_on) return launch_wgrad_ws_rot<NTAPS, PRE, true>(p, pl, st);
+    }
+    return launch_wgrad_ws_rot<NTAPS, PRE, false>(p, pl, st);
 }
 template <typename T, int NTAPS>
 int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
