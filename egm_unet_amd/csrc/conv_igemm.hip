@@ -269,8 +269,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 //   * R = tile rows per wave (workgroup tile = 4R x 32 pixels).  Within a k-step every patch-row fragment is read from LDS
 //     ONCE and fed to all (output row, kernel row) pairs that use it, and the weight fragments of one kernel column are
 //     held in registers across the patch rows: LDS reads per MFMA = (WH*NT + R+WH-1) / (R*WH*NT) per kernel column, i.e.
-//     0.5 (R=4, NT=2, 3x3) instead of 1.0 for the naive "two loads per MFMA pair" order -- LDS bandwidth (128 B/clk/CU)
-//     is what bounds a 32x32x16 MFMA loop fed from LDS.
+//     0.5 (R=4, NT=2, 3x3) instead of 1.0 for the naive "two loads per MFMA pair" order (fewer reads to schedule around the MFMAs;
+//     the LDS array itself, 256 B/clk/CU, is not saturated by either).
 template <int WH, int WW, int R> struct PipeGeom {
     static constexpr int THR = 4 * R;
     static constexpr int PH = THR + WH - 1, PW = TW + WW - 1, NTAPS = WH * WW;

@@ -727,9 +727,10 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
             {
                 // Row rotation (the 64-wide layers: every wave walks ALL rows of the tile).  Tap (r, s) of output row ry reads patch row
                 // ry + r, and that is the row tap (r - 1, s) reads one step later: the three patch rows of a step stay in registers and
-                // only ONE new row (3 fragments, one per kernel column) plus the dy fragment is read per 9 MFMAs -- 0.44 KB of LDS per
-                // MFMA instead of 1.1 KB (10 fragments per 9 MFMAs asked for 142 B/clk of a CU whose LDS delivers 128: the kernel was
-                // LDS-bound at 22 % MFMA-busy, 37 % on its best launches).  The k-step halves of a row run as two passes; the r = 2
+                // only ONE new row (3 fragments, one per kernel column) plus the dy fragment is read per 9 MFMAs: 0.9 ds_read_b64_tr_b16
+                // per MFMA gap instead of 2.2.  Measured: 5-10 % on these launches (r02) -- up to three such reads per gap are nearly free
+                // on this LDS array (256 B/clk/CU), so the plain loop was not LDS-bound; what is saved is issue slots and waits.  The
+                // k-step halves of a row run as two passes; the r = 2
                 // taps come last in a step, so the new row's reads have six MFMAs to land.
                 // one step = one output row: reads patch row ry + 2 into `n` and the NEXT row's dy fragment, multiplies with the rows held
                 // in (a, b, n); the callers rotate the three row sets, so no fragment is ever moved between registers

@@ -6,11 +6,12 @@
 // forward and (with the flipped pack `wd`) data gradient: the layers that are MFMA-bound (AI 287 .. 1117 FLOP/B).
 //
 // One workgroup = 16 x 32 pixels x 64 couts, K loop over 16-channel chunks, the (16+2) x (32+2) halo patch and the 9 x 64 weight rows
-// of the chunk in LDS (57 KB per stage, two stages).  The point of the shape is LDS bandwidth: every v_mfma_f32_32x32x16_bf16 (32 clk)
-// of the 8 x 32-pixel kernels (conv_igemm_pipe_kernel<2,3,3,2>, and this kernel's first version) needs 0.83 KB of LDS fragments, i.e.
-// 106 B/clk for four SIMDs plus the staging writes against the CU's 128 B/clk -- they are LDS-bound at 30-45 % MFMA-busy.  With FOUR
-// output rows per consumer wave the six weight fragments of a kernel column and the six patch-row fragments feed 24 MFMAs: 0.5 KB per
-// MFMA.  16-channel chunks keep two stages inside 160 KB.  The workgroup has EIGHT waves with two roles (as conv_wgrad_ws_kernel):
+// of the chunk in LDS (57 KB per stage, two stages).  The shape was chosen to cut LDS fragment traffic: the 8 x 32-pixel kernels
+// (conv_igemm_pipe_kernel<2,3,3,2>, and this kernel's first version) issue 0.83 ds_read_b128 per v_mfma_f32_32x32x16_bf16; with FOUR
+// output rows per consumer wave the six weight fragments of a kernel column and the six patch-row fragments feed 24 MFMAs: 0.5 per
+// MFMA.  It made no difference (see egm_conv_ws_plan below): the LDS array delivers 256 B/clk/CU and up to two such reads per MFMA gap
+// are nearly free (MI355X_MICROARCH.md), so fragment traffic was never the limit.
+// 16-channel chunks keep two stages inside 160 KB.  The workgroup has EIGHT waves with two roles (as conv_wgrad_ws_kernel):
 //   * waves 0-3, one per SIMD, are CONSUMERS (4 rows x 32 pixels x 64 couts each): their loop holds nothing but LDS fragment reads and 72 MFMAs per stage; no global
 //     load, no LDS write, no address arithmetic for staging.  In the 4-wave pipelined kernel the same wave issues the next stage's
 //     global loads before its MFMAs and writes them to LDS after them, behind two barriers per stage: 52 % of its time was the MFMA
