@@ -10,6 +10,7 @@ Prints ONE JSON line (rank 0) with the extra `roofline` (dominant kernel, timed 
 instrumented step outside the timed region) and `cpu_baseline` (CPU oracle on a bounded sample) objects.
 """
 import argparse
+import contextlib
 import ctypes
 import json
 import os
@@ -364,7 +365,8 @@ def ablation_bench(args, dev, rank, world):
 
     # (b) the whole network at 1024 x 1024
     torch.manual_seed(0)
-    model = GRFBUNet(3, 2, base_c=32).to(dev).train()
+    with contextlib.redirect_stdout(sys.stderr):           # the constructor prints a line like the reference's (src/EGM-UNet.py:516); stdout carries the JSON line only
+        model = GRFBUNet(3, 2, base_c=32).to(dev).train()
     model.set_compute_dtype(dt)
     opt = SGD(model.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
     x, t = synth_batch(B, S, S, 1000 + rank, dev)
@@ -438,7 +440,8 @@ def main():
     require_gpu()
 
     torch.manual_seed(0)                                   # identical initial weights on every rank
-    model = GRFBUNet(3, 2, base_c=32).to(dev).train()
+    with contextlib.redirect_stdout(sys.stderr):           # the constructor prints a line like the reference's (src/EGM-UNet.py:516); stdout carries the JSON line only
+        model = GRFBUNet(3, 2, base_c=32).to(dev).train()
     model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     opt = SGD(model.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
     reducer = GradAllReducer(model, world_size=world) if world > 1 else None
