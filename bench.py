@@ -140,6 +140,13 @@ class KernelTimer:
                         "frac_of_layer_roofline": round(roof_t / t, 3)})
         return out
 
+    def _kernel_name(self, entry, dtype, N, H, W, Cin, Cout, KH, KW, dil):
+        """The kernel a conv call takes, spelled as in a rocprofv3 kernel trace (egm_conv_kernel_name / egm_conv_wgrad_kernel_name), so
+        that the per-launch averages below sit beside the matching rows of profiles/*_kernel_trace_summary.md."""
+        buf = ctypes.create_string_buffer(96)
+        getattr(self.lib.cdll, entry)(dtype, 0, N, H, W, Cin, Cout, KH, KW, dil, ctypes.cast(buf, ctypes.c_void_p), 96)
+        return buf.value.decode()
+
     def summary(self):
         agg = {}
         for name, args, e0, e1 in self.records:
@@ -147,14 +154,14 @@ class KernelTimer:
             flops = 0.0
             if name == "egm_conv_fwd":
                 # (dtype, x, ldx, wf, bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, KH, KW, dil, stream)
-                N, H, W, Cin, Cout, KH, KW = args[9:16]
+                N, H, W, Cin, Cout, KH, KW, dil = args[9:17]
                 flops = 2.0 * N * H * W * Cin * Cout * KH * KW
-                key = f"egm_conv_fwd[{KH}x{KW}]"
+                key = self._kernel_name("egm_conv_kernel_name", args[0], N, H, W, Cin, Cout, KH, KW, dil)
             elif name == "egm_conv_wgrad":
                 N, H, W, Cin, Cout = args[7:12]
-                KH, KW = args[14:16]
+                KH, KW, dil = args[14:17]
                 flops = 2.0 * N * H * W * Cin * Cout * KH * KW
-                key = f"egm_conv_wgrad[{KH}x{KW}]"
+                key = self._kernel_name("egm_conv_wgrad_kernel_name", args[0], N, H, W, Cin, Cout, KH, KW, dil)
             a = agg.setdefault(key, [0, 0.0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += flops
             if flops:
@@ -502,8 +509,14 @@ def main():
     # rank 0 reports.  After a captured graph the reducer's autograd hooks are off: switch them back on for this eager step.
     if reducer is not None:
         reducer.hooks_enabled = True
-    with KernelTimer(lib()) as kt:
-        eager_step()
+    from egm_unet_amd import ops as _ops
+    grouped = _ops.group_convs()
+    _ops.group_convs(False)                 # every conv launched (and timed) on its own: inside a launch group the calls only record
+    try:
+        with KernelTimer(lib()) as kt:
+            eager_step()
+    finally:
+        _ops.group_convs(grouped)
     if rank == 0:
         agg = kt.summary()
         total_ms = sum(v[1] for v in agg.values())
@@ -515,8 +528,11 @@ def main():
         if os.path.exists(tpath) and args.dtype == "bf16":
             traffic_source = (os.path.relpath(tpath, ROOT) + ": rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this command, recorded "
                               "earlier and checked in (FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); not collected by this run")
+            cat = ("conv_fwd[3x3]" if "pipe_kernel<" in dom_key and ", 3, 3, " in dom_key else
+                   "conv_fwd[1x1]" if "pipe_kernel<" in dom_key and ", 1, 1, " in dom_key else
+                   "conv_wgrad[3x3]" if "wgrad" in dom_key and "<9" in dom_key else None)
             for k, v in json.load(open(tpath)).items():
-                if k.startswith(dom_key.split("[")[0].replace("egm_", "")) and dom_key.split("[")[1][:3] in k:
+                if cat is not None and k.startswith(cat):
                     traffic = v["hbm_bytes_per_launch_corrected"]
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3,
                     "unit": "TFLOP/s", "frac": round(achieved / (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3), 4),

@@ -26,6 +26,7 @@
 #include "prologue.h"
 #include "group.h"
 #include <string.h>
+#include <stdio.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -837,6 +838,22 @@ ConvPlan conv_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, in
 }
 }  // namespace
 
+// The name of the kernel egm_conv_fwd_pre takes for a shape, as rocprofv3 prints it (template arguments included): lets a harness
+// put its own per-launch timings beside the matching row of a kernel trace.  Returns the length written (buf may be NULL).
+extern "C" int egm_conv_kernel_name(int dtype, int pre_mode, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen) {
+    if (KH == 1 && KW == 1) dil = 1;
+    const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, pre_mode);
+    char tmp[96];
+    const int pre = pre_mode == EGM_PRE_NONE ? 0 : 1;
+    if (c.ws) snprintf(tmp, sizeof(tmp), "conv3x3_ws_kernel");
+    else if (c.direct) snprintf(tmp, sizeof(tmp), "conv_direct_kernel<%d, %d, %s>", c.NT, pre, KH == 1 ? "true" : "false");
+    else if (c.pipe) snprintf(tmp, sizeof(tmp), "conv_igemm_pipe_kernel<%d, %d, %d, %d, %d>", c.NT, (KH == 3 && dil == 1) ? 3 : 1,
+                              (KH == 3 && dil == 1) ? 3 : (KH == 7 ? 7 : 1), c.R, pre);
+    else snprintf(tmp, sizeof(tmp), "conv_igemm_kernel<%s, %d>", dtype == EGM_BF16 ? "bf16_t" : "float", c.NT);
+    const int n = (int)strlen(tmp);
+    if (buf != nullptr && buflen > 0) { strncpy(buf, tmp, (size_t)buflen - 1); buf[buflen - 1] = 0; }
+    return n;
+}
 extern "C" int egm_conv_stats_tiles(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil) {
     return conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil).G;
 }

@@ -24,6 +24,7 @@
 #include "prologue.h"
 #include "group.h"
 #include <string.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1106,6 +1107,21 @@ extern "C" long long egm_conv_wgrad_workspace(int N, int H, int W, int Cin, int 
     return a;
 }
 
+// Name of the kernel egm_conv_wgrad_pre launches for a shape, spelled like the rows of a rocprofv3 kernel trace (see egm_conv_kernel_name)
+extern "C" int egm_conv_wgrad_kernel_name(int dtype, int pre, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen) {
+    WgradPlan pl;
+    if (KH == 1 && KW == 1) dil = 1;
+    if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl, pre != 0) != EGM_OK) return -1;
+    char tmp[96];
+    static const bool rot_on = getenv("EGM_WGRAD_ROT") ? atoi(getenv("EGM_WGRAD_ROT")) != 0 : true;
+    if (dtype == EGM_BF16 && pl.ws)
+        snprintf(tmp, sizeof(tmp), "conv_wgrad_ws_kernel<%d, %s, %s>", pl.ntaps, pre ? "true" : "false", (pl.ntaps == 9 && pl.C == 1 && rot_on) ? "true" : "false");
+    else
+        snprintf(tmp, sizeof(tmp), "conv_wgrad_kernel<%s, %d, %s>", dtype == EGM_BF16 ? "bf16_t" : "float", pl.ntaps, pre ? "true" : "false");
+    const int n = (int)strlen(tmp);
+    if (buf != nullptr && buflen > 0) { strncpy(buf, tmp, (size_t)buflen - 1); buf[buflen - 1] = 0; }
+    return n;
+}
 extern "C" int egm_conv_wgrad_slabs(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil) {
     return egm_conv_wgrad_slabs_pre(dtype, 0, N, H, W, Cin, Cout, KH, KW, dil);
 }

@@ -77,6 +77,9 @@ int egm_conv_pack_multi(int dtype, const void* table_dev, int n, long long total
 int egm_group_begin(void);
 int egm_group_end(egm_stream_t s);
 int egm_group_abort(void);
+/* Name of the kernel egm_conv_fwd_pre launches for a shape, spelled like the rows of a rocprofv3 kernel trace (e.g.
+ * "conv_igemm_pipe_kernel<2, 3, 3, 2, 0>"); returns its length, copies at most buflen-1 characters into buf (may be NULL). */
+int egm_conv_kernel_name(int dtype, int pre_mode, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen);
 /* y = conv(x, wf) (+bias).  Cin/Cout are the PADDED counts of wf.  bias (fp32, bias_n <= Cout valid entries; the rest count as 0) may be NULL.
  * stats, when non-NULL, receives per-pixel-tile partial sums [ntiles][2][Cout] of y and y*y
  * (consumed by egm_bn_finalize); egm_conv_stats_tiles() gives ntiles for the same dtype/shape/kernel.
@@ -112,6 +115,7 @@ int egm_conv_wgrad_pre(int dtype, const void* x, int ldx, int xpre_mode, int xpr
  * workspace; egm_wgrad_reduce_multi() then finishes MANY convolutions in one launch.  table_dev: device array of 56-byte
  * entries {const float* slab; float* dw; int nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate, chunk0, pad;};
  * chunks per entry = ceil(taps*CoutP*CinP / egm_wgrad_reduce_chunk()), chunk0 / total_chunks as for egm_conv_pack_multi. */
+int egm_conv_wgrad_kernel_name(int dtype, int pre, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen);   /* as egm_conv_kernel_name */
 int egm_conv_wgrad_slabs(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
 int egm_wgrad_reduce_chunk(void);   /* packed elements reduced by one workgroup of egm_wgrad_reduce_multi */
 int egm_wgrad_reduce_multi(const void* table_dev, int n, long long total_chunks, egm_stream_t s);
