@@ -115,6 +115,7 @@ __device__ __forceinline__ void conv_direct_body(const DirectParams& p, const in
             n = (int)(pp / hw); const int rem = (int)(pp - (long long)n * hw);
             y = rem / p.W; x = rem - y * p.W;
         }
+        const long long pb = ((long long)(n * p.H + y) * p.W + x) * p.ldx + h * 8;      // this lane's pixel, element offset
         f32x16_t acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -124,7 +125,8 @@ __device__ __forceinline__ void conv_direct_body(const DirectParams& p, const in
         // Taps are loaded TG at a time with KS k-steps each, ALL issued before the first MFMA: with one tap in flight per wave the
         // kernel was latency-bound (9 dependent round trips per block: 51 us for the 32 -> 32 dilated layers at 8 x 256^2); 16-20
         // independent 16-byte loads per lane bring that to 41 us.  (Measured dead end, r02: a two-deep software pipeline over
-        // (block, tap group) items with exact vmcnt waits ran 2.4x SLOWER -- 15k instructions per kernel, past the instruction cache.)
+        // (block, tap group) items with exact vmcnt waits ran 2.4x SLOWER, also as a single-variant kernel: 255 VGPRs leave one wave per
+        // SIMD, and this loop lives on several waves interleaving their address arithmetic.)
         auto run_taps = [&](auto tg_c, auto ks_c) __attribute__((always_inline)) {
             constexpr int TG = decltype(tg_c)::value, KS = decltype(ks_c)::value;
             for (int k0 = 0; k0 < nks; k0 += KS) {
@@ -134,11 +136,15 @@ __device__ __forceinline__ void conv_direct_body(const DirectParams& p, const in
 #pragma unroll
                     for (int u = 0; u < TG; ++u) {
                         const int t = t0 + u;
-                        const int sy = (t / p.KW - p.KH / 2) * p.dil, sx = (t % p.KW - p.KW / 2) * p.dil;
+                        // the window is 1x1 or 3x3 (egm_conv_direct_plan): compile-time divisors, and the tap's address is the pixel's
+                        // own offset (pb, once per block) plus a UNIFORM tap offset -- the per-tap 64-bit multiply chain and the
+                        // run-time divisions were most of this loop's instructions
+                        constexpr int KWc = K1 ? 1 : 3;
+                        const int sy = (t / KWc - KWc / 2) * p.dil, sx = (t % KWc - KWc / 2) * p.dil;
                         const int ys = y + sy, xs = x + sx;
                         rowok[u] = t < ntaps && !(row_blocks && (ys < 0 || ys >= p.H));   // uniform: the whole block's source row is outside
                         const bool ok = t < ntaps && pvalid && ys >= 0 && ys < p.H && xs >= 0 && xs < p.W;
-                        const bf16_t* src = xg + ((long long)(n * p.H + ys) * p.W + xs) * p.ldx + h * 8;
+                        const bf16_t* src = xg + pb + ((long long)sy * p.W + sx) * p.ldx;
 #pragma unroll
                         for (int k = 0; k < KS; ++k) {
                             fb[u][k] = make_uint4(0, 0, 0, 0);
@@ -339,6 +345,8 @@ int egm_conv_direct_plan(int dtype, int N, int H, int W, int Cin, int Cout, int 
     if (smem > 150 * 1024) return 0;
     const int nct = egm_cdiv(Cout, NT * 32);
     // workgroups: enough waves to hide the global-load latency (no LDS staging to overlap with), at most one block per wave
+    // (the dilated instantiation holds 157 VGPRs = three waves per SIMD, so the fourth workgroup per CU of the narrow layers runs as a
+    // second, partial round; capping at three was measured SLOWER, 42.7 vs 38.4 us: shorter work items win)
     const int per_cu = smem > 76 * 1024 ? 1 : (smem > 50 * 1024 ? 2 : (smem > 36 * 1024 ? 3 : 4));
     int g = (256 * per_cu / nct) / 8 * 8;
     if (g < 8) g = 8;
