@@ -345,9 +345,11 @@ int egm_conv_direct_plan(int dtype, int N, int H, int W, int Cin, int Cout, int 
     if (smem > 150 * 1024) return 0;
     const int nct = egm_cdiv(Cout, NT * 32);
     // workgroups: enough waves to hide the global-load latency (no LDS staging to overlap with), at most one block per wave
-    // (the dilated instantiation holds 157 VGPRs = three waves per SIMD, so the fourth workgroup per CU of the narrow layers runs as a
-    // second, partial round; capping at three was measured SLOWER, 42.7 vs 38.4 us: shorter work items win)
-    const int per_cu = smem > 76 * 1024 ? 1 : (smem > 50 * 1024 ? 2 : (smem > 36 * 1024 ? 3 : 4));
+    // Dilated 3x3: two workgroups per CU measured best on every narrow shape (r02, 32 -> 32 @ 8 x 256^2: 48.7 / 33.7 / 42.7 / 38.3 /
+    // 41.4 us for 1 / 2 / 3 / 4 / 6 per CU; 16 -> 16 and the 128^2 maps alike): each workgroup stages the cout tile's weights once, so
+    // fewer, longer-lived workgroups amortise that prologue, and two per CU are all resident at once (157 VGPRs = three waves per SIMD)
+    int per_cu = smem > 76 * 1024 ? 1 : (smem > 50 * 1024 ? 2 : (smem > 36 * 1024 ? 3 : 4));
+    if (KH == 3 && per_cu > 2) per_cu = 2;
     int g = (256 * per_cu / nct) / 8 * 8;
     if (g < 8) g = 8;
     const int max_g = (nblk + 3) / 4;
