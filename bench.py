@@ -2,7 +2,8 @@
 """Headline benchmark: EGM-UNet training throughput (BASELINE.json: "train images/sec at 3x512x512 bs=8/GPU").
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+    (N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, or plainly as
+    `python bench.py --gpus N`, which then starts that launcher itself as a child process)
 
 One step = forward + 5-term criterion + backward + fused SGD of GRFBUNet(3, 2, base_c=32) on a device-resident synthetic
 batch of 8 x 3 x 512 x 512 per GPU, bf16 activation storage / MFMA, fp32 accumulation and master weights.
@@ -414,14 +415,29 @@ def main():
                     help="egm_unet_train = the headline metric (BASELINE.json configs[1]); clipseg_infer = configs[3] (ViT-B/16 image+text "
                          "encode + decoder on 352x352), reported as a secondary line")
     ap.add_argument("--eager", action="store_true", help="issue every kernel from Python instead of replaying the captured hipGraph")
+    ap.add_argument("--dp-single-graph", action="store_true",
+                    help="N > 1: one captured graph (forward + backward) followed by the exchange and the SGD launch, instead of the three-graph "
+                         "step that overlaps bucket 0's all-reduce with the encoder backward (fallback for A/B and triage)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves as a CHILD process (one rank per GPU over
+        # torch.distributed.run), before this process has touched the GPU, pass their output through (rank 0 prints the JSON
+        # line on the inherited stdout) and exit with the launcher's return code.  Never exec: the parent stays a plain waiter.
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env, cwd=ROOT).returncode)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launched by torch.distributed.run with another --nproc-per-node?)")
     if os.environ.get("EGM_BENCH_SINGLE_DEVICE"):          # rehearsal of the N>1 code path on a one-GPU box (with EGM_DIST_BACKEND=gloo)
         local = 0
     torch.cuda.set_device(local)
@@ -473,7 +489,8 @@ def main():
     else:
         from egm_unet_amd.graph import GraphedTrainStep
         try:
-            step = GraphedTrainStep(model, opt, x, t, lw, num_classes=2, ignore_index=255, reducer=reducer, warmup=2)
+            step = GraphedTrainStep(model, opt, x, t, lw, num_classes=2, ignore_index=255, reducer=reducer, warmup=2,
+                                    split=False if args.dp_single_graph else None)
         except Exception as e:                                  # capture problems must not cost the measurement: go eager
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
             torch.cuda.synchronize()
@@ -491,10 +508,12 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     fence()
+    coll0 = reducer.collectives_issued if reducer is not None else 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     t_enqueue = time.perf_counter() - t0                   # host-side cost of issuing the steps (GPU runs behind)
+    coll_per_step = ((reducer.collectives_issued - coll0) / args.steps) if reducer is not None else 0
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -564,6 +583,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "launch": (f"eager (capture failed: {capture_error})" if capture_error else "eager") if args.eager else
                        ("hipGraph replay" if world == 1 or not getattr(step, "split", False) else
                         "3 hipGraph replays per step (fwd + decoder bwd | encoder bwd | SGD), RCCL all-reduce of bucket 0 / 1 between them on a side stream"),
+                       "allreduces_per_step": coll_per_step, "dist_backend": (os.environ.get("EGM_DIST_BACKEND", "nccl") + (" (RCCL)" if os.environ.get("EGM_DIST_BACKEND", "nccl") == "nccl" else "")) if world > 1 else None,
                        "final_loss": round(final_loss, 4)},
             "roofline": roofline, "cpu_baseline": cpu,
         }

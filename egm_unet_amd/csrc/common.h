@@ -16,6 +16,28 @@ void egm_set_error(const char* fmt, ...);
 static inline bool egm_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int egm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// ---------------------------------------------------------------- conv weight operand images
+// Element offset of (tap, co, c) inside a packed weight image with Cout x Cin (padded) entries per tap:
+//     tap*Cout*Cin + co*co_stride + (c >> 4)*ch16_stride + (c & 15)
+//   row-major  [tap][Cout][Cin]        : co_stride = Cin, ch16_stride = 16           (every fp32 image; bf16 unless below)
+//   chunk-major [tap][Cin/16][Cout][16]: co_stride = 16,  ch16_stride = Cout*16      (bf16 3x3 with Cin, Cout multiples of 16)
+// The chunk-major image makes the 16-channel weight slab of a cout tile one contiguous run per tap, which is what the LDS-DMA
+// staging of conv3x3_tile.hip reads (1 KiB per wave-instruction); the condition is symmetric in (Cin, Cout), so a weight's forward
+// image wf and its data-gradient image wd always share a layout, and every kernel that reads them derives it from the call's shape.
+struct WLayout { int co_stride, ch16_stride; };
+__host__ __device__ static inline bool egm_w_chunk16(int dtype, int KH, int KW, int Cin, int Cout) {
+    return dtype == EGM_BF16 && KH == 3 && KW == 3 && (Cin & 15) == 0 && (Cout & 15) == 0;
+}
+__host__ __device__ static inline WLayout egm_w_layout(int dtype, int KH, int KW, int Cin, int Cout) {
+    WLayout l;
+    if (egm_w_chunk16(dtype, KH, KW, Cin, Cout)) { l.co_stride = 16; l.ch16_stride = Cout * 16; }
+    else { l.co_stride = Cin; l.ch16_stride = 16; }
+    return l;
+}
+__host__ __device__ static inline long long egm_w_off(const WLayout& l, int tap, int co, int c, int Cout, int Cin) {
+    return (long long)tap * Cout * Cin + (long long)co * l.co_stride + (long long)(c >> 4) * l.ch16_stride + (c & 15);
+}
+
 // ---------------------------------------------------------------- bf16 storage type
 struct bf16_t { uint16_t v; };
 

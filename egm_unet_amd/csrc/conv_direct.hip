@@ -67,6 +67,7 @@ __device__ __forceinline__ void conv_direct_body(const DirectParams& p, const in
         // eight loads in flight per lane: one at a time, the 18 round trips of a 64 -> 64 dilated conv's 73 KB slab were a flat
         // ~15 us in front of a kernel whose pixel work takes 5
         const int vec_per_row = nks * 2, total = ntaps * NT * 32 * vec_per_row;
+        const WLayout wl = egm_w_layout(EGM_BF16, p.KH, p.KW, p.Cin, p.Cout);     // chunk-major for the dilated 3x3 convs (common.h)
         for (int i0 = tid; i0 < total; i0 += 256 * 8) {
             uint4 v[8];
 #pragma unroll
@@ -75,7 +76,7 @@ __device__ __forceinline__ void conv_direct_body(const DirectParams& p, const in
                 const int row = i / vec_per_row, cv = i - row * vec_per_row;
                 const int t = row / (NT * 32), j = row - t * (NT * 32), co = co0 + j;
                 v[u] = make_uint4(0, 0, 0, 0);
-                if (i < total && co < p.Cout && cv < cvecs) v[u] = *reinterpret_cast<const uint4*>(wg + ((long long)t * p.Cout + co) * p.Cin + cv * 8);
+                if (i < total && co < p.Cout && cv < cvecs) v[u] = *reinterpret_cast<const uint4*>(wg + egm_w_off(wl, t, co, cv * 8, p.Cout, p.Cin));
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {

@@ -39,10 +39,11 @@ int egm_conv_direct_launch(const void* x, int ldx, const PreArgs& pre, const voi
                            float* stats, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int NT, int nct, int G, size_t smem,
                            egm_stream_t s);
 
-// conv_ws.hip: wave-specialised 3x3 kernel for the wide layers
-int egm_conv_ws_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int* nct_out, int* G_out);
-int egm_conv_ws_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, float* stats, int N, int H,
-                       int W, int Cin, int Cout, int nct, int G, egm_stream_t s);
+// conv3x3_tile.hip: 8-wave LDS-DMA 3x3 kernel (the throughput path of the 3x3 stacks)
+int egm_conv_tile_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int* cfg_out, int* nct_out, int* G_out);
+const char* egm_conv_tile_name(int cfg);
+int egm_conv_tile_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, float* stats, int N, int H,
+                         int W, int Cin, int Cout, int cfg, int nct, int G, egm_stream_t s);
 
 namespace {
 
@@ -94,6 +95,7 @@ struct ConvParams {
     int tiles_y, tiles_x, npt, nct;
     int wrows_per_stage;          // kernel rows whose weights are staged together (halo mode)
     int patch_bytes;
+    WLayout wl;                   // weight image layout (common.h)
     PreArgs pre;                  // prologue of the input operand (prologue.h); mode EGM_PRE_NONE = x is used as stored
 };
 
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                     const int co = co0 + j, c = c0 + v * VEC;
                     const int tap = tapbase + wr0 * ww + t;
                     const bool ok = (co < p.Cout) && (c < p.Cin);
-                    const T* src = wg + ((long long)tap * p.Cout + co) * p.Cin + c;
+                    const T* src = wg + egm_w_off(p.wl, tap, co, c, p.Cout, p.Cin);
                     M::stage16(wts + row * PS + v * 16, src, ok);
                 }
                 __syncthreads();
@@ -334,7 +336,7 @@ __device__ __forceinline__ void conv_igemm_pipe_body(const ConvParams& p, const 
     }
     // weight slab row (tid>>2) + 64 k = tap t, cout j with 64 / (NT*32) taps per k step
     constexpr int TAPS_PER_K = 64 / (NT * 32);
-    const int w_rel0 = (((tid >> 2) / (NT * 32)) * p.Cout + ((tid >> 2) % (NT * 32))) * p.Cin + (tid & 3) * 8;
+    const int w_rel0 = (int)egm_w_off(p.wl, (tid >> 2) / (NT * 32), (tid >> 2) % (NT * 32), (tid & 3) * 8, p.Cout, p.Cin);
     const int w_step = TAPS_PER_K * p.Cout * p.Cin;
     const bool w_rows_full = co0 + NT * 32 <= p.Cout;                      // uniform: every weight row of this cout tile exists
     uint4 pre_p[PVEC], pre_w[WVEC];
@@ -421,7 +423,7 @@ __device__ __forceinline__ void conv_igemm_pipe_body(const ConvParams& p, const 
         }
         if (with_weights) {
             if (w_rows_full && full_chunk) {
-                const bf16_t* wbase = wg + ((long long)st.tap0 * p.Cout + co0) * p.Cin + st.c0;
+                const bf16_t* wbase = wg + egm_w_off(p.wl, st.tap0, co0, st.c0, p.Cout, p.Cin);     // c0 is a multiple of 32: offsets add
 #pragma unroll
                 for (int k = 0; k < WVEC; ++k)
                     pre_w[k] = *reinterpret_cast<const uint4*>(wbase + ((!kWtsTail || k < WVEC - 1 || w_tail_ok) ? w_rel0 + k * w_step : 0));
@@ -432,7 +434,7 @@ __device__ __forceinline__ void conv_igemm_pipe_body(const ConvParams& p, const 
                     const int co = co0 + j, c = st.c0 + (i & 3) * 8;
                     const bool ok = i < WROWS * 4 && co < p.Cout && c < p.Cin;
                     pre_w[k] = make_uint4(0, 0, 0, 0);
-                    if (ok) pre_w[k] = *reinterpret_cast<const uint4*>(wg + ((long long)(st.tap0 + t) * p.Cout + co) * p.Cin + c);
+                    if (ok) pre_w[k] = *reinterpret_cast<const uint4*>(wg + egm_w_off(p.wl, st.tap0 + t, co, c, p.Cout, p.Cin));
                 }
             }
         }
@@ -652,10 +654,11 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, T* __restrict__ wf
             const int r = tap / KW, s = tap % KW;
             v = w[(((long long)co * cin_g + (ci % cin_g)) * KH + r) * KW + s];
         }
-        if (wf != nullptr) wf[i] = from_f32<T>(v);
+        const WLayout lf = egm_w_layout(TypeInfo<T>::kDtype, KH, KW, CinP, CoutP), ld = egm_w_layout(TypeInfo<T>::kDtype, KH, KW, CoutP, CinP);
+        if (wf != nullptr) wf[egm_w_off(lf, tap, co, ci, CoutP, CinP)] = from_f32<T>(v);
         if (wd != nullptr) {
             const int ftap = KH * KW - 1 - tap;
-            wd[((long long)ftap * CinP + ci) * CoutP + co] = from_f32<T>(v);
+            wd[egm_w_off(ld, ftap, ci, co, CinP, CoutP)] = from_f32<T>(v);          // the data gradient is a conv with Cin' = Cout, Cout' = Cin
         }
     }
 }
@@ -682,8 +685,9 @@ __global__ __launch_bounds__(256) void conv_pack_multi_kernel(const PackEntry* _
             const int r = tap / e.KW, sx = tap % e.KW;
             v = e.w[(((long long)co * cin_g + (ci % cin_g)) * e.KH + r) * e.KW + sx];
         }
-        wf[i] = from_f32<T>(v);
-        wd[((long long)(e.KH * e.KW - 1 - tap) * e.CinP + ci) * e.CoutP + co] = from_f32<T>(v);
+        const WLayout lf = egm_w_layout(TypeInfo<T>::kDtype, e.KH, e.KW, e.CinP, e.CoutP), ld = egm_w_layout(TypeInfo<T>::kDtype, e.KH, e.KW, e.CoutP, e.CinP);
+        wf[egm_w_off(lf, tap, co, ci, e.CoutP, e.CinP)] = from_f32<T>(v);
+        wd[egm_w_off(ld, e.KH * e.KW - 1 - tap, ci, co, e.CinP, e.CoutP)] = from_f32<T>(v);
     }
 }
 
@@ -802,14 +806,15 @@ int launch_pipe(ConvParams& p, int G, hipStream_t st) {
 }
 
 // One place decides kernel, tile shape and grouping, so the stats-tile count the caller allocates always matches the launch.
-struct ConvPlan { bool pipe, direct, ws; int R, NT, tiles_y, tiles_x, npt, nct, G; size_t smem; };
+struct ConvPlan { bool pipe, direct, tile; int tile_cfg; int R, NT, tiles_y, tiles_x, npt, nct, G; size_t smem; };
 ConvPlan conv_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int pre_mode = EGM_PRE_NONE) {
     ConvPlan c;
     if (KH == 1 && KW == 1) dil = 1;
     // prologues the fast kernels are not built with (the BatchNorm-backward form; anything in front of a 7x7) take the generic kernel
     const bool fast_ok = pre_mode == EGM_PRE_NONE || (pre_mode == EGM_PRE_BN_ACT && KH != 7);
-    c.ws = pre_mode == EGM_PRE_NONE && egm_conv_ws_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.nct, &c.G) != 0;
-    if (c.ws) { c.pipe = c.direct = false; c.R = 2; c.NT = 2; c.tiles_y = c.tiles_x = c.npt = 0; c.smem = 0; return c; }
+    c.tile_cfg = 0;
+    c.tile = pre_mode == EGM_PRE_NONE && egm_conv_tile_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.tile_cfg, &c.nct, &c.G) != 0;
+    if (c.tile) { c.pipe = c.direct = false; c.R = 2; c.NT = 2; c.tiles_y = c.tiles_x = c.npt = 0; c.smem = 0; return c; }
     c.direct = fast_ok && Cin > 0 && egm_conv_direct_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.NT, &c.nct, &c.G, &c.smem) != 0;
     if (c.direct) { c.pipe = false; c.R = 0; c.tiles_y = c.tiles_x = c.npt = 0; return c; }
     c.pipe = fast_ok && pipe_eligible(dtype, KH, KW, dil);
@@ -845,7 +850,7 @@ extern "C" int egm_conv_kernel_name(int dtype, int pre_mode, int N, int H, int W
     const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, pre_mode);
     char tmp[96];
     const int pre = pre_mode == EGM_PRE_NONE ? 0 : 1;
-    if (c.ws) snprintf(tmp, sizeof(tmp), "conv3x3_ws_kernel");
+    if (c.tile) snprintf(tmp, sizeof(tmp), "%s", egm_conv_tile_name(c.tile_cfg));
     else if (c.direct) snprintf(tmp, sizeof(tmp), "conv_direct_kernel<%d, %d, %s>", c.NT, pre, KH == 1 ? "true" : "false");
     else if (c.pipe) snprintf(tmp, sizeof(tmp), "conv_igemm_pipe_kernel<%d, %d, %d, %d, %d>", c.NT, (KH == 3 && dil == 1) ? 3 : 1,
                               (KH == 3 && dil == 1) ? 3 : (KH == 7 ? 7 : 1), c.R, pre);
@@ -911,9 +916,10 @@ extern "C" int egm_conv_fwd_pre(int dtype, const void* x, int ldx, int pre_mode,
     ConvParams p;
     p.x = x; p.w = wf; p.bias = (const float*)bias; p.y = y; p.stats = stats;
     p.ldx = ldx; p.ldy = ldy; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.dil = dil; p.bias_n = bias ? bias_n : 0;
+    p.wl = egm_w_layout(dtype, KH, KW, Cin, Cout);
     p.pre.mode = pre_mode; p.pre.act = pre_act; p.pre.cf = pre_cf; p.pre.aux = pre_aux; p.pre.ld_aux = pre_ld_aux; p.pre.C = Cin;
     const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, pre_mode);
-    if (c.ws) return egm_conv_ws_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, c.nct, c.G, s);
+    if (c.tile) return egm_conv_tile_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, c.tile_cfg, c.nct, c.G, s);
     if (c.direct)
         return egm_conv_direct_launch(x, ldx, p.pre, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, KH, KW, dil, c.NT,
                                       c.nct, c.G, c.smem, s);

@@ -26,6 +26,7 @@ replay, so LR schedulers keep working (a captured graph bakes by-value arguments
 restore_after_warmup=True to get weights, BatchNorm statistics and momentum back to their values from before the warm-up.
 """
 import itertools
+import weakref
 
 import torch
 
@@ -46,8 +47,17 @@ class GraphedTrainStep:
         self.trace = []                               # host-order log of the last call (tests assert the overlap structure on it)
         dev = self.x.device
         # ---- learning rate in device memory; managed here unless the caller already does (train_one_epoch)
-        self._own_lr = optimizer.lr_dev is None
+        lrs = {float(g["lr"]) for g in optimizer.param_groups}
+        if len(lrs) > 1:
+            # the fused SGD launch of every group reads ONE device scalar; groups at different rates would all train at group 0's
+            raise NotImplementedError("GraphedTrainStep: param_groups with different learning rates are not supported "
+                                      "(one device-resident lr scalar per optimizer)")
+        # whoever created optimizer.lr_dev refreshes it: this step when nobody has, or when the step that did is gone (its weakref is
+        # dead) -- otherwise a second step on a long-lived optimizer would replay with a frozen learning rate
+        owner = getattr(optimizer, "_lr_owner", None)
+        self._own_lr = optimizer.lr_dev is None or (owner is not None and owner() is None)
         if self._own_lr:
+            optimizer._lr_owner = weakref.ref(self)
             optimizer.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
             self._lr_pinned = torch.zeros(1, dtype=torch.float32).pin_memory()
             self._lr_event = None
@@ -160,9 +170,13 @@ class GraphedTrainStep:
         if self.split:
             red, cur = self.reducer, torch.cuda.current_stream()
             self.gA.replay(); tr.append("graph A: forward + decoder backward + gather bucket 0")
-            red.exchange_bucket(0, self.side, cur); tr.append("all-reduce bucket 0 enqueued on the side stream")
+            # the trace names a collective only when one was really enqueued (a process group exists); without one the slot is
+            # recorded as a bare stream hand-off so the overlap order stays visible
+            sent = red.exchange_bucket(0, self.side, cur)
+            tr.append("all-reduce bucket 0 enqueued on the side stream" if sent else "bucket 0 handed to the side stream (no process group: no collective)")
             self.gB.replay(); tr.append("graph B: encoder backward + gather bucket 1")
-            red.exchange_bucket(1, self.side, cur); tr.append("all-reduce bucket 1 enqueued on the side stream")
+            sent = red.exchange_bucket(1, self.side, cur)
+            tr.append("all-reduce bucket 1 enqueued on the side stream" if sent else "bucket 1 handed to the side stream (no process group: no collective)")
             red.join(self.side, cur); tr.append("main stream joined the side stream")
             self.gC.replay(); tr.append("graph C: SGD on the reduced buckets")
         else:

@@ -307,7 +307,14 @@ def _flush_wgrads(ready_only=False):
             todo.append(ent)
         elif ready_only:
             later.append(ent)
-        # else: nobody holds the gradient any more (it was discarded): nothing to finish
+        elif weight.grad is not None:
+            # the unfilled buffer is gone but the parameter HAS a gradient: autograd copied or transformed the buffer instead of
+            # adopting it (a tensor hook returning a new tensor, a non-stealable gradient), so weight.grad holds whatever the
+            # uninitialised buffer contained.  _conv_wgrad refuses to defer in the cases it can see; anything else must not train on.
+            raise RuntimeError("deferred conv weight gradient lost its destination: weight.grad exists but is not the buffer "
+                               "backward() returned (tensor hook / gradient copy); set EGM_DEFER_WGRAD=0 for this model")
+        # else: nobody holds the gradient and the parameter has none (torch.autograd.grad() result dropped, or the weight was not
+        # among backward(inputs=...)): it was discarded, nothing to finish
     _pending_wgrad[:] = later
     if not todo:
         return
@@ -338,6 +345,7 @@ def _channel_sum(t):
     return out
 
 
+_DEFER_WGRAD = os.environ.get("EGM_DEFER_WGRAD", "1") != "0"
 # environment switch for A/B runs and for the bit-exactness test of the fused path against the materialised one
 _FUSE_BN = os.environ.get("EGM_FUSE_BN", "0") != "0"
 # BatchNorm backward: 1 = dy computed inside the weight-gradient kernel's staging (by-product for the data gradient),
@@ -469,7 +477,9 @@ def _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, dy_pre, dy_out, weight, dil, gro
     nbytes = L.query("egm_conv_wgrad_workspace", N, H, W, CinP, CoutP, KH, KW)
     ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=x.device)
     # leaf parameter whose only gradient contribution this is: defer the slab reduction to one multi-conv launch
-    defer = _sole_conv_use(weight) and weight.is_leaf and weight.grad is None
+    # (not when a tensor hook may replace the returned buffer, nor under create_graph: both hand autograd something it copies)
+    defer = (_DEFER_WGRAD and _sole_conv_use(weight) and weight.is_leaf and weight.grad is None
+             and not weight._backward_hooks and not torch.is_grad_enabled())
     xm = PRE_BN_ACT if x_coef is not None else PRE_NONE
     if dy_pre is None:
         dm, dact, dcf, daux, dld = PRE_NONE, 0, None, None, 0

@@ -32,6 +32,13 @@ def _hip_gather(entries, device, stream_handle, table):
 class GradAllReducer:
     def __init__(self, model, world_size=None, gather_fn=None, use_side_stream=None, broadcast=True):
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        if self.world > 1 and not dist.is_initialized():
+            raise RuntimeError("GradAllReducer(world_size=%d) needs an initialised torch.distributed process group" % self.world)
+        # The collective is issued whenever a process group exists, ALSO at world size 1: a one-rank all-reduce is a valid RCCL
+        # call and exercises the same stream / event / Work interplay with the graph replays as the N-rank step (the only way
+        # a one-GPU box can run it).  Without a process group (plain single-process training) there is nothing to call.
+        self.collective = dist.is_initialized()
+        self.collectives_issued = 0               # all-reduces enqueued since construction (tests assert on it)
         if broadcast and dist.is_initialized() and dist.get_world_size() > 1:
             # every rank starts from rank 0's parameters and buffers (what DistributedDataParallel does at construction): ranks
             # that initialised differently would otherwise average gradients of different models and drift apart silently
@@ -94,12 +101,18 @@ class GradAllReducer:
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ev)
                 self._gather(entries, b)
-                if self.world > 1:
-                    self._works.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
+                self._all_reduce(b)
         else:
             self._gather(entries, b)
-            if self.world > 1:
-                self._works.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
+            self._all_reduce(b)
+
+    def _all_reduce(self, b):
+        """SUM all-reduce of flat bucket b on the current stream (async Work kept for join()/finish()); returns True if enqueued."""
+        if not self.collective:
+            return False
+        self._works.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
+        self.collectives_issued += 1
+        return True
 
     def _gather(self, entries, b):
         if self.gather_fn is not None:
@@ -116,13 +129,13 @@ class GradAllReducer:
         self._gather([(self.views[p], p.grad) for p in self.buckets[b]], b)
 
     def exchange_bucket(self, b, side, cur):
-        """All-reduce flat bucket b on `side` once everything queued on `cur` so far (the graph that filled it) has finished."""
+        """All-reduce flat bucket b on `side` once everything queued on `cur` so far (the graph that filled it) has finished.
+        Returns True when a collective was actually enqueued (a process group exists)."""
         ev = torch.cuda.Event()
         ev.record(cur)
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            if self.world > 1:
-                self._works.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
+            return self._all_reduce(b)
 
     def join(self, side, cur):
         """Make the reduced buckets visible to `cur`."""

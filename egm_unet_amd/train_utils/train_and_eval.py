@@ -79,6 +79,7 @@ def train_one_epoch(model, optimizer, data_loader, device, epoch, num_classes, l
         else:
             model._egm_train_graph = None
             optimizer.lr_dev = torch.zeros(1, dtype=torch.float32, device=device)
+        optimizer._lr_owner = None          # this loop refreshes the scalar itself (graph.GraphedTrainStep must not take it over)
         loss_pinned = [torch.zeros(1, dtype=torch.float32).pin_memory() for _ in range(2)]
         events = [torch.cuda.Event() for _ in range(2)]
     it = 0

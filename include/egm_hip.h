@@ -60,7 +60,11 @@ int egm_nhwc_to_nchw(int dtype, const void* src, int ld, void* dst_f32, int N, i
 /* ---- convolution (nn.Conv2d stride 1, 'same' padding = dil*(k-1)/2; src/EGM-UNet.py:49,893,964,1210-1218) ---- */
 /* Pack fp32 OIHW weights [Cout][Cin/groups][KH][KW] into the two dense operand layouts the kernels read:
  *   wf [KH*KW][CoutP][CinP]  (forward;  CoutP/CinP = Cout/Cin rounded up to 8, block-diagonal for groups>1)
- *   wd [KH*KW][CinP][CoutP]  (data gradient: taps flipped, in/out swapped).  Either output may be NULL. */
+ *   wd [KH*KW][CinP][CoutP]  (data gradient: taps flipped, in/out swapped).  Either output may be NULL.
+ * bf16 3x3 images whose CoutP and CinP are multiples of 16 are stored chunk-major instead, [tap][CinP/16][CoutP][16] (wd:
+ * [tap][CoutP/16][CinP][16]): same size, the 16-channel weight slab of a cout tile is contiguous per tap, which is what the LDS-DMA
+ * staging of the 3x3 kernel reads.  The layout is a function of (dtype, KH, KW, CinP, CoutP) alone; egm_conv_fwd derives it from its
+ * own arguments, callers never see it. */
 int egm_conv_pack(int dtype, const void* w_oihw_f32, void* wf, void* wd, int Cout, int Cin, int KH, int KW, int groups,
                   egm_stream_t s);
 /* Every conv weight of a model in one launch.  table_dev: device array of 56-byte entries
@@ -77,6 +81,9 @@ int egm_conv_pack_multi(int dtype, const void* table_dev, int n, long long total
 int egm_group_begin(void);
 int egm_group_end(egm_stream_t s);
 int egm_group_abort(void);
+/* 3x3 kernel selection: mode 1 (default; env EGM_CONV_TILE) = the 8-wave LDS-DMA tile kernel wherever it fills the chip, 0 = the
+ * 4-wave register-staged kernel everywhere, -1 = query only.  Returns the previous mode (A/B timing and parity tests). */
+int egm_conv_tile_mode(int mode);
 /* Name of the kernel egm_conv_fwd_pre launches for a shape, spelled like the rows of a rocprofv3 kernel trace (e.g.
  * "conv_igemm_pipe_kernel<2, 3, 3, 2, 0>"); returns its length, copies at most buflen-1 characters into buf (may be NULL). */
 int egm_conv_kernel_name(int dtype, int pre_mode, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen);

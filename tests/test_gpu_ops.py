@@ -79,6 +79,13 @@ CONV_CASES = [
     (3, 250, 500, 40, 24, 3, 1, 1, True),
     (2, 250, 270, 32, 72, 3, 1, 1, True),
     (1, 512, 512, 8, 32, 3, 1, 1, False),
+    # 8-wave LDS-DMA tile kernel (conv3x3_tile.hip), one case per tile shape; forward runs it, backward runs it with Cin/Cout swapped
+    (2, 250, 250, 64, 128, 3, 1, 1, True),   # 16 rows x 128 couts (A), ragged right/bottom tiles, 4 chunks; dgrad: 32 rows x 64 couts
+    (8, 64, 64, 32, 256, 3, 1, 1, False),    # 8 rows x 128 couts (B), two cout tiles per pixel group; dgrad: 16 rows x 32 couts
+    (8, 128, 128, 32, 64, 3, 1, 1, True),    # 16 rows x 64 couts (E); dgrad: 16 rows x 32 couts (G)
+    (2, 512, 512, 16, 32, 3, 1, 1, True),    # 32 rows x 32 couts (F), one chunk
+    (3, 500, 260, 32, 64, 3, 1, 1, False),   # 32 rows x 64 couts (D), 432 tiles on 256 workgroups (two tiles for some), ragged
+    (8, 128, 128, 48, 96, 3, 1, 1, False),   # Cout = 3 x 32: 16 rows x 32 couts with three cout tiles per group, 3 chunks
     # LDS-free activation path (conv_direct.hip): wide-in / narrow-out 1x1, ragged and 32-aligned rows; dilated on aligned rows
     (2, 40, 44, 112, 16, 1, 1, 1, True),
     (2, 64, 64, 64, 10, 1, 1, 1, True),

@@ -32,8 +32,8 @@ def _worker(rank, world, port, q, graphed=False):
     x = torch.randn(2, 3, 32, 32, generator=g).cuda()
     t = torch.randint(0, 2, (2, 32, 32), generator=g).cuda()
     lw = torch.tensor([1.0, 2.0], device="cuda")
+    from egm_unet_amd.graph import GraphedTrainStep
     if graphed:
-        from egm_unet_amd.graph import GraphedTrainStep
         step = GraphedTrainStep(m, opt, x, t, lw, num_classes=2, ignore_index=255, reducer=red, warmup=1)
         for _ in range(2):
             step()
@@ -46,31 +46,40 @@ def _worker(rank, world, port, q, graphed=False):
             opt.step()
     torch.cuda.synchronize()
     probe = {k: v.detach().float().cpu().numpy().tolist() for k, v in m.state_dict().items() if k in ("in_conv.0.weight", "out_conv.0.bias")}
-    # the averaged gradient of rank-local batches must be identical on both ranks after the all-reduce
-    if not graphed:
-        # ... and it must BE the mean: one step from the same initial weights with both ranks' batches evaluated in this process,
-        # gradients summed and scaled by 1/world, gives the weights of one distributed step (bitwise: a + b is commutative)
-        torch.manual_seed(0)
-        ref, dist_m = UNet(3, 2, base_c=8).to("cuda").train(), UNet(3, 2, base_c=8).to("cuda").train()
-        dist_m.load_state_dict(ref.state_dict())
-        red2 = GradAllReducer(dist_m, world_size=world, broadcast=False)
-        opt_d = SGD(dist_m.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4); opt_d.grad_scale = 1.0 / world
+    # the averaged gradient of rank-local batches must be identical on both ranks after the all-reduce ...
+    # ... and it must BE the mean: one step from the same initial weights with both ranks' batches evaluated in this process,
+    # gradients summed and scaled by 1/world, gives the weights of one distributed step (bitwise: a + b is commutative).  In the
+    # graphed variant the distributed step is one replay of the three-graph step (warm-up undone by restore_after_warmup).
+    torch.manual_seed(0)
+    ref, dist_m = UNet(3, 2, base_c=8).to("cuda").train(), UNet(3, 2, base_c=8).to("cuda").train()
+    dist_m.load_state_dict(ref.state_dict())
+    red2 = GradAllReducer(dist_m, world_size=world, broadcast=False)
+    opt_d = SGD(dist_m.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4); opt_d.grad_scale = 1.0 / world
+    if graphed:
+        step2 = GraphedTrainStep(dist_m, opt_d, x, t, lw, num_classes=2, ignore_index=255, reducer=red2, warmup=1, restore_after_warmup=True)
+        assert step2.split, "world 2 must take the three-graph step"
+        n0 = red2.collectives_issued
+        step2()
+        assert red2.collectives_issued - n0 == 2, "one all-reduce per bucket per step"
+        assert [s for s in step2.trace if s.startswith("all-reduce")] == ["all-reduce bucket 0 enqueued on the side stream",
+                                                                          "all-reduce bucket 1 enqueued on the side stream"], step2.trace
+    else:
         criterion(dist_m(x), t, lw, num_classes=2, ignore_index=255).backward()
         opt_d.grad_source = red2.finish(); opt_d.step()
-        sums = None
-        for r in range(world):
-            gr = torch.Generator().manual_seed(50 + r)
-            xr, tr = torch.randn(2, 3, 32, 32, generator=gr).cuda(), torch.randint(0, 2, (2, 32, 32), generator=gr).cuda()
-            probe_m = UNet(3, 2, base_c=8).to("cuda").train()
-            probe_m.load_state_dict(ref.state_dict())
-            criterion(probe_m(xr), tr, lw, num_classes=2, ignore_index=255).backward()
-            gs = [p.grad.clone() for p in probe_m.parameters()]
-            sums = gs if sums is None else [a + b for a, b in zip(sums, gs)]
-        opt_r = SGD(ref.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4); opt_r.grad_scale = 1.0 / world
-        opt_r.grad_source = dict(zip(ref.parameters(), sums)); opt_r.step()
-        torch.cuda.synchronize()
-        mism = [n for (n, a), b in zip(ref.named_parameters(), dist_m.parameters()) if not torch.equal(a, b)]
-        probe["mean_mismatch"] = mism[:4]
+    sums = None
+    for r in range(world):
+        gr = torch.Generator().manual_seed(50 + r)
+        xr, tr = torch.randn(2, 3, 32, 32, generator=gr).cuda(), torch.randint(0, 2, (2, 32, 32), generator=gr).cuda()
+        probe_m = UNet(3, 2, base_c=8).to("cuda").train()
+        probe_m.load_state_dict(ref.state_dict())
+        criterion(probe_m(xr), tr, lw, num_classes=2, ignore_index=255).backward()
+        gs = [p.grad.clone() for p in probe_m.parameters()]
+        sums = gs if sums is None else [a + b for a, b in zip(sums, gs)]
+    opt_r = SGD(ref.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4); opt_r.grad_scale = 1.0 / world
+    opt_r.grad_source = dict(zip(ref.parameters(), sums)); opt_r.step()
+    torch.cuda.synchronize()
+    mism = [n for (n, a), b in zip(ref.named_parameters(), dist_m.parameters()) if not torch.equal(a, b)]
+    probe["mean_mismatch"] = mism[:4]
     q.put((rank, probe))
     dist.barrier()
     dist.destroy_process_group()
@@ -174,8 +183,10 @@ def test_reducer_paths_match_plain_training_bitwise():
                 # the overlap structure of the data-parallel step: bucket 0's collective is enqueued (side stream) BEFORE the
                 # encoder-backward graph is launched, SGD runs as its own graph after the join
                 order = [s.split(":")[0] for s in step.trace]
-                assert order == ["graph A", "all-reduce bucket 0 enqueued on the side stream", "graph B",
-                                 "all-reduce bucket 1 enqueued on the side stream", "main stream joined the side stream", "graph C"], step.trace
+                # (no process group in this test: the two hand-offs to the side stream carry no collective and the trace says so)
+                assert order == ["graph A", "bucket 0 handed to the side stream (no process group", "graph B",
+                                 "bucket 1 handed to the side stream (no process group", "main stream joined the side stream", "graph C"], step.trace
+                assert red.collectives_issued == 0
         else:
             for _ in range(2):
                 loss = criterion(m(x), t, lw, num_classes=2, ignore_index=255)
@@ -208,3 +219,44 @@ def test_three_graph_step_over_rccl_single_rank():
                        timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all-reduce bucket 0 enqueued on the side stream" in r.stdout and "tensors that differ: 0" in r.stdout
+    assert "rccl all-reduces issued in 3 steps: 6" in r.stdout, r.stdout[-2000:]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher on the command line (how a driver may start it): bench.py spawns
+    torch.distributed.run itself before touching the GPU and relays rank 0's JSON line."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(EGM_BENCH_SINGLE_DEVICE="1", EGM_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "128",
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 16 and line["value"] > 0
+    assert line["config"]["allreduces_per_step"] == 2, line["config"]
+
+
+def test_weight_with_tensor_hook_is_not_deferred():
+    """A tensor hook on a conv weight makes autograd replace the gradient buffer backward() returned: the deferred slab reduction
+    must not be used for it (the hooked gradient would be computed from an unfilled buffer)."""
+    sys.path.insert(0, ROOT)
+    from egm_unet_amd import UNet
+    from egm_unet_amd.train_utils import criterion
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 32, 32, generator=g).cuda()
+    t = torch.randint(0, 2, (2, 32, 32), generator=g).cuda()
+    lw = torch.tensor([1.0, 2.0], device="cuda")
+    torch.manual_seed(0)
+    a = UNet(3, 2, base_c=8).to("cuda").train()
+    torch.manual_seed(0)
+    b = UNet(3, 2, base_c=8).to("cuda").train()
+    hooks = [p.register_hook(lambda gr: gr * 1) for p in b.parameters() if p.dim() == 4]
+    assert hooks
+    junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(16)]
+    del junk
+    criterion(a(x), t, lw, num_classes=2, ignore_index=255).backward()
+    criterion(b(x), t, lw, num_classes=2, ignore_index=255).backward()
+    torch.cuda.synchronize()
+    bad = [n for (n, p), q in zip(a.named_parameters(), b.parameters()) if not torch.equal(p.grad, q.grad)]
+    assert not bad, bad[:6]

@@ -23,9 +23,15 @@ for split in (True, False):
     red = GradAllReducer(m, world_size=1) if split else None
     step = GraphedTrainStep(m, opt, x, t, lw, num_classes=2, ignore_index=255, reducer=red, warmup=1, restore_after_warmup=True,
                             **({"split": True} if split else {}))
+    n0 = red.collectives_issued if red is not None else 0
     for _ in range(3):
         loss = step()
     torch.cuda.synchronize()
+    if red is not None:
+        # a process group exists, so every bucket exchange is a real dist.all_reduce on the nccl (= RCCL) backend: 2 per step
+        assert red.collective and dist.get_backend() == "nccl"
+        print("rccl all-reduces issued in 3 steps:", red.collectives_issued - n0)
+        assert red.collectives_issued - n0 == 6, red.collectives_issued - n0
     res.append((float(loss), {k: v.clone() for k, v in m.state_dict().items()}, getattr(step, "trace", None)))
 print("loss split / plain:", res[0][0], res[1][0])
 bad = [k for k in res[0][1] if not torch.equal(res[0][1][k], res[1][1][k])]
