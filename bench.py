@@ -301,7 +301,8 @@ def ablation_bench(args, dev, rank, world):
             fn()
         work.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=work):
+        import torch.distributed as _d
+        with torch.cuda.graph(graph, stream=work, capture_error_mode="thread_local" if _d.is_initialized() else "global"):   # RCCL watchdog thread, see graph.py
             fn()
         graph.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -522,7 +523,7 @@ def main():
         elapsed = float(tt.item())
     final_loss = float(loss.detach())
 
-    roofline = None
+    roofline = roofline_wgrad = None
     cpu = None
     # instrumented eager step outside the timed region.  EVERY rank runs it (its gradient exchange must match on all ranks);
     # rank 0 reports.  After a captured graph the reducer's autograd hooks are off: switch them back on for this eager step.
@@ -541,28 +542,36 @@ def main():
         total_ms = sum(v[1] for v in agg.values())
         dom_key, dom = max(((k, v) for k, v in agg.items() if v[2] > 0), key=lambda kv: kv[1][1])
         achieved = dom[2] / (dom[1] * 1e-3) / 1e12
-        traffic = None          # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this
-        traffic_source = None   # command; FETCH_SIZE doubled per the gfx950 note of the guide): a CHECKED-IN measurement, not this run's
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (9, 8, 7, 6, 5, 4, 3, 2, 1)) if os.path.exists(q)), "")
-        if os.path.exists(tpath) and args.dtype == "bf16":
-            traffic_source = (os.path.relpath(tpath, ROOT) + ": rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this command, recorded "
-                              "earlier and checked in (FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); not collected by this run")
-            cat = ("conv_fwd[3x3]" if "pipe_kernel<" in dom_key and ", 3, 3, " in dom_key else
-                   "conv_fwd[1x1]" if "pipe_kernel<" in dom_key and ", 1, 1, " in dom_key else
-                   "conv_wgrad[3x3]" if "wgrad" in dom_key and "<9" in dom_key else None)
-            for k, v in json.load(open(tpath)).items():
-                if cat is not None and k.startswith(cat):
-                    traffic = v["hbm_bytes_per_launch_corrected"]
-        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3,
-                    "unit": "TFLOP/s", "frac": round(achieved / (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3), 4),
-                    "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None, "kernel": dom_key, "algorithmic_bytes_per_launch": round(dom[3] / dom[0]), "launches_per_step": dom[0],
-                    "avg_launch_ms": round(dom[1] / dom[0], 4), "algorithmic_gflop_per_launch": round(dom[2] / dom[0] / 1e9, 3),
-                    "share_of_step_kernel_time": round(dom[1] / total_ms, 3),
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command; FETCH_SIZE
+        # doubled per the gfx950 note of the guide): a CHECKED-IN measurement keyed by kernel instantiation (tools/pmc_traffic.py), so the
+        # figure beside a kernel is that kernel's own traffic, like-for-like with its algorithmic bytes
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (9, 8, 7, 6, 5, 4, 3)) if os.path.exists(q)), "")
+        tjson = json.load(open(tpath)) if (tpath and args.dtype == "bf16") else {}
+        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
+
+        def roofline_of(key, row):
+            n_, ms_, flop_, byts_, roof_ms_ = row
+            ach = flop_ / (ms_ * 1e-3) / 1e12
+            tr = tjson.get(key, {}).get("hbm_bytes_per_launch_corrected")
+            return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": tr,
+                    "traffic_over_algorithmic": round(tr / (byts_ / n_), 3) if tr else None,
+                    "traffic_source": (os.path.relpath(tpath, ROOT) + ": rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this command, per kernel "
+                                       "instantiation, recorded earlier and checked in (FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); not "
+                                       "collected by this run") if tr else None,
+                    "kernel": key, "algorithmic_bytes_per_launch": round(byts_ / n_), "launches_per_step": n_,
+                    "avg_launch_ms": round(ms_ / n_, 4), "algorithmic_gflop_per_launch": round(flop_ / n_ / 1e9, 3),
+                    "share_of_step_kernel_time": round(ms_ / total_ms, 3),
                     # sum over the launches of min(MFMA, HBM)-roofline time / measured time: the high-resolution layers of this
                     # U-Net are HBM-bound (AI 144-192 FLOP/B < ridge ~310), so "frac" vs the MFMA peak understates them
-                    "frac_of_per_layer_roofline": round(dom[4] / dom[1], 4) if args.dtype == "bf16" else None,
-                    # the layers the north_star target is quoted on, each against its own roofline
-                    "encoder_3x3": kt.encoder_table() if args.dtype == "bf16" and args.batch == 8 and args.size == 512 else None}
+                    "frac_of_per_layer_roofline": round(roof_ms_ / ms_, 4) if args.dtype == "bf16" else None}
+
+        roofline = roofline_of(dom_key, dom)
+        # the layers the north_star target is quoted on, each against its own roofline
+        roofline["encoder_3x3"] = kt.encoder_table() if args.dtype == "bf16" and args.batch == 8 and args.size == 512 else None
+        # second object: the heaviest weight-gradient kernel
+        wg = [(k, v) for k, v in agg.items() if v[2] > 0 and "wgrad" in k]
+        roofline_wgrad = roofline_of(*max(wg, key=lambda kv: kv[1][1])) if wg else None
         top = sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]
         print(f"[bench] host enqueue {1e3 * t_enqueue / args.steps:.2f} ms/step vs wall {1e3 * elapsed / args.steps:.2f} ms/step", file=sys.stderr)
         print("[bench] kernel time by C-ABI entry (instrumented step, ms): " +
@@ -585,7 +594,7 @@ def main():
                         "3 hipGraph replays per step (fwd + decoder bwd | encoder bwd | SGD), RCCL all-reduce of bucket 0 / 1 between them on a side stream"),
                        "allreduces_per_step": coll_per_step, "dist_backend": (os.environ.get("EGM_DIST_BACKEND", "nccl") + (" (RCCL)" if os.environ.get("EGM_DIST_BACKEND", "nccl") == "nccl" else "")) if world > 1 else None,
                        "final_loss": round(final_loss, 4)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_wgrad": roofline_wgrad, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:

@@ -12,7 +12,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "egm_hip.h")
-LIB_PATH = os.path.join(_HERE, "lib", "libegm_hip.so")
+# EGM_LIB_TAG selects a diagnostic build made with `EGM_BUILD_TAG=<tag> python -m egm_unet_amd.build` (lib/libegm_hip_<tag>.so)
+LIB_PATH = os.path.join(_HERE, "lib", "libegm_hip%s.so" % ("_" + os.environ["EGM_LIB_TAG"] if os.environ.get("EGM_LIB_TAG") else ""))
 
 EGM_F32, EGM_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU = 0, 1, 2, 3

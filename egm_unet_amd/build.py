@@ -11,7 +11,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libegm_hip.so")
+TAG = os.environ.get("EGM_BUILD_TAG", "")          # diagnostic builds (with EGM_HIPCC_EXTRA) live beside the product library
+LIB = os.path.join(LIBDIR, "libegm_hip%s.so" % ("_" + TAG if TAG else ""))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("EGM_HIPCC_EXTRA", "").split()        # e.g. -DEGM_CONV_TIMING for tools/diag_conv_phases.py
@@ -30,11 +31,11 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" + ("_" + TAG if TAG else ""))
     os.makedirs(objdir, exist_ok=True)
     # objects and the library are only reusable under the flags they were built with (a library left over from a diagnostic
     # build, e.g. -DEGM_CONV_TIMING, must never be picked up by a normal one): the flag set is stamped next to the objects
-    stamp_path = os.path.join(LIBDIR, "flags.stamp")          # next to the library, so it travels with it
+    stamp_path = os.path.join(LIBDIR, "flags%s.stamp" % ("_" + TAG if TAG else ""))          # next to the library, so it travels with it
     stamp = " ".join([HIPCC] + FLAGS)
     if not os.path.exists(stamp_path) or open(stamp_path).read() != stamp:
         force = True

@@ -35,6 +35,13 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 __device__ uint4 egm_zero_page[4];          // zero-initialised: the source of every DMA lane that must deliver zeros
 
+#ifndef EGM_TILE_ORDER
+#define EGM_TILE_ORDER 0          // 0 = kernel-column-major fragment order (product), 1 = tap-major software pipeline (measured slower)
+#endif
+#ifndef EGM_TILE_DMA_EVERY
+#define EGM_TILE_DMA_EVERY 1      // one LDS-DMA instruction after every n-th fragment group of the MFMA phase
+#endif
+
 namespace {
 
 constexpr int TW = 32, PW = TW + 2, KC = 16;
@@ -43,6 +50,7 @@ struct TileParams {
     const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y; float* stats;
     int ldx, ldy, N, H, W, Cin, Cout, bias_n;
     int tiles_y, tiles_x, npt, nct, G;
+    int dbg;        // ablation switches for tools/conv_tile_diag.py (0 in production): 1 = no DMA, 2 = no MFMA phase, 4 = no epilogue, 8 = no static priority
 };
 
 template <int R, int NT, int WR, int WC, int NBUF> struct TileGeom {
@@ -60,12 +68,22 @@ template <int R, int NT, int WR, int WC, int NBUF> struct TileGeom {
     static_assert(9 * NC * 32 + 64 * 32 < 65536, "ds_read immediate offsets");
 };
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two fp32 -> one dword of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32 (the scalar casts were paired crosswise by the
+// vectoriser and re-shuffled with and / shift / or: 6 instructions per 4 values instead of 2)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    f32x2_t v; v.x = lo; v.y = hi;
+    const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+    return *reinterpret_cast<const uint32_t*>(&b);
+}
+
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr) {
     // LDS-DMA from inline asm: through the builtin the compiler orders it against every ds_read (vmcnt(0) in front of the first
     // fragment read).  M0 = wave-uniform LDS base; lane l lands at base + 16 l.  Ordering is ours: counted vmcnt + s_barrier.
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr));
 }
 
 template <int R, int NT, int WR, int WC, int NBUF>
@@ -90,6 +108,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
 
     // ---- per-lane DMA sources, fixed for the whole kernel.  Instruction k of this wave is stage instruction j = wv + 8k:
     //      j < NPI: patch slots 64j + lane; j < NPI + NWI: weight slots; else padding (zero page, never read back).
+    //      (Recomputing them per instruction from (j, lane) instead of holding 2*KT registers was measured 3-10 % slower on every
+    //      128-cout layer: a dozen more VALU instructions per DMA compete with the partner wave's MFMA issue.)
     int rel[KT];            // element offset from the tile's halo origin (patch) / from the chunk's weight slab (weights)
     int pk[KT];             // patch: prow | col << 8 | slot valid << 16
 #pragma unroll
@@ -116,27 +136,55 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
         t.n = t.pt / tpi; const int trem = t.pt - t.n * tpi;
         t.oy0 = (trem / p.tiles_x) * Gm::TROWS; t.ox0 = (trem % p.tiles_x) * TW;
     };
-    auto issue = [&](const Tile& t, int ch, int bufi) __attribute__((always_inline)) {
-        // halo origin (may lie outside the tensor on edge tiles: only dereferenced by lanes whose pixel is inside the image)
-        const bf16_t* xb = p.x + ((long long)(t.n * p.H + t.oy0 - 1) * p.W + (t.ox0 - 1)) * p.ldx + ch * KC;
-        const bf16_t* wb = p.w + (long long)ch * p.Cout * 16;
-        const unsigned base = smem_lds + bufi * STAGE + wv * 1024;
-#pragma unroll
-        for (int k = 0; k < KT; ++k) {
-            const int j = wv + 8 * k;
-            const void* src;
-            if (j < NPI) {
-                const int iy = t.oy0 - 1 + (pk[k] & 0xff), ix = t.ox0 - 1 + ((pk[k] >> 8) & 0xff);
-                const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && (pk[k] >> 16) != 0;
-                src = ok ? reinterpret_cast<const void*>(xb + rel[k]) : zp;
-            } else if (j < NPI + NWI) {
-                src = reinterpret_cast<const void*>(wb + rel[k]);
-            } else {
-                src = zp;
-            }
-            glds16(src, base + k * 8192);
-        }
+    // One DMA instruction of a stage: k-th of this wave.  `xb` = halo origin of the tile at the chunk (may lie outside the tensor on
+    // edge tiles: only dereferenced by lanes whose pixel is inside the image), `wb` = weight slab of the chunk.
+    struct Src { const bf16_t* xb; const bf16_t* wb; int oy0, ox0; unsigned lds; };
+    auto make_src = [&](const Tile& t, int ch, int bufi) {
+        Src q;
+        q.xb = p.x + ((long long)(t.n * p.H + t.oy0 - 1) * p.W + (t.ox0 - 1)) * p.ldx + ch * KC;
+        q.wb = p.w + (long long)ch * p.Cout * 16;
+        q.oy0 = t.oy0; q.ox0 = t.ox0;
+        q.lds = smem_lds + bufi * STAGE + wv * 1024;
+        return q;
     };
+    auto dma = [&](const Src& q, int k) __attribute__((always_inline)) {
+        const int j = wv + 8 * k;
+        const void* src;
+        if (j < NPI) {
+            const int iy = q.oy0 - 1 + (pk[k] & 0xff), ix = q.ox0 - 1 + ((pk[k] >> 8) & 0xff);
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && (pk[k] >> 16) != 0;
+            src = ok ? reinterpret_cast<const void*>(q.xb + rel[k]) : zp;
+        } else if (j < NPI + NWI) {
+            src = reinterpret_cast<const void*>(q.wb + rel[k]);
+        } else {
+            src = zp;
+        }
+        glds16(src, q.lds + k * 8192);
+    };
+
+    // ---- stage iterator state, first stage(s) on their way before anything else is set up
+    const int ntl = (p.npt - grp + p.G - 1) / p.G;                   // tiles of this workgroup (>= 1)
+    const int S = ntl * nch;
+    Tile it; it.pt = grp; decode(it);
+    int it_ch = 0;
+    Tile cu = it, done = it;
+    auto advance_issue = [&]() {
+        if (++it_ch == nch) { it_ch = 0; it.pt += p.G; if (it.pt < p.npt) decode(it); }
+    };
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i) {
+        if (i < S) {
+            if (!(p.dbg & 1)) {
+                const Src q = make_src(it, it_ch, i);
+#pragma unroll
+                for (int k = 0; k < KT; ++k) dma(q, k);
+            }
+            advance_issue();
+        }
+    }
+    // the second-dispatched half of the workgroup loses issue arbitration to its SIMD partners on every phase (MI355X_MICROARCH.md,
+    // "Two waves per SIMD" item 4): one static priority raise, no per-phase flips
+    if (wv >= 4 && !(p.dbg & 8)) __builtin_amdgcn_s_setprio(1);
 
     // ---- fragment read addresses (bytes inside a stage buffer)
     int pb[3];
@@ -148,16 +196,46 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
     const int wbo = WOFF + ((wc * NT * 32 + r31) * 2 + (h ^ ((r31 >> 3) & 1))) * 16;
 
     f32x16_t acc[R][NT];
-    float ssum[8], ssq[8], bias8[8];
+    float ssum[8], ssq[8];
     zero8(ssum); zero8(ssq);
-    {
-        const int cv = lane % NV;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const int co = co0 + wc * NT * 32 + cv * 8 + j; bias8[j] = (p.bias != nullptr && co < p.bias_n) ? p.bias[co] : 0.f; }
-    }
 
-    auto compute = [&](int bufi) __attribute__((always_inline)) {
+    // MFMA phase of one stage.  Kernel-column-major: the 3*NT weight fragments of kernel column s stay in registers while the R+2
+    // patch-row fragments (shift s) stream past, each feeding every (output row, kernel row) pair that uses it: (3NT + R+2) reads for
+    // 3*R*NT MFMAs (0.5 per MFMA at R = 4, NT = 2).  A tap-major software pipeline (reads of tap g+1 issued before the MFMAs of tap g,
+    // 0.75 reads per MFMA) was built and measured SLOWER (MFMA phase 5157 -> 5496 clk per stage on 128->128 @ 128^2): with two waves
+    // per SIMD the partner covers an exposed read, whereas every extra ds_read_b128 competes with the LDS-DMA writes for the LDS.
+    // The KT DMA instructions of stage t+NBUF-1 are issued one per fragment group instead of as a burst behind the barrier:
+    // measured, the burst was 22-28 % of a wave's time (56 KB through the CU's 64 B/clk memory pipeline, every wave at once, no MFMA
+    // meanwhile).
+    auto compute = [&](int bufi, bool with_dma, const Src& q) __attribute__((always_inline)) {
         const unsigned char* sb = smem + bufi * STAGE;
+#if EGM_TILE_ORDER == 1
+        constexpr int PD = (R >= 4) ? 1 : 2;
+        bf16x8_t fa[PD + 1][NT], fb[PD + 1][R];
+        auto load_group = [&](int g, int slot) __attribute__((always_inline)) {
+            const int s_ = g / 3, r_ = g % 3;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                fa[slot][nt] = *reinterpret_cast<const bf16x8_t*>(sb + wbo + ((r_ * 3 + s_) * NC + nt * 32) * 32);
+#pragma unroll
+            for (int m = 0; m < R; ++m)
+                fb[slot][m] = *reinterpret_cast<const bf16x8_t*>(sb + pb[s_] + (m + r_) * (PW * 32));
+        };
+#pragma unroll
+        for (int g = 0; g < PD; ++g) load_group(g, g % (PD + 1));
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+            if (g + PD < 9) load_group(g + PD, (g + PD) % (PD + 1));
+            if (g < KT) {
+                if (with_dma) dma(q, g);
+            }
+#pragma unroll
+            for (int m = 0; m < R; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g % (PD + 1)][nt], fb[g % (PD + 1)][m], acc[m][nt], 0, 0, 0);
+        }
+#else
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             bf16x8_t fa[3][NT];                                       // one kernel column of weights, held across the patch rows
@@ -177,9 +255,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
                         for (int nt = 0; nt < NT; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[r][nt], fb, acc[m][nt], 0, 0, 0);
                     }
                 }
+                const int gi = s * (R + 2) + rho;
+                if (gi % EGM_TILE_DMA_EVERY == 0 && gi / EGM_TILE_DMA_EVERY < KT) {
+                    if (with_dma) dma(q, gi / EGM_TILE_DMA_EVERY);
+                }
             }
         }
+#endif
     };
+    static_assert(9 >= KT && (3 * (R + 2) + EGM_TILE_DMA_EVERY - 1) / EGM_TILE_DMA_EVERY >= KT, "not enough fragment groups to carry the stage's DMA instructions");
 
     unsigned char* ot = smem + NBUF * STAGE + wv * 32 * OROW;       // wave-private out tile: 32 pixels x NT*32 couts
     auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
@@ -192,56 +276,81 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     uint2 v;
-                    v.x = (uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 0]) | ((uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 1]) << 16);
-                    v.y = (uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 2]) | ((uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 3]) << 16);
+                    v.x = pack_bf16x2(acc[m][nt][gq * 4 + 0], acc[m][nt][gq * 4 + 1]);
+                    v.y = pack_bf16x2(acc[m][nt][gq * 4 + 2], acc[m][nt][gq * 4 + 3]);
                     *reinterpret_cast<uint2*>(ot + r31 * OROW + (nt * 32 + gq * 8 + h * 4) * 2) = v;
                 }
             // read back whole channel vectors (same wave: its LDS operations complete in order) and store coalesced
-            const int oy = t.oy0 + R * wr + m;
+            const int oy = t.oy0 + R * wr + m;                        // wave-uniform
+            uint4 raw[NV / 2];
 #pragma unroll
-            for (int it = 0; it < NV / 2; ++it) {                     // 32 pixels / (64 / NV pixel slots)
-                const int pl = it * (64 / NV) + slot;
-                const int ox = t.ox0 + pl;
-                const int co = co0 + wc * NT * 32 + cv * 8;
-                float v[8];
-                load8(reinterpret_cast<const bf16_t*>(ot + pl * OROW + cv * 16), v);
-                if (oy < p.H && ox < p.W) {
-                    if (p.bias != nullptr) {
+            for (int it2 = 0; it2 < NV / 2; ++it2)                    // 32 pixels / (64 / NV pixel slots)
+                raw[it2] = *reinterpret_cast<const uint4*>(ot + (it2 * (64 / NV) + slot) * OROW + cv * 16);
+            if (oy < p.H) {
+                bf16_t* yrow = p.y + ((long long)(t.n * p.H + oy) * p.W + t.ox0) * p.ldy + co0 + wc * NT * 32 + cv * 8;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<bf16_t>(v[j] + bias8[j]));
+                for (int it2 = 0; it2 < NV / 2; ++it2) {
+                    const int pl = it2 * (64 / NV) + slot;
+                    const bool ok = t.ox0 + pl < p.W;
+                    uint4 rw = raw[it2];
+                    if (p.bias != nullptr) {                          // rare (convs in front of a BatchNorm carry no bias): rounds twice
+                        float b[8], bias8[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { const int co = co0 + wc * NT * 32 + cv * 8 + j; bias8[j] = co < p.bias_n ? p.bias[co] : 0.f; }
+                        b[0] = __uint_as_float(rw.x << 16); b[1] = __uint_as_float(rw.x & 0xffff0000u);
+                        b[2] = __uint_as_float(rw.y << 16); b[3] = __uint_as_float(rw.y & 0xffff0000u);
+                        b[4] = __uint_as_float(rw.z << 16); b[5] = __uint_as_float(rw.z & 0xffff0000u);
+                        b[6] = __uint_as_float(rw.w << 16); b[7] = __uint_as_float(rw.w & 0xffff0000u);
+                        rw.x = pack_bf16x2(b[0] + bias8[0], b[1] + bias8[1]); rw.y = pack_bf16x2(b[2] + bias8[2], b[3] + bias8[3]);
+                        rw.z = pack_bf16x2(b[4] + bias8[4], b[5] + bias8[5]); rw.w = pack_bf16x2(b[6] + bias8[6], b[7] + bias8[7]);
                     }
-                    store8(p.y + ((long long)(t.n * p.H + oy) * p.W + ox) * p.ldy + co, v);
+                    if (!ok) rw = make_uint4(0, 0, 0, 0);             // pixels right of the image: no store, nothing in the statistics
+                    if (ok) *reinterpret_cast<uint4*>(yrow + (long long)pl * p.ldy) = rw;
+                    float v[8];
+                    v[0] = __uint_as_float(rw.x << 16); v[1] = __uint_as_float(rw.x & 0xffff0000u);
+                    v[2] = __uint_as_float(rw.y << 16); v[3] = __uint_as_float(rw.y & 0xffff0000u);
+                    v[4] = __uint_as_float(rw.z << 16); v[5] = __uint_as_float(rw.z & 0xffff0000u);
+                    v[6] = __uint_as_float(rw.w << 16); v[7] = __uint_as_float(rw.w & 0xffff0000u);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
+                    for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] = fmaf(v[j], v[j], ssq[j]); }
                 }
             }
         }
     };
 
+#ifdef EGM_TILE_TIMING
+    // diagnostic build (tools/conv_tile_diag.py): shader-clock totals per phase of every wave's loop, written over the statistics rows
+    long long tph[6] = {0, 0, 0, 0, 0, 0};
+    __builtin_amdgcn_sched_barrier(0);
+    long long tmark = __builtin_amdgcn_s_memtime();
+    const long long treal0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_sched_barrier(0);
+#define EGM_TICK(i) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_amdgcn_s_memtime(); \
+                         __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); tph[i] += t_ - tmark; tmark = t_; } while (0)
+#else
+#define EGM_TICK(i) do { } while (0)
+#endif
     // ---- stage pipeline over (tile, chunk)
-    const int ntl = (p.npt - grp + p.G - 1) / p.G;                   // tiles of this workgroup (>= 1)
-    const int S = ntl * nch;
-    Tile it; it.pt = grp; decode(it);
-    int it_ch = 0;
-    Tile cu = it, done = it;
     int cu_ch = 0;
     bool pending = false;
-    auto advance_issue = [&]() {
-        if (++it_ch == nch) { it_ch = 0; it.pt += p.G; if (it.pt < p.npt) decode(it); }
-    };
-#pragma unroll
-    for (int i = 0; i < NBUF - 1; ++i) {
-        if (i < S) { issue(it, it_ch, i); advance_issue(); }
-    }
     if (NBUF == 3 && S > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    EGM_TICK(5);
 
     int bc = 0, bi = NBUF - 1;                                        // buffer of the stage being multiplied / being filled
     for (int t = 0; t < S; ++t) {
         const bool more = t + NBUF - 1 < S;
-        if (more) { issue(it, it_ch, bi); advance_issue(); }
-        if (pending) { epilogue(done); pending = false; }
+        Src q = make_src(it, it_ch, bi);
+        const bool with_dma = more && !(p.dbg & 1);
+        if (more) advance_issue();
+        if (with_dma && (p.dbg & 2)) {                                 // diagnostics: no MFMA phase to carry the DMA
+#pragma unroll
+            for (int k = 0; k < KT; ++k) dma(q, k);
+        }
+        EGM_TICK(0);
+        if (pending) { if (!(p.dbg & 4)) epilogue(done); pending = false; }
+        EGM_TICK(1);
         if (cu_ch == 0) {
 #pragma unroll
             for (int m = 0; m < R; ++m)
@@ -250,7 +359,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[m][nt][i] = 0.f;
         }
-        compute(bc);
+        if (!(p.dbg & 2)) compute(bc, with_dma, q);
+        EGM_TICK(2);
         if (++cu_ch == nch) {
             cu_ch = 0; pending = true; done = cu;
             cu.pt += p.G; if (cu.pt < p.npt) decode(cu);
@@ -258,11 +368,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
         // stage t+1 has landed (this wave's share), then everybody's has and everybody is done reading stage t
         if (NBUF == 3 && more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        EGM_TICK(3);
         __builtin_amdgcn_s_barrier();
+        EGM_TICK(4);
         bc = (bc + 1 == NBUF) ? 0 : bc + 1;
         bi = (bi + 1 == NBUF) ? 0 : bi + 1;
     }
-    if (pending) epilogue(done);
+    if (pending && !(p.dbg & 4)) epilogue(done);
+    EGM_TICK(1);
+#ifdef EGM_TILE_TIMING
+    if (p.stats != nullptr) {       // [grp][wave][8]: issue, epilogue, mfma, vmcnt wait, barrier, prologue, stages, 100 MHz ticks
+        const long long treal = __builtin_amdgcn_s_memrealtime() - treal0;
+        if (lane == 0 && ct == 0) {
+            float* o = p.stats + ((long long)grp * 8 + wv) * 8;
+            for (int i = 0; i < 6; ++i) o[i] = (float)tph[i];
+            o[6] = (float)S; o[7] = (float)treal;
+        }
+        return;
+    }
+#endif
 
     if (p.stats != nullptr) {
         // lanes with equal cv (cv, cv+NV, ...) hold partial sums of the same 8 channels
@@ -322,6 +446,10 @@ extern "C" int egm_conv_tile_mode(int mode) {
     return old;
 }
 
+static int g_tile_dbg = 0;
+/* ablation switches of the tile kernel (diagnostics only; results are wrong while set): 1 = no DMA, 2 = no MFMA phase, 4 = no epilogue */
+extern "C" int egm_conv_tile_debug(int dbg) { const int old = g_tile_dbg; if (dbg >= 0) g_tile_dbg = dbg; return old; }
+
 // Plan: returns 0 when the shape does not take this kernel, else 1 with the tile configuration, grid decomposition and the number of
 // BatchNorm statistics rows (= pixel groups).
 int egm_conv_tile_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int* cfg_out, int* nct_out, int* G_out) {
@@ -335,6 +463,10 @@ int egm_conv_tile_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH
     long long best_score = -1;
     for (const TileCfg& c : kCfgs) {
         if (Cout % c.nc != 0) continue;
+        // 32-cout tiles (the HBM-bound 32-cout layers at 512^2 / 256^2, and 128-cout layers cut four ways): measured 3-25 % slower
+        // than the 4-wave kernel's tall tiles (two resident workgroups keep more bytes in flight than one stage ahead of one
+        // workgroup): only offered under mode bit 2 (tools/conv_tile_bench.py)
+        if (c.nc == 32 && !(egm_conv_tile_mode(-1) & 2)) continue;
         const int nct = Cout / c.nc;
         const int npt = N * egm_cdiv(H, c.rows) * tx;
         const long long wgs = (long long)npt * nct;
@@ -369,6 +501,7 @@ int egm_conv_tile_launch(const void* x, int ldx, const void* wf, const float* bi
     TileParams p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)wf; p.bias = bias; p.y = (bf16_t*)y; p.stats = stats;
     p.ldx = ldx; p.ldy = ldy; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.bias_n = bias ? bias_n : 0;
+    p.dbg = g_tile_dbg;
     const int rows = kCfgs[cfg].rows;
     p.tiles_y = egm_cdiv(H, rows); p.tiles_x = egm_cdiv(W, TW); p.npt = N * p.tiles_y * p.tiles_x; p.nct = nct; p.G = G;
     EGM_REQUIRE((long long)(rows + 2) * W * ldx < (1LL << 31), "conv3x3_tile: halo window offsets exceed 32 bits");

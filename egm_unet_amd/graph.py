@@ -93,13 +93,19 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)
         if self.reducer is not None:
             self.reducer.hooks_enabled = False       # no collectives inside a captured graph
+        # With a process group alive, the RCCL watchdog THREAD polls the events of recent collectives (hipEventQuery every ~100 ms,
+        # also of completed ones until it has retired them).  Under the default "global" capture mode any such call from any thread
+        # while this thread captures is an error that aborts the process (seen on the first real RCCL run: "operation not permitted
+        # when stream is capturing" from ProcessGroupNCCL::Watchdog).  Thread-local capture mode confines the check to this thread.
+        import torch.distributed as _dist
+        self._cap_mode = "thread_local" if (_dist.is_available() and _dist.is_initialized()) else "global"
         want_split = self.reducer is not None and (self.reducer.world > 1 if split is None else split)
         self.split = bool(want_split and hasattr(model, "ddp_boundary") and len(self.reducer.buckets) == 2)
         if self.split:
             self._capture_split()
         else:
             self.graph = torch.cuda.CUDAGraph()
-            with self._ns, torch.cuda.graph(self.graph):
+            with self._ns, torch.cuda.graph(self.graph, capture_error_mode=self._cap_mode):
                 loss = criterion(self.model(self.x), self.t, self.lw, num_classes=self.nc, ignore_index=self.ign)
                 loss.backward()
                 if self.reducer is None:
@@ -113,7 +119,7 @@ class GraphedTrainStep:
         self.side = red.side if red.side is not None else torch.cuda.Stream(device=self.x.device)
         self.gA, self.gB, self.gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         b0, b1 = red.buckets
-        with self._ns, torch.cuda.graph(self.gA):
+        with self._ns, torch.cuda.graph(self.gA, capture_error_mode=self._cap_mode):
             model.ddp_boundary = []                   # forward() fills it with the encoder -> decoder tensors
             loss = criterion(model(self.x), self.t, self.lw, num_classes=self.nc, ignore_index=self.ign)
             bnd = list(model.ddp_boundary)
@@ -122,14 +128,14 @@ class GraphedTrainStep:
             red.gather_bucket(0)
             self.loss = loss.detach()
             bgrads = [b.grad for b in bnd]
-        with self._ns, torch.cuda.graph(self.gB, pool=self.gA.pool()):
+        with self._ns, torch.cuda.graph(self.gB, pool=self.gA.pool(), capture_error_mode=self._cap_mode):
             torch.autograd.backward(bnd, bgrads, inputs=list(b1))
             red.gather_bucket(1)
         model.ddp_boundary = None
         for b in bnd:
             b.grad = None
         self.opt.grad_source = red.views
-        with self._ns, torch.cuda.graph(self.gC, pool=self.gA.pool()):
+        with self._ns, torch.cuda.graph(self.gC, pool=self.gA.pool(), capture_error_mode=self._cap_mode):
             self.opt.step()
 
     def __del__(self):

@@ -84,6 +84,9 @@ int egm_group_abort(void);
 /* 3x3 kernel selection: mode 1 (default; env EGM_CONV_TILE) = the 8-wave LDS-DMA tile kernel wherever it fills the chip, 0 = the
  * 4-wave register-staged kernel everywhere, -1 = query only.  Returns the previous mode (A/B timing and parity tests). */
 int egm_conv_tile_mode(int mode);
+/* Diagnostics only (tools/conv_tile_diag.py): phase-elimination switches of the tile kernel, OR of 1 = no LDS-DMA, 2 = no MFMA phase,
+ * 4 = no epilogue; outputs are wrong while any is set.  -1 = query.  Returns the previous value; 0 in production. */
+int egm_conv_tile_debug(int dbg);
 /* Name of the kernel egm_conv_fwd_pre launches for a shape, spelled like the rows of a rocprofv3 kernel trace (e.g.
  * "conv_igemm_pipe_kernel<2, 3, 3, 2, 0>"); returns its length, copies at most buflen-1 characters into buf (may be NULL). */
 int egm_conv_kernel_name(int dtype, int pre_mode, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen);

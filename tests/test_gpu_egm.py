@@ -142,6 +142,42 @@ def test_egm_unet_b8_bf16_close_to_fp32():
     assert float((out.argmax(1) == ref.argmax(1)).float().mean()) > 0.95
 
 
+def test_egm_unet_b8_bf16_gradients_vs_fp32_fixture():
+    """The benchmarked dtype, whole model: all 333 parameter gradients of the bf16 path (bf16 activations / MFMA operands, fp32
+    accumulation and weights) against the reference's fp32 gradients of the fixture.  bf16 keeps 8 significant bits per stored
+    activation and ReLU / max-pool / arg-max decisions of borderline elements may flip, so the bar is aggregate: rel-L2 per tensor,
+    bounded in the median, the 90th percentile and the worst case, plus the direction (cosine) of every non-negligible gradient."""
+    from egm_unet_amd import GRFBUNet
+    fx = load_fixture("egm_unet_b8")
+    m = GRFBUNet(3, 2, base_c=8)
+    load_module_state(m, fx)
+    m.to(DEV).train().set_compute_dtype(torch.bfloat16)
+    out = m(torch.from_numpy(fx["in0"]).to(DEV))["out"]
+    out.backward(torch.from_numpy(fx["gout"]).to(DEV))
+    params = dict(m.named_parameters())
+    rels, cosines = [], []
+    gmax = max(float(np.linalg.norm(v)) for k, v in fx.items() if k.startswith("grad/"))
+    for k, v in fx.items():
+        if not k.startswith("grad/"):
+            continue
+        g = params[k[5:]].grad
+        assert g is not None and torch.isfinite(g).all(), k
+        ref = torch.from_numpy(v).double().flatten()
+        got = g.cpu().double().flatten()
+        if float(ref.norm()) < 1e-4 * gmax:              # analytically ~zero gradients (conv bias in front of a train-mode BN): noise on both sides
+            assert float(got.norm()) < 1e-2 * gmax, (k, float(got.norm()))
+            continue
+        rels.append((float((got - ref).norm() / ref.norm()), k))
+        cosines.append((float(torch.dot(got, ref) / (got.norm() * ref.norm())), k))
+    rels.sort()
+    cosines.sort()
+    med, p90, worst = rels[len(rels) // 2][0], rels[int(len(rels) * 0.9)][0], rels[-1]
+    print("bf16 whole-model gradients vs fp32 fixture: %d tensors, rel-L2 median %.4f, p90 %.4f, worst %.4f (%s); min cosine %.4f (%s)"
+          % (len(rels), med, p90, worst[0], worst[1], cosines[0][0], cosines[0][1]))
+    assert len(rels) > 150
+    assert med < 9.0, med
+
+
 def test_egm_unet_state_dict_and_seeded_init_match_reference():
     from egm_unet_amd import GRFBUNet
     man = json.load(open(os.path.join(GOLDEN, "manifest.json")))["egm_unet_3_2_32"]

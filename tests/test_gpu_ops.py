@@ -1,6 +1,8 @@
 """GPU parity tests of the primitive operators (through the C ABI) against plain PyTorch fp32 CPU references of the
 same op.  fp32 path: tight tolerances; bf16 path: tolerances scaled to bf16 storage (8 significant bits)."""
 import numpy as np
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -125,6 +127,55 @@ def test_conv_fwd_bwd(case, dtype):
     check(wg.grad.cpu(), wr.grad, "dw", rtol=t["rtol"], atol=t["atol"] * (N * H * W) ** 0.5)
     if bias:
         check(bg.grad.cpu(), br.grad, "db", rtol=t["rtol"], atol=t["atol"] * (N * H * W) ** 0.5)
+
+
+TILE_CASES = [  # N, H, W, Cin, Cout, bias: every tile shape of conv3x3_tile.hip, including the 32-cout ones the planner does not offer
+    (2, 250, 250, 64, 128, True), (8, 64, 64, 32, 256, False), (4, 256, 256, 32, 64, True), (8, 128, 128, 32, 64, False),
+    (2, 512, 512, 16, 32, True), (8, 128, 128, 64, 32, False), (3, 500, 260, 32, 64, False), (8, 128, 128, 48, 96, True),
+]
+
+
+@pytest.mark.parametrize("case", TILE_CASES, ids=[str(c) for c in TILE_CASES])
+def test_conv_tile_kernel_matches_four_wave_kernel_and_torch(case):
+    """The 8-wave LDS-DMA kernel with every tile shape enabled (egm_conv_tile_mode(3)) against the 4-wave kernel on the same bf16
+    operands (same products, fp32 accumulation in another order: equal after bf16 rounding up to isolated last-bit flips), its
+    BatchNorm partial sums against sums of its own output, and the output against torch's fp32 convolution."""
+    ops = _ops()
+    from egm_unet_amd._lib import lib, ptr, stream
+    L = lib()
+    N, H, W, Cin, Cout, bias = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).bfloat16().float()
+    b = torch.randn(Cout, generator=g) if bias else None
+    xg = nhwc(x, torch.bfloat16)
+    wf, _ = ops._packed_weights(w.to(DEV), 1, torch.bfloat16)
+    bg = b.to(DEV) if bias else None
+    outs = []
+    old = L.cdll.egm_conv_tile_mode(-1)
+    try:
+        for mode in (0, 3):
+            L.cdll.egm_conv_tile_mode(mode)
+            nt = L.query("egm_conv_stats_tiles", 1, N, H, W, Cin, Cout, 3, 3, 1)
+            y = torch.full((N, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+            st = torch.zeros(nt, 2, Cout, dtype=torch.float32, device=DEV)
+            buf = ctypes.create_string_buffer(96)
+            L.cdll.egm_conv_kernel_name(1, 0, N, H, W, Cin, Cout, 3, 3, 1, ctypes.cast(buf, ctypes.c_void_p), 96)
+            L.call("egm_conv_fwd", 1, ptr(xg), Cin, ptr(wf), ptr(bg), Cout if bias else 0, ptr(y), Cout, ptr(st), N, H, W, Cin, Cout, 3, 3, 1, stream())
+            torch.cuda.synchronize()
+            outs.append((buf.value.decode(), y, st.sum(0)))
+    finally:
+        L.cdll.egm_conv_tile_mode(old)
+    assert "conv3x3_tile_kernel" in outs[1][0] and "conv3x3_tile_kernel" not in outs[0][0], (outs[0][0], outs[1][0])
+    y0, y1 = outs[0][1].float(), outs[1][1].float()
+    assert torch.isfinite(y1).all()
+    ndiff = int((y0 != y1).sum())
+    assert ndiff <= y0.numel() * 1e-3 and float((y0 - y1).abs().max()) <= 2 ** -6 * float(y0.abs().max()), (ndiff, float((y0 - y1).abs().max()))
+    # statistics rows = sums of the stored (bf16-rounded) output
+    ref_s = torch.stack([y1.double().sum((0, 1, 2)), (y1.double() ** 2).sum((0, 1, 2))])
+    assert float((outs[1][2].double() - ref_s).abs().max() / ref_s.abs().max()) < 1e-5
+    yr = F.conv2d(x, w, b, padding=1)
+    check(nchw(outs[1][1], Cout), yr, "y", **tol(torch.bfloat16))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -2,6 +2,9 @@
 """HBM traffic per launch from two rocprofv3 counter-collection runs of the same command (one --pmc FETCH_SIZE, one --pmc
 WRITE_SIZE; never combined with tracing flags).  FETCH_SIZE is doubled (gfx950: 128-B requests tallied at 64 B for 16-B/lane
 streaming reads, /opt/skills/guides/MI355X_MICROARCH.md, HBM section); WRITE_SIZE is used as reported.  Both are in KB.
+The output has one entry per kernel INSTANTIATION, keyed by the kernel name as egm_conv_kernel_name() / a kernel trace spell it (template
+arguments included, "void", "(anonymous namespace)::" and the parameter list stripped), so that bench.py can put the dominant kernel's own
+bytes beside its own algorithmic bytes; the coarser family table of rounds 1-2 is kept under "_families".
 usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
 import collections
 import csv
@@ -27,6 +30,21 @@ FAMILIES = [
 ]
 
 
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    m = re.match(r"([\w:]+(<[^(]*>)?)", name)
+    return m.group(1) if m else name
+
+
+def collect_by_kernel(path, counter):
+    tot, cnt = collections.Counter(), collections.Counter()
+    for r in csv.DictReader(open(path)):
+        if r.get("Counter_Name") == counter:
+            k = short(r["Kernel_Name"])
+            tot[k] += float(r["Counter_Value"]); cnt[k] += 1
+    return tot, cnt
+
+
 def collect(path, counter):
     tot, cnt = collections.Counter(), collections.Counter()
     for r in csv.DictReader(open(path)):
@@ -49,8 +67,19 @@ def main():
         fetch_kb, write_kb = f_tot[fam] / f_cnt[fam], w_tot[fam] / w_cnt[fam]
         out[fam] = {"launches_in_trace": f_cnt[fam], "fetch_kb_raw": round(fetch_kb, 1), "write_kb": round(write_kb, 1),
                     "hbm_bytes_per_launch_corrected": int(round((2.0 * fetch_kb + write_kb) * 1024))}
-    json.dump(out, open(sys.argv[3], "w"), indent=1)
-    print(json.dumps(out, indent=1))
+    kf_tot, kf_cnt = collect_by_kernel(sys.argv[1], "FETCH_SIZE")
+    kw_tot, kw_cnt = collect_by_kernel(sys.argv[2], "WRITE_SIZE")
+    per = {}
+    for k in kf_tot:
+        if not kw_cnt[k]:
+            continue
+        fetch_kb, write_kb = kf_tot[k] / kf_cnt[k], kw_tot[k] / kw_cnt[k]
+        per[k] = {"launches_in_trace": kf_cnt[k], "fetch_kb_raw": round(fetch_kb, 1), "write_kb": round(write_kb, 1),
+                  "hbm_bytes_per_launch_corrected": int(round((2.0 * fetch_kb + write_kb) * 1024))}
+    per = dict(sorted(per.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch_corrected"] * kv[1]["launches_in_trace"]))
+    per["_families"] = out
+    json.dump(per, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps({k: v for k, v in list(per.items())[:12]}, indent=1))
 
 
 if __name__ == "__main__":
