@@ -143,10 +143,12 @@ def test_egm_unet_b8_bf16_close_to_fp32():
 
 
 def test_egm_unet_b8_bf16_gradients_vs_fp32_fixture():
-    """The benchmarked dtype, whole model: all 333 parameter gradients of the bf16 path (bf16 activations / MFMA operands, fp32
-    accumulation and weights) against the reference's fp32 gradients of the fixture.  bf16 keeps 8 significant bits per stored
-    activation and ReLU / max-pool / arg-max decisions of borderline elements may flip, so the bar is aggregate: rel-L2 per tensor,
-    bounded in the median, the 90th percentile and the worst case, plus the direction (cosine) of every non-negligible gradient."""
+    """The benchmarked dtype, whole model: the parameter gradients of the bf16 path (bf16 activations / MFMA operands, fp32
+    accumulation and weights) against the REFERENCE's fp32 gradients of the fixture.  bf16 keeps 8 significant bits per stored
+    activation, and every flipped ReLU / max-pool / arg-max decision is an O(1) error in the gradient (tests/test_gpu_fullsize.py
+    explains the arithmetic and pins the headline shape); on this 64 x 64, base_c = 8 fixture the deepest BatchNorms average 32
+    values, which adds statistical noise on top, and a few gate weights with three elements can even change sign.  The bar is
+    therefore aggregate (median / 90th percentile of the per-tensor rel-L2) plus exactness where no rectifier lies in between."""
     from egm_unet_amd import GRFBUNet
     fx = load_fixture("egm_unet_b8")
     m = GRFBUNet(3, 2, base_c=8)
@@ -175,7 +177,9 @@ def test_egm_unet_b8_bf16_gradients_vs_fp32_fixture():
     print("bf16 whole-model gradients vs fp32 fixture: %d tensors, rel-L2 median %.4f, p90 %.4f, worst %.4f (%s); min cosine %.4f (%s)"
           % (len(rels), med, p90, worst[0], worst[1], cosines[0][0], cosines[0][1]))
     assert len(rels) > 150
-    assert med < 9.0, med
+    assert med < 0.6 and p90 < 0.85, (med, p90)                     # measured 0.479 / 0.687
+    top = dict((k, r) for r, k in rels)
+    assert top["grad/out_conv.0.weight"] < 0.02, top["grad/out_conv.0.weight"]
 
 
 def test_egm_unet_state_dict_and_seeded_init_match_reference():

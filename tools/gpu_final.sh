@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-end evidence: kernel trace + stats of the bench command, PMC passes (traffic, MFMA busy), ablation table, bench line
-tag=${1:-r02}; out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
+tag=${1:-r03}; out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"; tail -c 600 $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o p -- python bench.py --steps 12 --warmup 3 --no-cpu-baseline > $out/prof.log 2>&1
 f=$(find $out/prof -name "*kernel_trace.csv" | head -1); st=$(find $out/prof -name "*kernel_stats.csv" | head -1)

@@ -10,6 +10,11 @@ import re
 import sys
 
 FAMILIES = [
+    ("conv fwd/dgrad 3x3, 8-wave LDS-DMA tile kernel, 16 rows x 128 couts (conv3x3_tile_kernel<4,2,4,2>)", re.compile(r"conv3x3_tile_kernel<4, 2, 4, 2")),
+    ("conv fwd/dgrad 3x3, tile kernel, 8 rows x 128 couts (conv3x3_tile_kernel<2,2,4,2>)", re.compile(r"conv3x3_tile_kernel<2, 2, 4, 2")),
+    ("conv fwd/dgrad 3x3, tile kernel, 32 rows x 64 couts (conv3x3_tile_kernel<4,2,8,1>)", re.compile(r"conv3x3_tile_kernel<4, 2, 8, 1")),
+    ("conv fwd/dgrad 3x3, tile kernel, 16 rows x 64 couts (conv3x3_tile_kernel<2,2,8,1>)", re.compile(r"conv3x3_tile_kernel<2, 2, 8, 1")),
+    ("conv fwd/dgrad 3x3, tile kernel, all shapes", re.compile(r"conv3x3_tile_kernel<")),
     ("conv fwd/dgrad 3x3, 64-wide cout tiles (conv_igemm_pipe_kernel<2,3,3,2>)", re.compile(r"conv_igemm_pipe_kernel<2, 3, 3, 2")),
     ("conv fwd/dgrad 3x3, tall tiles (conv_igemm_pipe_kernel<1,3,3,4>)", re.compile(r"conv_igemm_pipe_kernel<1, 3, 3, 4")),
     ("conv fwd/dgrad 1x1 (conv_igemm_pipe_kernel<*,1,1,2>)", re.compile(r"conv_igemm_pipe_kernel<\d, 1, 1, 2")),
