@@ -438,9 +438,11 @@ constexpr TileCfg kCfgs[] = {
 };
 }  // namespace
 
-static int g_tile_mode = -1;      // -1: not read yet (EGM_CONV_TILE, default 1); 0 = off (every 3x3 takes the 4-wave kernel); 1 = on
+// bits: 1 = 8-wave tile kernel (>= 64-cout tiles), 2 = also its 32-cout tiles (measured slower: tests / A-B runs only), 4 = weights-in-
+// registers kernel for the 32 -> 32 layers (conv3x3_wreg.hip).  -1: not read yet (env EGM_CONV_TILE, default 5); 0 = 4-wave kernel only
+static int g_tile_mode = -1;
 extern "C" int egm_conv_tile_mode(int mode) {
-    if (g_tile_mode < 0) g_tile_mode = getenv("EGM_CONV_TILE") ? atoi(getenv("EGM_CONV_TILE")) : 1;
+    if (g_tile_mode < 0) g_tile_mode = getenv("EGM_CONV_TILE") ? atoi(getenv("EGM_CONV_TILE")) : 5;
     const int old = g_tile_mode;
     if (mode >= 0) g_tile_mode = mode;
     return old;
@@ -457,7 +459,7 @@ int egm_conv_tile_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH
     if (!egm_w_chunk16(dtype, KH, KW, Cin, Cout)) return 0;
     if (Cout % 32 != 0) return 0;
     if (egm_group_recording()) return 0;                     // merged launches of small sibling convs stay on the 4-wave kernel
-    if (egm_conv_tile_mode(-1) == 0) return 0;
+    if (!(egm_conv_tile_mode(-1) & 1)) return 0;
     const int tx = egm_cdiv(W, TW);
     int best = -1, best_nct = 0, best_npt = 0;
     long long best_score = -1;

@@ -42,6 +42,11 @@ int egm_conv_direct_launch(const void* x, int ldx, const PreArgs& pre, const voi
 // conv3x3_tile.hip: 8-wave LDS-DMA 3x3 kernel (the throughput path of the 3x3 stacks)
 int egm_conv_tile_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int* cfg_out, int* nct_out, int* G_out);
 const char* egm_conv_tile_name(int cfg);
+// conv3x3_wreg.hip: weights-in-registers 3x3 kernel for the 32-cout layers
+int egm_conv_wreg_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int* G_out);
+const char* egm_conv_wreg_name(int Cin);
+int egm_conv_wreg_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, float* stats, int N, int H,
+                         int W, int Cin, int Cout, int G, egm_stream_t s);
 int egm_conv_tile_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, float* stats, int N, int H,
                          int W, int Cin, int Cout, int cfg, int nct, int G, egm_stream_t s);
 
@@ -806,13 +811,15 @@ int launch_pipe(ConvParams& p, int G, hipStream_t st) {
 }
 
 // One place decides kernel, tile shape and grouping, so the stats-tile count the caller allocates always matches the launch.
-struct ConvPlan { bool pipe, direct, tile; int tile_cfg; int R, NT, tiles_y, tiles_x, npt, nct, G; size_t smem; };
+struct ConvPlan { bool pipe, direct, tile, wreg; int tile_cfg; int R, NT, tiles_y, tiles_x, npt, nct, G; size_t smem; };
 ConvPlan conv_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int pre_mode = EGM_PRE_NONE) {
     ConvPlan c;
     if (KH == 1 && KW == 1) dil = 1;
     // prologues the fast kernels are not built with (the BatchNorm-backward form; anything in front of a 7x7) take the generic kernel
     const bool fast_ok = pre_mode == EGM_PRE_NONE || (pre_mode == EGM_PRE_BN_ACT && KH != 7);
     c.tile_cfg = 0;
+    c.wreg = pre_mode == EGM_PRE_NONE && egm_conv_wreg_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.G) != 0;
+    if (c.wreg) { c.pipe = c.direct = c.tile = false; c.R = 2; c.NT = 1; c.nct = 1; c.tiles_y = c.tiles_x = c.npt = 0; c.smem = 0; return c; }
     c.tile = pre_mode == EGM_PRE_NONE && egm_conv_tile_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.tile_cfg, &c.nct, &c.G) != 0;
     if (c.tile) { c.pipe = c.direct = false; c.R = 2; c.NT = 2; c.tiles_y = c.tiles_x = c.npt = 0; c.smem = 0; return c; }
     c.direct = fast_ok && Cin > 0 && egm_conv_direct_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.NT, &c.nct, &c.G, &c.smem) != 0;
@@ -850,7 +857,8 @@ extern "C" int egm_conv_kernel_name(int dtype, int pre_mode, int N, int H, int W
     const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, pre_mode);
     char tmp[96];
     const int pre = pre_mode == EGM_PRE_NONE ? 0 : 1;
-    if (c.tile) snprintf(tmp, sizeof(tmp), "%s", egm_conv_tile_name(c.tile_cfg));
+    if (c.wreg) snprintf(tmp, sizeof(tmp), "%s", egm_conv_wreg_name(Cin));
+    else if (c.tile) snprintf(tmp, sizeof(tmp), "%s", egm_conv_tile_name(c.tile_cfg));
     else if (c.direct) snprintf(tmp, sizeof(tmp), "conv_direct_kernel<%d, %d, %s>", c.NT, pre, KH == 1 ? "true" : "false");
     else if (c.pipe) snprintf(tmp, sizeof(tmp), "conv_igemm_pipe_kernel<%d, %d, %d, %d, %d>", c.NT, (KH == 3 && dil == 1) ? 3 : 1,
                               (KH == 3 && dil == 1) ? 3 : (KH == 7 ? 7 : 1), c.R, pre);
@@ -919,6 +927,7 @@ extern "C" int egm_conv_fwd_pre(int dtype, const void* x, int ldx, int pre_mode,
     p.wl = egm_w_layout(dtype, KH, KW, Cin, Cout);
     p.pre.mode = pre_mode; p.pre.act = pre_act; p.pre.cf = pre_cf; p.pre.aux = pre_aux; p.pre.ld_aux = pre_ld_aux; p.pre.C = Cin;
     const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, pre_mode);
+    if (c.wreg) return egm_conv_wreg_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, c.G, s);
     if (c.tile) return egm_conv_tile_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, c.tile_cfg, c.nct, c.G, s);
     if (c.direct)
         return egm_conv_direct_launch(x, ldx, p.pre, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, KH, KW, dil, c.NT,

@@ -81,8 +81,10 @@ int egm_conv_pack_multi(int dtype, const void* table_dev, int n, long long total
 int egm_group_begin(void);
 int egm_group_end(egm_stream_t s);
 int egm_group_abort(void);
-/* 3x3 kernel selection: mode 1 (default; env EGM_CONV_TILE) = the 8-wave LDS-DMA tile kernel wherever it fills the chip, 0 = the
- * 4-wave register-staged kernel everywhere, -1 = query only.  Returns the previous mode (A/B timing and parity tests). */
+/* 3x3 kernel selection, a bit mask (default 5; env EGM_CONV_TILE): 1 = the 8-wave LDS-DMA tile kernel wherever its >= 64-cout tiles
+ * fill the chip, 2 = its 32-cout tiles too (measured slower than the 4-wave kernel: parity tests and A/B runs only), 4 = the
+ * weights-in-registers kernel for the 32 -> 32 layers; 0 = the 4-wave register-staged kernel everywhere; -1 = query only.
+ * Returns the previous mode (A/B timing and parity tests). */
 int egm_conv_tile_mode(int mode);
 /* Diagnostics only (tools/conv_tile_diag.py): phase-elimination switches of the tile kernel, OR of 1 = no LDS-DMA, 2 = no MFMA phase,
  * 4 = no epilogue; outputs are wrong while any is set.  -1 = query.  Returns the previous value; 0 in production. */

@@ -43,11 +43,13 @@ def test_argument_validation_without_gpu(built_lib):
     rc = L.cdll.egm_conv_fwd(1, None, 8, None, None, 0, None, 8, None, 1, 8, 8, 8, 8, 3, 3, 1, None)
     assert rc == -1 and b"null pointer" in L.cdll.egm_last_error()
     assert L.cdll.egm_conv_stats_tiles(0, 8, 512, 512, 32, 32, 3, 3, 1) == 8 * 64 * 16
-    assert L.cdll.egm_conv_stats_tiles(1, 8, 512, 512, 32, 32, 3, 3, 1) == 512      # 32-cout layer: 4-wave kernel, two pixel groups per CU
+    assert L.cdll.egm_conv_stats_tiles(1, 8, 512, 512, 64, 32, 3, 3, 1) == 512      # 64 -> 32: 4-wave kernel, two pixel groups per CU
+    assert L.cdll.egm_conv_stats_tiles(1, 8, 512, 512, 32, 32, 3, 3, 1) == 256      # 32 -> 32: weights-in-registers kernel, one per CU
     assert L.cdll.egm_conv_stats_tiles(1, 8, 256, 256, 64, 64, 3, 3, 1) == 256      # 8-wave tile kernel: one pixel group per CU
-    assert L.cdll.egm_conv_tile_mode(0) == 1
+    assert L.cdll.egm_conv_tile_mode(0) == 5
     assert L.cdll.egm_conv_stats_tiles(1, 8, 256, 256, 64, 64, 3, 3, 1) == 512      # switched off: the 4-wave kernel again
-    assert L.cdll.egm_conv_tile_mode(1) == 0
+    assert L.cdll.egm_conv_stats_tiles(1, 8, 512, 512, 32, 32, 3, 3, 1) == 512
+    assert L.cdll.egm_conv_tile_mode(5) == 0
     assert L.cdll.egm_loss_workspace(8, 2) > 0
     assert L.cdll.egm_conv_wgrad_workspace(8, 512, 512, 64, 32, 3, 3) > 0
 

@@ -132,12 +132,13 @@ def test_conv_fwd_bwd(case, dtype):
 TILE_CASES = [  # N, H, W, Cin, Cout, bias: every tile shape of conv3x3_tile.hip, including the 32-cout ones the planner does not offer
     (2, 250, 250, 64, 128, True), (8, 64, 64, 32, 256, False), (4, 256, 256, 32, 64, True), (8, 128, 128, 32, 64, False),
     (2, 512, 512, 16, 32, True), (8, 128, 128, 64, 32, False), (3, 500, 260, 32, 64, False), (8, 128, 128, 48, 96, True),
+    (8, 256, 256, 32, 32, False), (3, 500, 270, 32, 32, True), (5, 208, 320, 32, 32, False),     # weights-in-registers kernel (Cin = Cout = 32): even / odd tile counts per workgroup, ragged edges
 ]
 
 
 @pytest.mark.parametrize("case", TILE_CASES, ids=[str(c) for c in TILE_CASES])
 def test_conv_tile_kernel_matches_four_wave_kernel_and_torch(case):
-    """The 8-wave LDS-DMA kernel with every tile shape enabled (egm_conv_tile_mode(3)) against the 4-wave kernel on the same bf16
+    """The 8-wave LDS-DMA kernels with every tile shape and the weights-in-registers form enabled (egm_conv_tile_mode(7)) against the 4-wave kernel on the same bf16
     operands (same products, fp32 accumulation in another order: equal after bf16 rounding up to isolated last-bit flips), its
     BatchNorm partial sums against sums of its own output, and the output against torch's fp32 convolution."""
     ops = _ops()
@@ -154,7 +155,7 @@ def test_conv_tile_kernel_matches_four_wave_kernel_and_torch(case):
     outs = []
     old = L.cdll.egm_conv_tile_mode(-1)
     try:
-        for mode in (0, 3):
+        for mode in (0, 7):
             L.cdll.egm_conv_tile_mode(mode)
             nt = L.query("egm_conv_stats_tiles", 1, N, H, W, Cin, Cout, 3, 3, 1)
             y = torch.full((N, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
@@ -166,7 +167,7 @@ def test_conv_tile_kernel_matches_four_wave_kernel_and_torch(case):
             outs.append((buf.value.decode(), y, st.sum(0)))
     finally:
         L.cdll.egm_conv_tile_mode(old)
-    assert "conv3x3_tile_kernel" in outs[1][0] and "conv3x3_tile_kernel" not in outs[0][0], (outs[0][0], outs[1][0])
+    assert "conv3x3_" in outs[1][0] and "conv3x3_" not in outs[0][0], (outs[0][0], outs[1][0])
     y0, y1 = outs[0][1].float(), outs[1][1].float()
     assert torch.isfinite(y1).all()
     ndiff = int((y0 != y1).sum())

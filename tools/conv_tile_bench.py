@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egm_unet_amd import ops
 from egm_unet_amd._lib import lib, ptr, stream
 
+NEW = int(os.environ.get("NEW_MODE", "5"))      # egm_conv_tile_mode bits: 1 = tile kernel, 2 = + 32-cout tiles, 4 = + weights-in-registers kernel
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 train = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 # (name, Cin, Cout, HW); the data gradient of a layer is the same conv with Cin/Cout swapped
@@ -28,6 +29,9 @@ for name, ci, co, hw in LAYERS:
     shapes.append((name, ci, co, hw))
     if ci != co:
         shapes.append((name + " dgrad", co, ci, hw))
+if os.environ.get("ONLY"):            # e.g. ONLY=32x32: just the layers with that Cin x Cout (either order)
+    a, b = (int(v) for v in os.environ["ONLY"].split("x"))
+    shapes = [sh for sh in shapes if (sh[1], sh[2]) in ((a, b), (b, a))]
 L = lib()
 N = 8
 rows = []
@@ -39,7 +43,7 @@ for name, ci, co, hw in shapes:
     outs, names, ntiles = [], [], []
     ys = [torch.empty(N, hw, hw, co, dtype=torch.bfloat16, device="cuda") for _ in range(2)]
     st = []
-    for mode in (0, 1):
+    for mode in (0, NEW):
         L.cdll.egm_conv_tile_mode(mode)
         nt = L.query("egm_conv_stats_tiles", 1, N, hw, hw, ci, co, 3, 3, 1)
         st.append(torch.zeros(nt, 2, co, dtype=torch.float32, device="cuda"))
@@ -48,7 +52,7 @@ for name, ci, co, hw in shapes:
         names.append(buf.value.decode())
 
     def run(mode):
-        L.cdll.egm_conv_tile_mode(mode)
+        L.cdll.egm_conv_tile_mode(NEW if mode else 0)
         L.call("egm_conv_fwd", 1, ptr(x), ci, ptr(wf), None, 0, ptr(ys[mode]), co, ptr(st[mode]), N, hw, hw, ci, co, 3, 3, 1, stream())
 
     run(0); run(1)

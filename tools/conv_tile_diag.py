@@ -19,6 +19,8 @@ timing = os.environ.get("EGM_LIB_TAG") == "timing"
 shapes = [(8, 128, 128, 128, 128), (8, 256, 256, 64, 64), (8, 512, 512, 32, 32), (8, 64, 64, 256, 256), (8, 64, 64, 256, 512)]
 if len(sys.argv) > 5:
     shapes = [tuple(int(v) for v in sys.argv[1:6])]
+if os.environ.get("NEW_MODE"):
+    L.cdll.egm_conv_tile_mode(int(os.environ["NEW_MODE"]))
 for N, H, W, ci, co in shapes:
     g = torch.Generator().manual_seed(1)
     x = torch.randn(N, H, W, ci, generator=g).cuda().bfloat16()
