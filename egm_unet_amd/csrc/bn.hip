@@ -7,7 +7,6 @@
 
 namespace {
 
-constexpr int kMaxPartialBlocks = 1024;
 
 // block = 256 threads = (256 / ncv) pixel rows x ncv channel-vectors; out[blk][2][C]
 // MODE 0: (x, x^2).  MODE 1 (BN backward): (dzp, dzp*xhat) with dzp = dz*act'(y*scale+shift), xhat = (y-mean)*rstd.
@@ -326,13 +325,6 @@ inline int stream_grid(long long total_threads) {
     return (int)b;
 }
 
-inline int partial_blocks(long long npix, int C) {
-    const int rows = 256 / (C >> 3);
-    long long b = (npix + rows - 1) / rows;
-    if (b > kMaxPartialBlocks) b = kMaxPartialBlocks;
-    if (b < 1) b = 1;
-    return (int)b;
-}
 
 // ---- multi-tensor forms: the BatchNorm passes of up to EGM_BN_MULTI_MAX INDEPENDENT layers (the parallel branches of
 // EdgeEnhancedGRFB, src/EGM-UNet.py:1256-1278: 8-32 channel tensors whose passes are launch-latency bound) in ONE launch each.
@@ -378,7 +370,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_multi_kernel(BnMulti m) {
 int multi_blocks(const egm_bn_desc& d, int which) {
     switch (which) {
         case 0: case 3: return (d.C + 7) / 8;
-        case 2: return partial_blocks(d.npix, d.C);
+        case 2: return egm_partial_blocks(d.npix, d.C);
         default: return stream_grid(d.npix * (d.C >> 3));
     }
 }
@@ -403,13 +395,13 @@ int multi_build(const egm_bn_desc* descs, int n, int which, BnMulti* m) {
 
 extern "C" int egm_channel_partials_blocks(long long npix, int C) {
     if (C <= 0 || C % 8 || C > 2048) return -1;
-    return partial_blocks(npix, C);
+    return egm_partial_blocks(npix, C);
 }
 
 extern "C" int egm_channel_sums(int dtype, const void* x, int ld, long long npix, int C, float* partials, egm_stream_t s) {
     EGM_REQ_VEC("channel_sums", x, ld, C);
     EGM_REQUIRE(partials && npix > 0 && C <= 2048, "channel_sums: bad args");
-    const int nb = partial_blocks(npix, C);
+    const int nb = egm_partial_blocks(npix, C);
     EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_partials_kernel<T, 0>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const T*)x,
                                                  ld, (const T*)nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, npix, C, partials));
     EGM_CHECK_LAUNCH("channel_sums");
@@ -469,7 +461,7 @@ extern "C" int egm_bn_act_bwd_reduce(int dtype, const void* dz, int lddz, const 
     EGM_REQ_VEC("bn_act_bwd_reduce", dz, lddz, C);
     EGM_REQ_VEC("bn_act_bwd_reduce", y, ldy, C);
     EGM_REQUIRE(scale && shift && save_mean && save_rstd && partials && npix > 0 && C <= 1024, "bn_act_bwd_reduce: bad args (C <= 1024)");
-    const int nb = partial_blocks(npix, C);
+    const int nb = egm_partial_blocks(npix, C);
     EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_partials_kernel<T, 1>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const T*)dz,
                                                  lddz, (const T*)y, ldy, scale, shift, save_mean, save_rstd, act, npix, C, partials));
     EGM_CHECK_LAUNCH("bn_act_bwd_reduce");

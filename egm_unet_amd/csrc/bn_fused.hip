@@ -16,7 +16,6 @@
 
 namespace {
 
-constexpr int kMaxPartialBlocks = 1024;
 
 template <typename T> __device__ __forceinline__ float rnd(float v) { return to_f32(from_f32<T>(v)); }   // value after a store + load
 
@@ -196,13 +195,6 @@ inline int stream_grid(long long total_threads) {
     if (b < 1) b = 1;
     return (int)b;
 }
-inline int partial_blocks(long long npix, int C) {
-    const int rows = 256 / (C >> 3);
-    long long b = (npix + rows - 1) / rows;
-    if (b > kMaxPartialBlocks) b = kMaxPartialBlocks;
-    if (b < 1) b = 1;
-    return (int)b;
-}
 
 }  // namespace
 
@@ -229,7 +221,7 @@ extern "C" int egm_bn_ew_bwd_reduce(int dtype, int mode, const void* g, int ldg,
                                     float alpha, float* partials, long long npix, int C, egm_stream_t s) {
     EGM_REQ_VEC("bn_ew_bwd_reduce", g, ldg, C); EGM_REQ_VEC("bn_ew_bwd_reduce", q, ldq, C); EGM_REQ_VEC("bn_ew_bwd_reduce", y, ldy, C);
     EGM_REQUIRE(scale && shift && save_mean && save_rstd && partials && npix > 0 && C <= 1024, "bn_ew_bwd_reduce: bad args (C <= 1024)");
-    const int nb = partial_blocks(npix, C);
+    const int nb = egm_partial_blocks(npix, C);
     EGM_EW_DISPATCH(mode, hipLaunchKernelGGL((bn_ew_bwd_reduce_kernel<T, MODE>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const T*)g, ldg,
                                              (const T*)q, ldq, (const T*)y, ldy, scale, shift, save_mean, save_rstd, act, alpha, npix, C,
                                              partials));

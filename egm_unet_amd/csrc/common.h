@@ -109,6 +109,18 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return r;
 }
 
+// Workgroups of a per-channel partial-sum pass over an NHWC tensor (bn.hip channel_partials / bn_fused.hip bn_ew_bwd_reduce): the
+// callers size the partials buffer with egm_channel_partials_blocks() and the kernels of BOTH files launch with this count, so there
+// is exactly one definition.
+constexpr int kMaxPartialBlocks = 1024;
+static inline int egm_partial_blocks(long long npix, int C) {
+    const int rows = 256 / (C >> 3);
+    long long b = (npix + rows - 1) / rows;
+    if (b > kMaxPartialBlocks) b = kMaxPartialBlocks;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 // dtype dispatch for host launchers: body sees `T`

@@ -219,6 +219,81 @@ __global__ void upcat_bwd_low_kernel(const T* __restrict__ dout, int ldo, T* __r
     }
 }
 
+// The same gather with the up-res gradient staged in LDS (r03).  The kernel above lets every lane walk its own <= 6 x 6 up-res pixels
+// through L1: at the 512^2 level (8 x 256 x 256 x 32 outputs) that is 16 strided 16-byte loads per output vector whose wave-instruction
+// touches 32 cache lines for 1 KiB of payload, 114 us = 1.5 TB/s of algorithmic bytes.  Here a workgroup owns an 8 x 16 low-res tile of
+// a 32-channel chunk, stages the (2*8+4) x (2*16+4) up-res window once with coalesced loads (zeros outside the image / the padded
+// frame) and gathers from LDS; weights, candidate order and summation order are those of the kernel above, so the results are
+// bit-identical.
+constexpr int UB_TY = 8, UB_TX = 16, UB_CB = 32, UB_UY = 2 * UB_TY + 4, UB_UX = 2 * UB_TX + 4;
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_bwd_low_tiled_kernel(const T* __restrict__ dout, int ldo, T* __restrict__ dlow, int ldl, int N, int Hs,
+                                                                  int Ws, int Cs, int Hl, int Wl, int Cl, int tiles_x, int tiles_y, int nchunk) {
+    __shared__ __attribute__((aligned(16))) T sg[UB_UY * UB_UX * UB_CB];
+    __shared__ float swy[UB_TY][6], swx[UB_TX][6];               // interpolation weights of the tile's rows / columns, once per workgroup
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int chunk = b % nchunk; b /= nchunk;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y; const int n = b / tiles_y;
+    const int yl0 = ty * UB_TY, xl0 = tx * UB_TX, c0 = chunk * UB_CB;
+    const int nvec = (Cl - c0 < UB_CB ? Cl - c0 : UB_CB) >> 3;
+    const int Hu = 2 * Hl, Wu = 2 * Wl, py = (Hs - Hu) / 2, px = (Ws - Wu) / 2;
+    const int uy0 = 2 * yl0 - 2, ux0 = 2 * xl0 - 2;
+    if (tid < UB_TY * 6) {                                         // (the per-lane form spent ~200 of its ~600 VALU operations per vector here)
+        const int ly = tid / 6, k = tid - ly * 6, yl = yl0 + ly, uy = 2 * yl - 2 + k;
+        float w = 0.f;
+        if (uy >= 0 && uy < Hu && uy + py >= 0 && uy + py < Hs) {
+            const Lerp l = lerp_coord(uy, Hl, Hu);
+            w = (l.i0 == yl ? l.w0 : 0.f) + (l.i1 == yl ? l.w1 : 0.f);
+        }
+        swy[ly][k] = w;
+    } else if (tid >= 64 && tid < 64 + UB_TX * 6) {
+        const int t2 = tid - 64, lx = t2 / 6, k = t2 - lx * 6, xl = xl0 + lx, ux = 2 * xl - 2 + k;
+        float w = 0.f;
+        if (ux >= 0 && ux < Wu && ux + px >= 0 && ux + px < Ws) {
+            const Lerp l = lerp_coord(ux, Wl, Wu);
+            w = (l.i0 == xl ? l.w0 : 0.f) + (l.i1 == xl ? l.w1 : 0.f);
+        }
+        swx[lx][k] = w;
+    }
+    constexpr int VPT = 16 / sizeof(T);                            // elements per 16-byte vector
+    constexpr int NVR = UB_CB / VPT;
+    for (int i = tid; i < UB_UY * UB_UX * NVR; i += 256) {
+        const int pix = i / NVR, v = i - pix * NVR, ry = pix / UB_UX, rx = pix - ry * UB_UX;
+        const int uy = uy0 + ry, ux = ux0 + rx, c = c0 + v * VPT;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (uy >= 0 && uy < Hu && ux >= 0 && ux < Wu && uy + py >= 0 && uy + py < Hs && ux + px >= 0 && ux + px < Ws && c < Cl)
+            val = *reinterpret_cast<const uint4*>(dout + (((long long)n * Hs + uy + py) * Ws + ux + px) * ldo + Cs + c);
+        *reinterpret_cast<uint4*>(sg + pix * UB_CB + v * VPT) = val;
+    }
+    __syncthreads();
+    for (int i = tid; i < UB_TY * UB_TX * 4; i += 256) {
+        const int pix = i >> 2, cv = i & 3, ly = pix / UB_TX, lx = pix - ly * UB_TX;
+        const int yl = yl0 + ly, xl = xl0 + lx;
+        if (cv >= nvec || yl >= Hl || xl >= Wl) continue;
+        float acc[8]; zero8(acc);
+        float wyv[6], wxv[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { wyv[k] = swy[ly][k]; wxv[k] = swx[lx][k]; }
+        const T* base = sg + ((2 * ly) * UB_UX + 2 * lx) * UB_CB + cv * 8;     // window row 2*ly + a, column 2*lx + b
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            if (wyv[a] == 0.f) continue;
+#pragma unroll
+            for (int bb = 0; bb < 6; ++bb) {
+                if (wxv[bb] == 0.f) continue;
+                float g[8];
+                load8(base + (a * UB_UX + bb) * UB_CB, g);
+                const float w = wyv[a] * wxv[bb];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += w * g[j];
+            }
+        }
+        store8(dlow + (((long long)n * Hl + yl) * Wl + xl) * ldl + c0 + cv * 8, acc);
+    }
+}
+
 // ---- depthwise 3x3 (+bias) * scale ------------------------------------------------------------------
 template <typename T>
 __global__ void dwconv3_fwd_kernel(const T* __restrict__ x, int ldx, const float* w, const float* b,
@@ -554,6 +629,13 @@ extern "C" int egm_upcat_bwd_low(int dtype, const void* dout, int ldo, void* dlo
     EGM_REQ_VEC("upcat_bwd_low", dlow, ldl, Cl);
     EGM_REQUIRE(N > 0 && Hl > 0 && Wl > 0 && Hs >= 2 * Hl && Ws >= 2 * Wl && Cs % 8 == 0, "upcat_bwd_low: bad shape");
     const long long total = (long long)N * Hl * Wl * (Cl / 8);
+    if (dtype == EGM_BF16 && Hl >= UB_TY && Wl >= UB_TX) {           // LDS-tiled gather (bit-identical); tiny maps keep the direct form
+        const int tiles_y = egm_cdiv(Hl, UB_TY), tiles_x = egm_cdiv(Wl, UB_TX), nchunk = egm_cdiv(Cl, UB_CB);
+        hipLaunchKernelGGL((upcat_bwd_low_tiled_kernel<bf16_t>), dim3((unsigned)((long long)N * tiles_y * tiles_x * nchunk)), dim3(256), 0, (hipStream_t)s,
+                           (const bf16_t*)dout, ldo, (bf16_t*)dlow, ldl, N, Hs, Ws, Cs, Hl, Wl, Cl, tiles_x, tiles_y, nchunk);
+        EGM_CHECK_LAUNCH("upcat_bwd_low");
+        return EGM_OK;
+    }
     EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((upcat_bwd_low_kernel<T>), dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)s,
                                                  (const T*)dout, ldo, (T*)dlow, ldl, N, Hs, Ws, Cs, Hl, Wl, Cl));
     EGM_CHECK_LAUNCH("upcat_bwd_low");

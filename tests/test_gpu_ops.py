@@ -277,7 +277,9 @@ def test_maxpool2(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("shapes", [((2, 16, 10, 12), (2, 16, 20, 24)), ((1, 8, 7, 9), (1, 16, 15, 19))])
+@pytest.mark.parametrize("shapes", [((2, 16, 10, 12), (2, 16, 20, 24)), ((1, 8, 7, 9), (1, 16, 15, 19)),
+                                    # LDS-tiled backward gather (low map >= 8 x 16): ragged tiles, two channel chunks (32 + 8), padded frame
+                                    ((2, 40, 20, 37), (2, 24, 41, 75)), ((1, 64, 32, 32), (1, 32, 64, 64))])
 def test_upcat(dtype, shapes):
     ops = _ops()
     g = torch.Generator().manual_seed(2)
