@@ -40,6 +40,25 @@ def _f32(n, device, zero=False):
     return (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=device)
 
 
+_zero_pools = {}
+
+
+def _zero_grad_vec(n, device):
+    """An all-zero fp32 gradient of n elements for a parameter whose gradient is identically zero (a conv bias in front of a train-mode
+    BatchNorm): a slice of one zero buffer per device, allocated once OUTSIDE any capture, instead of a fill kernel per parameter and
+    step (14 launches per EGM-UNet step).  The slices are read (SGD, bucket gather), scaled or re-zeroed by their users, never
+    accumulated into: such a bias has this one gradient contribution."""
+    pool = _zero_pools.get(device)
+    if pool is None or pool[0].numel() < pool[1] + n:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.zeros(n, dtype=torch.float32, device=device)      # first need arises inside a capture: plain fill this time
+        pool = _zero_pools[device] = [torch.zeros(max(1 << 16, 4 * n), dtype=torch.float32, device=device), 0]
+    # every caller gets its own slice while the pool lasts (wraps around: all slices hold zeros anyway)
+    off = pool[1]
+    pool[1] = off + n if off + 2 * n <= pool[0].numel() else 0
+    return pool[0][off:off + n]
+
+
 # ----------------------------------------------------------------------------------------------------------
 # layout conversion at the module boundary
 # ----------------------------------------------------------------------------------------------------------
@@ -535,7 +554,7 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[3]:
             gw = _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, None, None, weight, dil, groups, Cin, Cout)
         if has_bias and ctx.needs_input_grad[4]:
-            gb = _f32(Cout, x.device, zero=True) if ctx.bias_grad_zero else _channel_sum(gy)[0, :Cout]
+            gb = _zero_grad_vec(Cout, x.device) if ctx.bias_grad_zero else _channel_sum(gy)[0, :Cout]
         return gx, None, None, gw, gb, None, None, None, None
 
 
@@ -615,7 +634,7 @@ class _ConvBN(Function):
             gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=dev)
             L.call("egm_conv_fwd", dt, ptr(dy), CoutP, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
         if has_bias and ctx.needs_input_grad[4]:
-            gb = _f32(Cout, dev, zero=True)             # a conv bias feeding a BatchNorm has an identically zero gradient
+            gb = _zero_grad_vec(Cout, dev)              # a conv bias feeding a BatchNorm has an identically zero gradient
         ggamma = sums[1, :Cout] if ctx.needs_input_grad[5] else None
         gbeta = sums[0, :Cout] if ctx.needs_input_grad[6] else None
         return gx, None, None, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None
@@ -791,7 +810,7 @@ class _MultiConvBN(Function):
             base = 1 + 5 * k
             gx, gw, gb = gxs[k], gws[k], None
             if has_bias and ctx.needs_input_grad[base + 2]:
-                gb = _f32(Cout, x.device, zero=True)
+                gb = _zero_grad_vec(Cout, x.device)
             ggamma = sums[1, :Cout] if ctx.needs_input_grad[base + 3] else None
             gbeta = sums[0, :Cout] if ctx.needs_input_grad[base + 4] else None
             grads += [gx, gw, gb, ggamma, gbeta]
@@ -896,7 +915,7 @@ class _ConvBNEw(Function):
         if ctx.needs_input_grad[2]:
             gw = _conv_wgrad(x, ldx, None, ACT_NONE, dy, CoutP, None, None, weight, 1, 1, Cin, Cout)
         if has_bias and ctx.needs_input_grad[3]:
-            gb = _f32(Cout, dev, zero=True)             # a conv bias feeding a BatchNorm has an identically zero gradient
+            gb = _zero_grad_vec(Cout, dev)              # a conv bias feeding a BatchNorm has an identically zero gradient
         ggamma = sums[1, :Cout] if ctx.needs_input_grad[4] else None
         gbeta = sums[0, :Cout] if ctx.needs_input_grad[5] else None
         return gx, dp if ctx.needs_input_grad[1] else None, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None, None
