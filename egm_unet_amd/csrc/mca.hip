@@ -2,7 +2,8 @@
 //
 //   gates:  for each of the three axes (row h over (C,W); column w over (C,H); channel c over (H,W)):
 //             mean, unbiased std -> o = (0.5+sig(w0))*mean + (0.5+sig(w1))*std -> conv1d(k) along the axis -> sigmoid
-//   x_out = x * (g_h[n,h] + g_w[n,w] + g_c[n,c]) / 3
+//   x_out = x * (g_h[n,h] + g_w[n,w] + g_c[n,c]) / 3          (MCALayer(no_spatial=True), :688-703,766-771: no channel gate, / 2:
+//                                                            the channel gate row is all zeros and the scale argument is 0.5)
 //   out   = 0.4*x_out + 0.2*(max3 - min3)(x_out) + 0.2*avg3((x_out - avg3 x_out)^2) + 0.1*F(x_out) + 0.1*shuffle4(x_out)
 //   F = ifft2(1.1*|fft2 x| * e^{i*angle}) == 1.1*x exactly (scaling the magnitude at unchanged phase), so the two FFTs of
 //   the reference are replaced by the multiply: out = 0.51*x_out + ...  (pinned by tests/golden/mca_c*.npz, which were
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(256) void mca_reduce_h_kernel(const float* __restri
 struct GateParams {
     const float* w[3];      // MCAGate.weight (2 floats) per axis: h_cw, w_hc, c_hw
     const float* k[3];      // conv kernel per axis
-    int ks[3];              // kernel sizes (<= 7)
+    int ks[3];              // kernel sizes (<= 7); ks[2] == 0: no channel gate (no_spatial): its gates are 0, its parameters unread
+    float inv;              // 1/3, or 1/2 without the channel gate
 };
 __device__ __forceinline__ void axis_of(int e, int H, int W, int C, int& ax, int& idx, int& len) {
     const int L = H + W + C, r = e % L;
@@ -119,7 +121,7 @@ __global__ void mca_gates_fwd_kernel(const float* __restrict__ sums, GateParams 
     // expf) per element of a one-workgroup kernel that is pure latency
     __shared__ float sk[3][8], sab[3][2];
     if (threadIdx.x < 24) { const int a = threadIdx.x >> 3, t = threadIdx.x & 7; sk[a][t] = t < gp.ks[a] ? gp.k[a][t] : 0.f; }
-    else if (threadIdx.x >= 32 && threadIdx.x < 38) { const int a = (threadIdx.x - 32) >> 1, j = (threadIdx.x - 32) & 1; sab[a][j] = 0.5f + sigm(gp.w[a][j]); }
+    else if (threadIdx.x >= 32 && threadIdx.x < 38) { const int a = (threadIdx.x - 32) >> 1, j = (threadIdx.x - 32) & 1; sab[a][j] = gp.ks[a] > 0 ? 0.5f + sigm(gp.w[a][j]) : 0.f; }
     __syncthreads();
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         int ax, idx, len; axis_of(e, H, W, C, ax, idx, len);
@@ -138,7 +140,7 @@ __global__ void mca_gates_fwd_kernel(const float* __restrict__ sums, GateParams 
         const int ks = gp.ks[ax], pad = (ks - 1) / 2;
         float z = 0.f;
         for (int t = 0; t < ks; ++t) { const int j = idx + t - pad; if (j >= 0 && j < len) z += sk[ax][t] * o[e - idx + j]; }
-        gates[e] = sigm(z);
+        gates[e] = ks > 0 ? sigm(z) : 0.f;                         // absent axis (no_spatial): contributes nothing to x * (sum of gates)
     }
 }
 // dG [N][L][2] (slot 0 = sum over the slice of dx_out*x) -> coef [N][L][2] (A, B), dwts [3][2], dks [3][8]; dz scratch [N][L]
@@ -148,8 +150,8 @@ __global__ void mca_gates_bwd_kernel(const float* __restrict__ dG, const float* 
     const int L = H + W + C, total = N * L;
     __shared__ float sk[3][8], sab[3][2];                           // gate parameters once into LDS (see mca_gates_fwd_kernel)
     if (threadIdx.x < 24) { const int a = threadIdx.x >> 3, t = threadIdx.x & 7; sk[a][t] = t < gp.ks[a] ? gp.k[a][t] : 0.f; }
-    else if (threadIdx.x >= 32 && threadIdx.x < 38) { const int a = (threadIdx.x - 32) >> 1, j = (threadIdx.x - 32) & 1; sab[a][j] = 0.5f + sigm(gp.w[a][j]); }
-    for (int e = threadIdx.x; e < total; e += blockDim.x) dz[e] = dG[e * 2] * (1.f / 3.f) * gates[e] * (1.f - gates[e]);
+    else if (threadIdx.x >= 32 && threadIdx.x < 38) { const int a = (threadIdx.x - 32) >> 1, j = (threadIdx.x - 32) & 1; sab[a][j] = gp.ks[a] > 0 ? 0.5f + sigm(gp.w[a][j]) : 0.f; }
+    for (int e = threadIdx.x; e < total; e += blockDim.x) dz[e] = dG[e * 2] * gp.inv * gates[e] * (1.f - gates[e]);   // absent axis: gates = 0 -> dz = 0
     __syncthreads();
     // per-thread partials of everything that is summed over the entries: d(alpha), d(beta) per axis and the <= 7 kernel taps
     // per axis (dk[a][t] = sum_e dz[e] * o[e + t - pad]); one LDS reduction at the end instead of one per scalar
@@ -189,7 +191,7 @@ __global__ void mca_gates_bwd_kernel(const float* __restrict__ dG, const float* 
         for (int w = 0; w < nw; ++w) v += part[w][threadIdx.x];
         const int i = threadIdx.x;
         if (i < 6) {
-            const float sg = sigm(gp.w[i >> 1][i & 1]);
+            const float sg = gp.ks[i >> 1] > 0 ? sigm(gp.w[i >> 1][i & 1]) : 0.f;
             dwts[i] = v * sg * (1.f - sg);
         } else {
             const int a = (i - 6) / 7, t = (i - 6) % 7;
@@ -201,7 +203,7 @@ __global__ void mca_gates_bwd_kernel(const float* __restrict__ dG, const float* 
 // ---- x_out = x * (g_h + g_w + g_c)/3 -------------------------------------------------------------------------------
 template <typename T>
 __global__ void mca_xout_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ gates, T* __restrict__ xo, int ldo, int N, int H,
-                                int W, int C) {
+                                int W, int C, float inv) {
     const int ncv = C >> 3, L = H + W + C;
     const long long total = (long long)N * H * W * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -212,7 +214,7 @@ __global__ void mca_xout_kernel(const T* __restrict__ x, int ldx, const float* _
         float v[8];
         load8(x + p * ldx + cv * 8, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= (ghw + g[H + W + cv * 8 + j]) * (1.f / 3.f);
+        for (int j = 0; j < 8; ++j) v[j] *= (ghw + g[H + W + cv * 8 + j]) * inv;
         store8(xo + p * ldo + cv * 8, v);
     }
 }
@@ -304,7 +306,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void mca_fused_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ gates,
                                                             T* __restrict__ xo, int ldxo, T* __restrict__ out, int ldo,
                                                             unsigned char* __restrict__ codes, int N, int H, int W, int C, int tiles_x,
-                                                            int tiles_y, int nchunk) {
+                                                            int tiles_y, int nchunk, float inv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mf_smem[];
     T* sxo = reinterpret_cast<T*>(mf_smem);                         // [PY*PX][CB]
     T* su2 = sxo + MF_PY * MF_PX * MF_CB;                           // [UY*UX][CB]
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(256) void mca_fused_fwd_kernel(const T* __restrict_
             else load8(x + p * ldx + c0 + v * 8, val);
             const float ghw = sgh[py] + sgw[px];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) val[j] = to_f32(from_f32<T>(val[j] * ((ghw + gc8[j]) * (1.f / 3.f))));
+            for (int j = 0; j < 8; ++j) val[j] = to_f32(from_f32<T>(val[j] * ((ghw + gc8[j]) * inv)));
             if (xo != nullptr && py >= 2 && py < MF_TY + 2 && px >= 2 && px < MF_TX + 2) store8(xo + p * ldxo + c0 + v * 8, val);
         }
         store8(sxo + pix * MF_CB + v * 8, val);
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256) void mca_fused_fwd_kernel(const T* __restrict_
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float sh = to_f32(from_f32<T>(to_f32(shv[k][j]) * ((ghw + gs8[j]) * (1.f / 3.f))));
+            const float sh = to_f32(from_f32<T>(to_f32(shv[k][j]) * ((ghw + gs8[j]) * inv)));
             const float o1 = to_f32(from_f32<T>(0.51f * c[j] + 0.2f * (mx[j] - mn[j]) + 0.1f * sh));
             o[j] = o1 + 0.2f * s2[j] * (1.f / 9.f);
         }
@@ -532,7 +534,7 @@ __global__ void mca_bwd_dxo_kernel(const unsigned char* __restrict__ codes, cons
 // dx = dxo*(g_h+g_w+g_c)/3 + sum_axes (A + B*x)
 template <typename T>
 __global__ void mca_bwd_dx_kernel(const T* __restrict__ dxo, int ldd, const T* __restrict__ x, int ldx, const float* __restrict__ gates,
-                                  const float* __restrict__ coef, T* __restrict__ dx, int ldo, int N, int H, int W, int C) {
+                                  const float* __restrict__ coef, T* __restrict__ dx, int ldo, int N, int H, int W, int C, float inv) {
     const int ncv = C >> 3, L = H + W + C;
     const long long total = (long long)N * H * W * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -547,7 +549,7 @@ __global__ void mca_bwd_dx_kernel(const T* __restrict__ dxo, int ldd, const T* _
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = H + W + cv * 8 + j;
-            d[j] = d[j] * (ghw + g[c]) * (1.f / 3.f) + (A0 + cf[c * 2]) + (B0 + cf[c * 2 + 1]) * v[j];
+            d[j] = d[j] * (ghw + g[c]) * inv + (A0 + cf[c * 2]) + (B0 + cf[c * 2 + 1]) * v[j];
         }
         store8(dx + p * ldo + cv * 8, d);
     }
@@ -590,9 +592,11 @@ extern "C" int egm_mca_reduce(int dtype, int mode, const void* a, int lda, const
 
 static int gate_params(GateParams& gp, const float* w_h, const float* k_h, int ks_h, const float* w_w, const float* k_w, int ks_w,
                        const float* w_c, const float* k_c, int ks_c) {
-    if (!w_h || !k_h || !w_w || !k_w || !w_c || !k_c) return 0;
-    if (ks_h < 1 || ks_h > 7 || ks_w < 1 || ks_w > 7 || ks_c < 1 || ks_c > 7 || !(ks_h & 1) || !(ks_w & 1) || !(ks_c & 1)) return 0;
+    // ks_c == 0: MCALayer(no_spatial=True) -- no c_hw gate; its gate row is written as zeros and w_c / k_c are not read
+    if (!w_h || !k_h || !w_w || !k_w || (ks_c != 0 && (!w_c || !k_c))) return 0;
+    if (ks_h < 1 || ks_h > 7 || ks_w < 1 || ks_w > 7 || ks_c < 0 || ks_c > 7 || !(ks_h & 1) || !(ks_w & 1) || (ks_c != 0 && !(ks_c & 1))) return 0;
     gp.w[0] = w_h; gp.w[1] = w_w; gp.w[2] = w_c; gp.k[0] = k_h; gp.k[1] = k_w; gp.k[2] = k_c; gp.ks[0] = ks_h; gp.ks[1] = ks_w; gp.ks[2] = ks_c;
+    gp.inv = ks_c != 0 ? 1.f / 3.f : 0.5f;
     return 1;
 }
 extern "C" int egm_mca_gates_fwd(const float* sums, const float* w_h, const float* k_h, int ks_h, const float* w_w, const float* k_w,
@@ -619,11 +623,12 @@ extern "C" int egm_mca_gates_bwd(const float* dG, const float* stats, const floa
     return EGM_OK;
 }
 extern "C" int egm_mca_xout(int dtype, const void* x, int ldx, const float* gates, void* xo, int ldo, int N, int H, int W, int C,
-                            egm_stream_t s) {
+                            int no_spatial, egm_stream_t s) {
+    const float inv = no_spatial ? 0.5f : 1.f / 3.f;
     EGM_REQ_VEC("mca_xout", x, ldx, C); EGM_REQ_VEC("mca_xout", xo, ldo, C); EGM_REQ_SHAPE("mca_xout");
     EGM_REQUIRE(gates, "mca_xout: null gates");
     EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((mca_xout_kernel<T>), dim3(EGM_MCA_GRID), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, gates,
-                                                 (T*)xo, ldo, N, H, W, C));
+                                                 (T*)xo, ldo, N, H, W, C, inv));
     EGM_CHECK_LAUNCH("mca_xout");
     return EGM_OK;
 }
@@ -647,7 +652,7 @@ extern "C" int egm_add_avg3(int dtype, const void* a, int lda, const void* b, in
 }
 template <typename T>
 static int launch_mca_fused(const void* x, int ldx, const float* gates, void* xo, int ldxo, void* out, int ldo, unsigned char* codes, int N, int H,
-                            int W, int C, hipStream_t st) {
+                            int W, int C, float inv, hipStream_t st) {
     const size_t smem = (size_t)(MF_PY * MF_PX + MF_UY * MF_UX) * MF_CB * sizeof(T);
     static bool attr_done = false;
     if (!attr_done) {
@@ -660,17 +665,18 @@ static int launch_mca_fused(const void* x, int ldx, const float* gates, void* xo
     const long long grid = (long long)N * tiles_x * tiles_y * nchunk;
     EGM_REQUIRE(grid < (1LL << 31), "mca_fused_fwd: grid too large");
     hipLaunchKernelGGL((mca_fused_fwd_kernel<T>), dim3((unsigned)grid), dim3(256), smem, st, (const T*)x, ldx, gates, (T*)xo, ldxo, (T*)out, ldo,
-                       codes, N, H, W, C, tiles_x, tiles_y, nchunk);
+                       codes, N, H, W, C, tiles_x, tiles_y, nchunk, inv);
     EGM_CHECK_LAUNCH("mca_fused_fwd");
     return EGM_OK;
 }
 extern "C" int egm_mca_fused_fwd(int dtype, const void* x, int ldx, const float* gates, void* xo, int ldxo, void* out, int ldo,
-                                 unsigned char* codes, int N, int H, int W, int C, egm_stream_t s) {
+                                 unsigned char* codes, int N, int H, int W, int C, int no_spatial, egm_stream_t s) {
+    const float inv = no_spatial ? 0.5f : 1.f / 3.f;
     EGM_REQ_VEC("mca_fused_fwd", x, ldx, C); EGM_REQ_VEC("mca_fused_fwd", out, ldo, C); EGM_REQ_SHAPE("mca_fused_fwd");
     if (xo != nullptr) EGM_REQ_VEC("mca_fused_fwd", xo, ldxo, C);
     EGM_REQUIRE(gates && C % 4 == 0 && (codes == nullptr || (reinterpret_cast<uintptr_t>(codes) & 7) == 0), "mca_fused_fwd: bad gates / codes buffer");
-    if (dtype == EGM_BF16) return launch_mca_fused<bf16_t>(x, ldx, gates, xo, ldxo, out, ldo, codes, N, H, W, C, (hipStream_t)s);
-    if (dtype == EGM_F32) return launch_mca_fused<float>(x, ldx, gates, xo, ldxo, out, ldo, codes, N, H, W, C, (hipStream_t)s);
+    if (dtype == EGM_BF16) return launch_mca_fused<bf16_t>(x, ldx, gates, xo, ldxo, out, ldo, codes, N, H, W, C, inv, (hipStream_t)s);
+    if (dtype == EGM_F32) return launch_mca_fused<float>(x, ldx, gates, xo, ldxo, out, ldo, codes, N, H, W, C, inv, (hipStream_t)s);
     EGM_FAIL(EGM_ERR_ARG, "mca_fused_fwd: unknown dtype %d", dtype);
 }
 extern "C" int egm_mca_bwd_du(int dtype, const void* xo, int ld, const void* g, int ldg, void* du, int ldd, int N, int H, int W, int C,
@@ -692,12 +698,13 @@ extern "C" int egm_mca_bwd_dxo(int dtype, const unsigned char* codes, const void
     return EGM_OK;
 }
 extern "C" int egm_mca_bwd_dx(int dtype, const void* dxo, int ldd, const void* x, int ldx, const float* gates, const float* coef, void* dx,
-                              int ldo, int N, int H, int W, int C, egm_stream_t s) {
+                              int ldo, int N, int H, int W, int C, int no_spatial, egm_stream_t s) {
+    const float inv = no_spatial ? 0.5f : 1.f / 3.f;
     EGM_REQ_VEC("mca_bwd_dx", dxo, ldd, C); EGM_REQ_VEC("mca_bwd_dx", x, ldx, C); EGM_REQ_VEC("mca_bwd_dx", dx, ldo, C);
     EGM_REQ_SHAPE("mca_bwd_dx");
     EGM_REQUIRE(gates && coef, "mca_bwd_dx: null pointer");
     EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((mca_bwd_dx_kernel<T>), dim3(EGM_MCA_GRID), dim3(256), 0, (hipStream_t)s, (const T*)dxo, ldd,
-                                                 (const T*)x, ldx, gates, coef, (T*)dx, ldo, N, H, W, C));
+                                                 (const T*)x, ldx, gates, coef, (T*)dx, ldo, N, H, W, C, inv));
     EGM_CHECK_LAUNCH("mca_bwd_dx");
     return EGM_OK;
 }

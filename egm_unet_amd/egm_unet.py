@@ -37,15 +37,14 @@ class MCAGate(nn.Module):
 class MCALayer(nn.Module):
     def __init__(self, inp, no_spatial=False):
         super().__init__()
-        if no_spatial:
-            raise NotImplementedError("egm_unet_amd: MCALayer(no_spatial=True) is not used by EGM-UNet")
         self.no_spatial = no_spatial
         self.inp = inp
         temp = round(abs((math.log2(inp) - 1) / 1.5))
         kernel = temp if temp % 2 else temp - 1
         self.h_cw = MCAGate(3)
         self.w_hc = MCAGate(3)
-        self.c_hw = MCAGate(kernel)
+        if not no_spatial:                                                      # :700-703: without it, x_out = (x_h + x_w) / 2
+            self.c_hw = MCAGate(kernel)
 
     def forward(self, x):
         return ops.mca_layer(x, self, self.training and torch.is_grad_enabled())

@@ -1907,6 +1907,8 @@ def ela(x, conv, gn):
 # MCALayer
 # ----------------------------------------------------------------------------------------------------------
 class _MCALayer(Function):
+    """wc / kc None: MCALayer(no_spatial=True) -- two gates, x_out = x*(g_h+g_w)/2 (src/EGM-UNet.py:766-771)"""
+
     @staticmethod
     def forward(ctx, x, wh, kh, ww, kw, wc, kc, training):
         x, ldx = _nhwc(x)
@@ -1917,15 +1919,17 @@ class _MCALayer(Function):
         sums = _f32((N, Lax, 2), dev)
         L.call("egm_mca_reduce", dt, 0, ptr(x), ldx, None, 0, ptr(sums), ptr(ws), N, H, W, C, st)
         stats, o, gates = _f32((N, Lax, 2), dev), _f32((N, Lax), dev), _f32((N, Lax), dev)
-        ps = [t.detach().contiguous() for t in (wh, kh, ww, kw, wc, kc)]
-        ks = (kh.numel(), kw.numel(), kc.numel())
-        L.call("egm_mca_gates_fwd", ptr(sums), ptr(ps[0]), ptr(ps[1]), ks[0], ptr(ps[2]), ptr(ps[3]), ks[1], ptr(ps[4]), ptr(ps[5]), ks[2],
+        ps = [t.detach().contiguous() for t in (wh, kh, ww, kw, wc, kc) if t is not None]
+        ns = int(wc is None)
+        ks = (kh.numel(), kw.numel(), 0 if ns else kc.numel())
+        pc = (None, None) if ns else (ptr(ps[4]), ptr(ps[5]))
+        L.call("egm_mca_gates_fwd", ptr(sums), ptr(ps[0]), ptr(ps[1]), ks[0], ptr(ps[2]), ptr(ps[3]), ks[1], pc[0], pc[1], ks[2],
                ptr(stats), ptr(o), ptr(gates), N, H, W, C, st)
         # x_out = x * gate, the 3x3 stencils (range, squared high-pass, its average), the channel shuffle and the sum: one fused pass
         xo = torch.empty((N, H, W, C), dtype=x.dtype, device=dev) if training else None
         codes = torch.empty((N, H, W, C), dtype=torch.uint8, device=dev) if training else None
         out = torch.empty((N, H, W, C), dtype=x.dtype, device=dev)
-        L.call("egm_mca_fused_fwd", dt, ptr(x), ldx, ptr(gates), ptr(xo), C, ptr(out), C, ptr(codes), N, H, W, C, st)
+        L.call("egm_mca_fused_fwd", dt, ptr(x), ldx, ptr(gates), ptr(xo), C, ptr(out), C, ptr(codes), N, H, W, C, ns, st)
         if training:
             ctx.save_for_backward(x, xo, codes, stats, o, gates, *ps)
             ctx.ks = ks
@@ -1933,8 +1937,9 @@ class _MCALayer(Function):
 
     @staticmethod
     def backward(ctx, g):
-        x, xo, codes, stats, o, gates, wh, kh, ww, kw, wc, kc = ctx.saved_tensors
+        x, xo, codes, stats, o, gates, wh, kh, ww, kw, *pc = ctx.saved_tensors
         ks = ctx.ks
+        ns = int(not pc)
         x, ldx = _nhwc(x); g, ldg = _nhwc(g)
         N, H, W, C = x.shape
         L, dt, st, dev = lib(), dtype_code(x.dtype), stream(), x.device
@@ -1950,18 +1955,21 @@ class _MCALayer(Function):
         coef = _f32((N, Lax, 2), dev)
         dwts = _f32((3, 2), dev)
         dks = _f32((3, 8), dev, zero=True)
-        L.call("egm_mca_gates_bwd", ptr(dG), ptr(stats), ptr(o), ptr(gates), ptr(wh), ptr(kh), ks[0], ptr(ww), ptr(kw), ks[1], ptr(wc), ptr(kc),
-               ks[2], ptr(dz), ptr(coef), ptr(dwts), ptr(dks), N, H, W, C, st)
+        L.call("egm_mca_gates_bwd", ptr(dG), ptr(stats), ptr(o), ptr(gates), ptr(wh), ptr(kh), ks[0], ptr(ww), ptr(kw), ks[1],
+               None if ns else ptr(pc[0]), None if ns else ptr(pc[1]), ks[2], ptr(dz), ptr(coef), ptr(dwts), ptr(dks), N, H, W, C, st)
         dx = torch.empty((N, H, W, C), dtype=x.dtype, device=dev)
-        L.call("egm_mca_bwd_dx", dt, ptr(dxo), C, ptr(x), ldx, ptr(gates), ptr(coef), ptr(dx), C, N, H, W, C, st)
-        gk = [dks[a, :ks[a]].reshape(1, 1, 1, ks[a]) for a in range(3)]
+        L.call("egm_mca_bwd_dx", dt, ptr(dxo), C, ptr(x), ldx, ptr(gates), ptr(coef), ptr(dx), C, N, H, W, C, ns, st)
+        gk = [dks[a, :ks[a]].reshape(1, 1, 1, ks[a]) for a in range(2 if ns else 3)]
+        if ns:
+            return dx, dwts[0], gk[0], dwts[1], gk[1], None, None, None
         return dx, dwts[0], gk[0], dwts[1], gk[1], dwts[2], gk[2], None
 
 
 def mca_layer(x, layer, training):
-    """layer: an MCALayer parameter holder with gates h_cw, w_hc, c_hw (each: .weight [2], .conv.weight [1,1,1,k])."""
-    return _MCALayer.apply(x, layer.h_cw.weight, layer.h_cw.conv.weight, layer.w_hc.weight, layer.w_hc.conv.weight,
-                           layer.c_hw.weight, layer.c_hw.conv.weight, training)
+    """layer: an MCALayer parameter holder with gates h_cw, w_hc and -- unless layer.no_spatial -- c_hw
+    (each: .weight [2], .conv.weight [1,1,1,k])."""
+    c = (None, None) if layer.no_spatial else (layer.c_hw.weight, layer.c_hw.conv.weight)
+    return _MCALayer.apply(x, layer.h_cw.weight, layer.h_cw.conv.weight, layer.w_hc.weight, layer.w_hc.conv.weight, c[0], c[1], training)
 
 
 class _SAConv7(Function):

@@ -343,7 +343,9 @@ long long egm_mca_reduce_workspace(int N, int H, int W, int C);
 int egm_mca_reduce(int dtype, int mode, const void* a, int lda, const void* b, int ldb, float* sums, void* workspace, int N,
                    int H, int W, int C, egm_stream_t s);
 /* sums -> stats [N][L][2] (mean, unbiased std), o [N][L] (pre-conv gate input), gates [N][L] (sigmoid outputs); L=H+W+C.
- * w_*: MCAGate.weight (2 floats); k_*: the 1 x ks conv kernel of each gate (h_cw, w_hc, c_hw). */
+ * w_*: MCAGate.weight (2 floats); k_*: the 1 x ks conv kernel of each gate (h_cw, w_hc, c_hw).
+ * ks_c == 0 is MCALayer(no_spatial=True) (src/EGM-UNet.py:700-703,766-771): there is no c_hw gate, w_c / k_c may be NULL, the channel
+ * rows of `gates` are written as zeros (so x*(g_h+g_w+g_c) is x*(g_h+g_w)) and, in the backward, their coef / dwts / dks rows are zeros. */
 int egm_mca_gates_fwd(const float* sums, const float* w_h, const float* k_h, int ks_h, const float* w_w, const float* k_w,
                       int ks_w, const float* w_c, const float* k_c, int ks_c, float* stats, float* o, float* gates, int N, int H,
                       int W, int C, egm_stream_t s);
@@ -352,9 +354,9 @@ int egm_mca_gates_fwd(const float* sums, const float* w_h, const float* k_h, int
 int egm_mca_gates_bwd(const float* dG, const float* stats, const float* o, const float* gates, const float* w_h, const float* k_h,
                       int ks_h, const float* w_w, const float* k_w, int ks_w, const float* w_c, const float* k_c, int ks_c,
                       float* dz_scratch, float* coef, float* dwts, float* dks, int N, int H, int W, int C, egm_stream_t s);
-/* x_out = x*(g_h+g_w+g_c)/3 */
+/* x_out = x*(g_h+g_w+g_c)/3; no_spatial != 0: x*(g_h+g_w)/2 (gates from egm_mca_gates_fwd with ks_c == 0) */
 int egm_mca_xout(int dtype, const void* x, int ldx, const float* gates, void* xo, int ldo, int N, int H, int W, int C,
-                 egm_stream_t s);
+                 int no_spatial, egm_stream_t s);
 /* r1 = 0.51*xo + 0.2*(max3-min3)(xo) + 0.1*shuffle4(xo); u2 = (xo - avg3 xo)^2; codes (optional, N*H*W*C bytes) = window
  * positions of the first max / first min, for the backward.  Then out = r1 + 0.2*avg3(u2) via egm_add_avg3. */
 int egm_mca_stencil1(int dtype, const void* xo, int ld, void* r1, int ldr, void* u2, int ldu, unsigned char* codes, int N, int H,
@@ -365,15 +367,15 @@ int egm_add_avg3(int dtype, const void* a, int lda, const void* b, int ldb, floa
  * of 32-channel chunks staged through LDS.  xo may be NULL (the backward recomputes x_out = x * gate).  Same arithmetic, rounding points
  * and summation order as egm_mca_xout + egm_mca_stencil1 + egm_add_avg3. */
 int egm_mca_fused_fwd(int dtype, const void* x, int ldx, const float* gates, void* xo, int ldxo, void* out, int ldo, unsigned char* codes,
-                      int N, int H, int W, int C, egm_stream_t s);
+                      int N, int H, int W, int C, int no_spatial, egm_stream_t s);
 /* backward chain: du = 0.4*(xo - avg3 xo)*avg3(g); dxo = 0.51 g + 0.1 unshuffle(g) + du - avg3(du) + 0.2*range_bwd(codes, g);
- * dx = dxo*(g_h+g_w+g_c)/3 + sum_axes(A + B*x) */
+ * dx = dxo*(g_h+g_w+g_c)/3 + sum_axes(A + B*x)   (no_spatial != 0: /2, as in the forward) */
 int egm_mca_bwd_du(int dtype, const void* xo, int ld, const void* g, int ldg, void* du, int ldd, int N, int H, int W, int C,
                    egm_stream_t s);
 int egm_mca_bwd_dxo(int dtype, const unsigned char* codes, const void* g, int ldg, const void* du, int ldd, void* dxo, int ldo,
                     int N, int H, int W, int C, egm_stream_t s);
 int egm_mca_bwd_dx(int dtype, const void* dxo, int ldd, const void* x, int ldx, const float* gates, const float* coef, void* dx,
-                   int ldo, int N, int H, int W, int C, egm_stream_t s);
+                   int ldo, int N, int H, int W, int C, int no_spatial, egm_stream_t s);
 
 /* ---- CLIP ViT / CLIPSeg inference path (clip/model.py:159-206,487-501; models/clipseg.py:79-133,188-256,436-496) --------
  * Activations are row-major [rows, D] token matrices (batch-first), bf16 or fp32; scores and statistics are fp32. */

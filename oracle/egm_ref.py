@@ -87,13 +87,17 @@ def _mca_gate(state: State, p: str, mean, std):
     return torch.sigmoid(o[:, 0, :])
 
 
-def mca_layer(state: State, p: str, x, fft_exact: bool = False):
+def mca_layer(state: State, p: str, x, fft_exact: bool = False, no_spatial: bool = False):
+    """no_spatial (:700-703, :766-771): the layer has no c_hw gate and x_out is the mean of the other two."""
     B, C, H, W = x.shape
     # per-row (h) statistics over (C, W); per-column (w) over (C, H); per-channel over (H, W)
     g_h = _mca_gate(state, p + ".h_cw", x.mean(dim=(1, 3)), x.permute(0, 2, 1, 3).reshape(B, H, -1).std(dim=2))
     g_w = _mca_gate(state, p + ".w_hc", x.mean(dim=(1, 2)), x.permute(0, 3, 1, 2).reshape(B, W, -1).std(dim=2))
-    g_c = _mca_gate(state, p + ".c_hw", x.mean(dim=(2, 3)), x.reshape(B, C, -1).std(dim=2))
-    x_out = (1.0 / 3.0) * (x * g_c[:, :, None, None] + x * g_h[:, None, :, None] + x * g_w[:, None, None, :])
+    if no_spatial:
+        x_out = (1.0 / 2.0) * (x * g_h[:, None, :, None] + x * g_w[:, None, None, :])
+    else:
+        g_c = _mca_gate(state, p + ".c_hw", x.mean(dim=(2, 3)), x.reshape(B, C, -1).std(dim=2))
+        x_out = (1.0 / 3.0) * (x * g_c[:, :, None, None] + x * g_h[:, None, :, None] + x * g_w[:, None, None, :])
     # parameter-free enhancements (:774-789)
     rng = F.max_pool2d(x_out, 3, 1, 1) - (-F.max_pool2d(-x_out, 3, 1, 1))
     mean3 = F.avg_pool2d(x_out, 3, 1, 1)

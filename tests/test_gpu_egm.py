@@ -23,6 +23,18 @@ def test_mca_layer_fixture(c):
     run_block(m, fx, 1, grad_tol=GT)
 
 
+@pytest.mark.parametrize("c", [16, 64])
+def test_mca_layer_no_spatial_fixture(c):
+    """MCALayer(c, no_spatial=True) (src/EGM-UNet.py:700-703,766-771): two gates, x*(g_h+g_w)/2, no c_hw parameters; forward, dx and the
+    four parameter gradients against the reference's own fixture (tools/make_golden_mca_nospatial.py)."""
+    from egm_unet_amd.egm_unet import MCALayer
+    fx = load_fixture(f"mca_nospatial_c{c}")
+    m = MCALayer(c, no_spatial=True)
+    assert not hasattr(m, "c_hw") and len(list(m.parameters())) == 4
+    load_module_state(m, fx)
+    run_block(m, fx, 1, grad_tol=GT)
+
+
 def test_edge_gate_fixture():
     from egm_unet_amd.egm_unet import EdgeAwareFeatureEnhancer
     fx = load_fixture("edge_gate")

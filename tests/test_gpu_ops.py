@@ -303,7 +303,8 @@ def test_upcat(dtype, shapes):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 37, 29, 24), (1, 64, 48, 64), (2, 16, 16, 8)], ids=["ragged_c24", "c64", "one_tile_c8"])
-def test_mca_fused_tail_equals_the_three_kernels(dtype, shape):
+@pytest.mark.parametrize("ns", [0, 1], ids=["three_gates", "no_spatial"])
+def test_mca_fused_tail_equals_the_three_kernels(dtype, shape, ns):
     """egm_mca_fused_fwd against egm_mca_xout + egm_mca_stencil1 + egm_add_avg3 on the same x and gates: x_out and the arg codes
     bit-exact, out equal up to the last bit of the storage type (same rounding points; only FMA contraction may differ), including
     ragged tiles (H, W not multiples of 16) and a partial 32-channel chunk.  Also the in-place upsample path against the copy path."""
@@ -311,16 +312,19 @@ def test_mca_fused_tail_equals_the_three_kernels(dtype, shape):
     N, H, W, C = shape
     g = torch.Generator().manual_seed(sum(shape))
     x = torch.randn(N, H, W, C, generator=g).to(DEV).to(dtype)
-    gates = torch.rand(N, H + W + C, generator=g).to(DEV)
+    gates = torch.rand(N, H + W + C, generator=g)
+    if ns:
+        gates[:, H + W:] = 0                                  # what egm_mca_gates_fwd writes for ks_c == 0
+    gates = gates.to(DEV)
     L, dt, st = lib(), dtype_code(dtype), stream()
     xo_a, r1, u2, out_a = (torch.empty_like(x) for _ in range(4))
     codes_a = torch.empty((N, H, W, C), dtype=torch.uint8, device=DEV)
-    L.call("egm_mca_xout", dt, ptr(x), C, ptr(gates), ptr(xo_a), C, N, H, W, C, st)
+    L.call("egm_mca_xout", dt, ptr(x), C, ptr(gates), ptr(xo_a), C, N, H, W, C, ns, st)
     L.call("egm_mca_stencil1", dt, ptr(xo_a), C, ptr(r1), C, ptr(u2), C, ptr(codes_a), N, H, W, C, st)
     L.call("egm_add_avg3", dt, ptr(r1), C, ptr(u2), C, 0.2, ptr(out_a), C, N, H, W, C, st)
     xo_b, out_b = torch.empty_like(x), torch.empty_like(x)
     codes_b = torch.empty_like(codes_a)
-    L.call("egm_mca_fused_fwd", dt, ptr(x), C, ptr(gates), ptr(xo_b), C, ptr(out_b), C, ptr(codes_b), N, H, W, C, st)
+    L.call("egm_mca_fused_fwd", dt, ptr(x), C, ptr(gates), ptr(xo_b), C, ptr(out_b), C, ptr(codes_b), N, H, W, C, ns, st)
     torch.cuda.synchronize()
     assert torch.equal(xo_a, xo_b)
     assert torch.equal(codes_a, codes_b)
@@ -330,7 +334,7 @@ def test_mca_fused_tail_equals_the_three_kernels(dtype, shape):
     assert float((diff > 0).float().mean()) < 0.02          # at most a stray last-bit difference here and there
     # x_out may be dropped (inference)
     out_c = torch.empty_like(x)
-    L.call("egm_mca_fused_fwd", dt, ptr(x), C, ptr(gates), None, C, ptr(out_c), C, None, N, H, W, C, st)
+    L.call("egm_mca_fused_fwd", dt, ptr(x), C, ptr(gates), None, C, ptr(out_c), C, None, N, H, W, C, ns, st)
     torch.cuda.synchronize()
     assert torch.equal(out_b, out_c)
 

@@ -59,6 +59,13 @@ def test_mca_layer_fft_identity(c):
     _run_block(f"mca_c{c}", lambda st, x: R.mca_layer(st, "m", x, fft_exact=True))
 
 
+@pytest.mark.parametrize("c", [16, 64])
+def test_mca_layer_no_spatial(c):
+    # reference MCALayer(c, no_spatial=True): two gates, no c_hw parameters (tools/make_golden_mca_nospatial.py)
+    _run_block(f"mca_nospatial_c{c}", lambda st, x: R.mca_layer(st, "m", x, no_spatial=True))
+    _run_block(f"mca_nospatial_c{c}", lambda st, x: R.mca_layer(st, "m", x, fft_exact=True, no_spatial=True))
+
+
 def test_edge_gate():
     _run_block("edge_gate", lambda st, x: R.edge_gate(st, "m", x, True))
 
