@@ -49,6 +49,10 @@ int egm_conv_wreg_launch(const void* x, int ldx, const void* wf, const float* bi
                          int W, int Cin, int Cout, int G, egm_stream_t s);
 int egm_conv_tile_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, float* stats, int N, int H,
                          int W, int Cin, int Cout, int cfg, int nct, int G, egm_stream_t s);
+// conv7x7_c16.hip: weights-in-registers 7x7 kernel for 16 -> 16 channels (FusionConv's merged multi-scale conv at the 64-channel level)
+int egm_conv_c7_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
+int egm_conv_c7_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, int N, int H, int W,
+                       egm_stream_t s);
 
 namespace {
 
@@ -811,13 +815,16 @@ int launch_pipe(ConvParams& p, int G, hipStream_t st) {
 }
 
 // One place decides kernel, tile shape and grouping, so the stats-tile count the caller allocates always matches the launch.
-struct ConvPlan { bool pipe, direct, tile, wreg; int tile_cfg; int R, NT, tiles_y, tiles_x, npt, nct, G; size_t smem; };
+struct ConvPlan { bool pipe, direct, tile, wreg, c7; int tile_cfg; int R, NT, tiles_y, tiles_x, npt, nct, G; size_t smem; };
 ConvPlan conv_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int pre_mode = EGM_PRE_NONE) {
     ConvPlan c;
     if (KH == 1 && KW == 1) dil = 1;
     // prologues the fast kernels are not built with (the BatchNorm-backward form; anything in front of a 7x7) take the generic kernel
     const bool fast_ok = pre_mode == EGM_PRE_NONE || (pre_mode == EGM_PRE_BN_ACT && KH != 7);
     c.tile_cfg = 0;
+    // taken at launch when no BatchNorm statistics are asked for (the kernel has no statistics epilogue); the rest of the plan stays
+    // that of the generic kernel, so a caller's statistics-tile count does not depend on it
+    c.c7 = pre_mode == EGM_PRE_NONE && !egm_group_recording() && egm_conv_c7_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil) != 0;
     c.wreg = pre_mode == EGM_PRE_NONE && egm_conv_wreg_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.G) != 0;
     if (c.wreg) { c.pipe = c.direct = c.tile = false; c.R = 2; c.NT = 1; c.nct = 1; c.tiles_y = c.tiles_x = c.npt = 0; c.smem = 0; return c; }
     c.tile = pre_mode == EGM_PRE_NONE && egm_conv_tile_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.tile_cfg, &c.nct, &c.G) != 0;
@@ -857,7 +864,8 @@ extern "C" int egm_conv_kernel_name(int dtype, int pre_mode, int N, int H, int W
     const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, pre_mode);
     char tmp[96];
     const int pre = pre_mode == EGM_PRE_NONE ? 0 : 1;
-    if (c.wreg) snprintf(tmp, sizeof(tmp), "%s", egm_conv_wreg_name(Cin));
+    if (c.c7) snprintf(tmp, sizeof(tmp), "conv7x7_c16_kernel");
+    else if (c.wreg) snprintf(tmp, sizeof(tmp), "%s", egm_conv_wreg_name(Cin));
     else if (c.tile) snprintf(tmp, sizeof(tmp), "%s", egm_conv_tile_name(c.tile_cfg));
     else if (c.direct) snprintf(tmp, sizeof(tmp), "conv_direct_kernel<%d, %d, %s>", c.NT, pre, KH == 1 ? "true" : "false");
     else if (c.pipe) snprintf(tmp, sizeof(tmp), "conv_igemm_pipe_kernel<%d, %d, %d, %d, %d>", c.NT, (KH == 3 && dil == 1) ? 3 : 1,
@@ -927,6 +935,7 @@ extern "C" int egm_conv_fwd_pre(int dtype, const void* x, int ldx, int pre_mode,
     p.wl = egm_w_layout(dtype, KH, KW, Cin, Cout);
     p.pre.mode = pre_mode; p.pre.act = pre_act; p.pre.cf = pre_cf; p.pre.aux = pre_aux; p.pre.ld_aux = pre_ld_aux; p.pre.C = Cin;
     const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, pre_mode);
+    if (c.c7 && stats == nullptr) return egm_conv_c7_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, N, H, W, s);
     if (c.wreg) return egm_conv_wreg_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, c.G, s);
     if (c.tile) return egm_conv_tile_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, c.tile_cfg, c.nct, c.G, s);
     if (c.direct)

@@ -216,7 +216,8 @@ class EdgeEnhancedGRFB(nn.Module):
             return None
         return ops.cat_slots(N, H, W, [C, i2, i2, i2], dtype, device)
 
-    def forward(self, x, out=None, cat=None):
+    def forward(self, x, out=None, cat=None, pool=False):
+        """pool=True: -> (result, maxpool2(result)) with the pool fused into the target gate (ops.gate3_pool) where that applies."""
         edge, x_e2, x_cat, x_sc = ops.fork_highpass3(x, 3)       # highpass3(x) + three aliases: backward sums all four gradients in one pass
         xe = self.edge_enhancer(None, x_e2, edge=edge)
         xe_d, xe_e, xe_c = ops.fork(xe, 3)
@@ -251,6 +252,10 @@ class EdgeEnhancedGRFB(nn.Module):
         out_f = ops.conv_bn_ew(x_sc, sc.conv, sc.bn, ACT_NONE, out_f, ops.EW_SAR, alpha=self.scale)
         o_a, o_b = ops.fork(out_f, 2)
         t = ops.conv2d(o_a, self.target_enhancer[0].weight, self.target_enhancer[0].bias)
+        if pool:
+            if ops.pool_fusable(o_b):
+                return ops.gate3_pool(o_b, t, out)
+            return ops.fork_maxpool2(ops.gate3(o_b, t, out))
         return ops.gate3(o_b, t, out)                                           # out*(1 + mean_c sigmoid(t))
 
 
@@ -444,7 +449,7 @@ class DoubleConv1(nn.Sequential):
         super().__init__(*layers)
         self._mca = use_mca
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, pool=False):
         o = 1 if self._mca else 0
         x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU, lazy=not self._mca)   # the MCALayer needs the tensor; a conv does not
         if self._mca:
@@ -454,16 +459,16 @@ class DoubleConv1(nn.Sequential):
         N, H, W = x.shape[0], x.shape[1], x.shape[2]
         cat = grfb.cat_buffer(N, H, W, x.dtype, x.device) if self[3 + o].out_channels == grfb.shortcut.conv.in_channels else None
         x = ops.conv_bn_act(x, self[3 + o], self[4 + o], ACT_RELU, out=None if cat is None else cat[1][0])
-        return grfb(x, out, cat)
+        return grfb(x, out, cat, pool=pool)
 
 
 class Down(nn.Sequential):
     def __init__(self, in_channels, out_channels, use_mca=True):
         super().__init__(nn.MaxPool2d(2, stride=2), DoubleConv1(in_channels, out_channels, use_mca=use_mca))
 
-    def forward(self, x, out=None, pooled=None):
-        """pooled: maxpool2(x) when the caller already has it (ops.fork_maxpool2 at the skip connection)."""
-        return self[1](ops.maxpool2(x) if pooled is None else pooled, out)
+    def forward(self, x, out=None, pooled=None, pool=False):
+        """pooled: maxpool2(x) when the caller already has it (the skip connection's fork); pool=True: -> (result, maxpool2(result))."""
+        return self[1](ops.maxpool2(x) if pooled is None else pooled, out, pool=pool)
 
 
 class GRFBUNet(_SegNetBase):
@@ -501,10 +506,11 @@ class GRFBUNet(_SegNetBase):
                     bufs[k], (slots[k], _) = ops.cat_slots(N, h, w, [cs, cin - cs], x.dtype, x.device)
         # each encoder output feeds the skip connection and the next level's max pool: one node, whose backward sums the two gradients
         # while it scatters the pooled one
-        x1s, p1 = ops.fork_maxpool2(self.in_conv(x, slots[0]))
-        x2s, p2 = ops.fork_maxpool2(self.down1(None, slots[1], pooled=p1))
-        x3s, p3 = ops.fork_maxpool2(self.down2(None, slots[2], pooled=p2))
-        x4s, p4 = ops.fork_maxpool2(self.down3(None, slots[3], pooled=p3))
+        # (the producer of each -- BatchNorm+ReLU at the top, the GRFB target gate below -- writes the pooled tensor in the same pass)
+        x1s, p1 = self.in_conv(x, slots[0], pool=True)
+        x2s, p2 = self.down1(None, slots[1], pooled=p1, pool=True)
+        x3s, p3 = self.down2(None, slots[2], pooled=p2, pool=True)
+        x4s, p4 = self.down3(None, slots[3], pooled=p3, pool=True)
         d4 = self.down4(None, pooled=p4)
         if self.ddp_boundary is not None:                 # graph.GraphedTrainStep splits backward at the encoder -> decoder tensors
             self.ddp_boundary.extend([x1s, x2s, x3s, x4s, d4])

@@ -640,6 +640,120 @@ class _ConvBN(Function):
         return gx, None, None, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None
 
 
+# environment switch for A/B runs: the max pool at a skip connection fused into its producer / consumer (csrc/pool_fused.hip)
+_FUSE_POOL = os.environ.get("EGM_FUSE_POOL", "1") != "0"
+
+
+def fuse_pool(enabled=None):
+    """Get / set whether the skip-connection max pool is fused into the kernels on either side of it (tests compare both ways)."""
+    global _FUSE_POOL
+    if enabled is not None:
+        _FUSE_POOL = bool(enabled)
+    return _FUSE_POOL
+
+
+class _ConvBNPool(Function):
+    """conv -> BatchNorm -> act -> (z for the skip connection, maxpool2(z)) as ONE autograd node (the encoder's top level:
+    src/EGM-UNet.py:44-55 followed by :908).  forward: the BatchNorm apply writes z and the pooled tensor in one pass
+    (egm_bn_act_fwd_pool).  backward: receives the skip gradient and the pooled gradient; the BatchNorm backward passes compute
+    dz = gskip + scatter(gpool) on the fly (egm_bn_pool_bwd_*), so the pool's scatter pass and the tensor it wrote do not exist."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, eps, momentum, act, training, dil, groups, out_slot):
+        x, ldx = _nhwc(x)
+        Cout, Cin_g = weight.shape[0], weight.shape[1]
+        y, stats, wd = _conv_forward(x, ldx, None, ACT_NONE, weight, bias, dil, groups, training)
+        N, H, W, CoutP = y.shape
+        npix, dev = _npix(y), y.device
+        L, dt, st = lib(), dtype_code(y.dtype), stream()
+        coef = _f32((4, CoutP), dev)                    # scale, shift, save_mean, save_rstd
+        if training:
+            L.call("egm_bn_finalize", ptr(stats), stats.shape[0], npix, ptr(gamma.detach()), ptr(beta.detach()), eps, momentum,
+                   ptr(running_mean), ptr(running_var), ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), CoutP, Cout, st)
+        else:
+            L.call("egm_bn_eval_coeffs", ptr(gamma.detach()), ptr(beta.detach()), ptr(running_mean), ptr(running_var), eps,
+                   ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), CoutP, Cout, st)
+        z, ldz = _slot_or_new(out_slot, (N, H, W, CoutP), y.dtype, dev)
+        pooled = torch.empty((N, H // 2, W // 2, CoutP), dtype=y.dtype, device=dev)
+        L.call("egm_bn_act_fwd_pool", dt, ptr(y), CoutP, ptr(coef[0]), ptr(coef[1]), act, ptr(z), ldz, ptr(pooled), CoutP, N, H, W, CoutP, st)
+        if ctx.needs_input_grad[1]:
+            _note_conv_use(weight)
+        ctx.save_for_backward(x, weight, wd, y, coef, z)
+        ctx.meta = (dil, groups, bias is not None, Cin_g * groups, Cout, act, training)
+        ctx.set_materialize_grads(False)
+        return z, pooled
+
+    @staticmethod
+    def backward(ctx, gz, gpool):
+        if gz is None and gpool is None:
+            return (None,) * 14
+        x, weight, wd, y, coef, z = ctx.saved_tensors
+        dil, groups, has_bias, Cin, Cout, act, training = ctx.meta
+        x, ldx = _nhwc(x)
+        N, H, W, CinP = x.shape
+        CoutP, npix, dev = y.shape[3], _npix(y), y.device
+        KH, KW = weight.shape[2], weight.shape[3]
+        L, dt, st = lib(), dtype_code(x.dtype), stream()
+        scale, shift, mean, rstd = coef[0], coef[1], coef[2], coef[3]
+        sums, cf4 = _f32((2, CoutP), dev), _f32((4, CoutP), dev)
+        dy = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev)
+        train = 1 if training else 0
+        if gz is not None and gpool is not None:
+            gz, ldg = _nhwc(gz)
+            gpool, ldp = _nhwc(gpool)
+            nb = L.query("egm_bn_pool_bwd_blocks", N, H, W, CoutP)
+            part = _f32(nb * 2 * CoutP, dev)
+            L.call("egm_bn_pool_bwd_reduce", dt, ptr(gz), ldg, ptr(gpool), ldp, ptr(y), CoutP, ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
+                   act, ptr(part), N, H, W, CoutP, st)
+            L.call("egm_bn_bwd_coefs", ptr(part), nb, npix, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), train, ptr(sums), ptr(cf4), CoutP, st)
+            L.call("egm_bn_pool_bwd_apply", dt, ptr(gz), ldg, ptr(gpool), ldp, ptr(y), CoutP, ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
+                   act, train, ptr(sums), ptr(dy), CoutP, N, H, W, CoutP, st)
+        else:
+            # only one of the two consumers produced a gradient: the separate kernels
+            if gz is None:
+                zk, ldzk = _nhwc(z)
+                gpool, ldp = _nhwc(gpool)
+                gz = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev)
+                L.call("egm_maxpool2_bwd", dt, ptr(zk), ldzk, ptr(gpool), ldp, ptr(gz), CoutP, N, H, W, CoutP, st)
+            gz, ldg = _nhwc(gz)
+            nb = L.query("egm_channel_partials_blocks", npix, CoutP)
+            part = _f32(nb * 2 * CoutP, dev)
+            L.call("egm_bn_act_bwd_reduce", dt, ptr(gz), ldg, ptr(y), CoutP, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), act, ptr(part),
+                   npix, CoutP, st)
+            L.call("egm_bn_bwd_coefs", ptr(part), nb, npix, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), train, ptr(sums), ptr(cf4), CoutP, st)
+            L.call("egm_bn_act_bwd_apply", dt, ptr(gz), ldg, ptr(y), CoutP, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), act, train,
+                   ptr(sums), ptr(dy), CoutP, npix, CoutP, st)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[1]:
+            gw = _conv_wgrad(x, ldx, None, ACT_NONE, dy, CoutP, None, None, weight, dil, groups, Cin, Cout)
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=dev)
+            L.call("egm_conv_fwd", dt, ptr(dy), CoutP, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = _zero_grad_vec(Cout, dev)              # a conv bias feeding a BatchNorm has an identically zero gradient
+        ggamma = sums[1, :Cout] if ctx.needs_input_grad[3] else None
+        gbeta = sums[0, :Cout] if ctx.needs_input_grad[4] else None
+        return gx, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None, None
+
+
+def conv_bn_act_pool(x, conv, bn, act, dil=1, groups=1, out=None):
+    """conv -> BatchNorm -> activation -> (result, maxpool2(result)): the skip-connection tensor (into the destination view `out` when
+    given) and its pooled copy from one BatchNorm apply pass, one autograd node (see _ConvBNPool).  H and W must be even; callers fall
+    back to conv_bn_act + fork_maxpool2 otherwise (pool_fusable)."""
+    if bn.training and bn.num_batches_tracked is not None and not getattr(bn, "_egm_counter_managed", False):
+        bn.num_batches_tracked.add_(1)                  # bookkeeping counter (int64), as nn.BatchNorm2d does
+    training = bn.training or bn.running_mean is None
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    x = materialize(x)
+    return _ConvBNPool.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, act,
+                             training, dil, groups, None if out is None else [out])
+
+
+def pool_fusable(x):
+    """True when the fused skip-connection pool applies to the NHWC tensor / Lazy x (switch on, even H and W, <= 1024 channels)."""
+    return _FUSE_POOL and not _FUSE_BN and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and x.shape[1] >= 2 and x.shape[2] >= 2 and x.shape[3] <= 1024
+
+
 # ----------------------------------------------------------------------------------------------------------
 # BatchNorm (+ activation)
 # ----------------------------------------------------------------------------------------------------------
@@ -1369,6 +1483,49 @@ class _Gate3(Function):
 
 def gate3(x, t, out=None):
     return _Gate3.apply(x, t, None if out is None else [out])
+
+
+class _Gate3Pool(Function):
+    """gate3 followed by the skip-connection fork + max pool as ONE node: -> (out, maxpool2(out)); backward takes both gradients and
+    never materialises their sum (egm_gate3_pool_bwd; EdgeEnhancedGRFB's last op, src/EGM-UNet.py:1319-1321, behind :908)."""
+
+    @staticmethod
+    def forward(ctx, x, t, out_slot=None):
+        x, ldx = _nhwc(x); t, ldt = _nhwc(t)
+        N, H, W, C = x.shape
+        out, ldo = _slot_or_new(out_slot, tuple(x.shape), x.dtype, x.device)
+        pooled = torch.empty((N, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+        lib().call("egm_gate3_fwd_pool", dtype_code(x.dtype), ptr(x), ldx, ptr(t), ldt, ptr(out), ldo, ptr(pooled), C, N, H, W, C, stream())
+        ctx.save_for_backward(x, t, out)
+        ctx.set_materialize_grads(False)
+        return out, pooled
+
+    @staticmethod
+    def backward(ctx, gskip, gpool):
+        if gskip is None and gpool is None:
+            return None, None, None
+        x, t, out = ctx.saved_tensors
+        x, ldx = _nhwc(x); t, ldt = _nhwc(t)
+        N, H, W, C = x.shape
+        L, dt_, st = lib(), dtype_code(x.dtype), stream()
+        dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        dt = torch.empty(t.shape[:3] + (8,), dtype=x.dtype, device=x.device)
+        if gskip is not None and gpool is not None:
+            gs, lds = _nhwc(gskip); gp, ldp = _nhwc(gpool)
+            L.call("egm_gate3_pool_bwd", dt_, ptr(gs), lds, ptr(gp), ldp, ptr(x), ldx, ptr(t), ldt, ptr(dx), C, ptr(dt), 8, N, H, W, C, st)
+            return dx, dt, None
+        if gskip is None:                                       # only the pooled branch was used: the separate scatter
+            ok, ldo = _nhwc(out); gp, ldp = _nhwc(gpool)
+            gskip = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+            L.call("egm_maxpool2_bwd", dt_, ptr(ok), ldo, ptr(gp), ldp, ptr(gskip), C, N, H, W, C, st)
+        g, ldg = _nhwc(gskip)
+        L.call("egm_gate3_bwd", dt_, ptr(g), ldg, ptr(x), ldx, ptr(t), ldt, ptr(dx), C, ptr(dt), 8, _npix(x), C, st)
+        return dx, dt, None
+
+
+def gate3_pool(x, t, out=None):
+    """-> (gate3(x, t) [into `out`], maxpool2 of it); see _Gate3Pool.  Callers check pool_fusable(x) first."""
+    return _Gate3Pool.apply(x, t, None if out is None else [out])
 
 
 class _BcastGate(Function):

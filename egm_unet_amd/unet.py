@@ -26,10 +26,16 @@ class DoubleConv(nn.Sequential):
             nn.ReLU(inplace=True),
         )
 
-    def forward(self, x, out=None, lazy=False):
+    def forward(self, x, out=None, lazy=False, pool=False):
         """x: NHWC; out: optional destination view (a concat slot); lazy: hand the result on as an ops.Lazy (the caller feeds it to a
-        convolution).  The first BatchNorm+ReLU is never a pass: the second conv applies it while staging its input."""
+        convolution).  The first BatchNorm+ReLU is never a pass: the second conv applies it while staging its input.
+        pool=True: -> (result, maxpool2(result)), the skip tensor and the next level's input from ONE BatchNorm apply pass (or from
+        the separate pool kernel when the fused form does not apply: odd sizes, switch off)."""
         x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU, lazy=True)
+        if pool:
+            if ops.pool_fusable(x):
+                return ops.conv_bn_act_pool(x, self[3], self[4], ACT_RELU, out=out)
+            return ops.fork_maxpool2(ops.conv_bn_act(x, self[3], self[4], ACT_RELU, out=out))
         return ops.conv_bn_act(x, self[3], self[4], ACT_RELU, out=out, lazy=lazy)
 
 
@@ -39,9 +45,9 @@ class Down(nn.Sequential):
     def __init__(self, in_channels, out_channels):
         super().__init__(nn.MaxPool2d(2, stride=2), DoubleConv(in_channels, out_channels))
 
-    def forward(self, x, pooled=None):
-        """pooled: maxpool2(x) when the caller already has it (ops.fork_maxpool2 at the skip connection)."""
-        return self[1](ops.maxpool2(x) if pooled is None else pooled)
+    def forward(self, x, pooled=None, pool=False):
+        """pooled: maxpool2(x) when the caller already has it (the skip connection's fork); pool: see DoubleConv.forward."""
+        return self[1](ops.maxpool2(x) if pooled is None else pooled, pool=pool)
 
 
 class Up(nn.Module):
@@ -135,10 +141,12 @@ class UNet(_SegNetBase):
 
     def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         x = self._enter(x)
-        x1s, p1 = ops.fork_maxpool2(self.in_conv(x))             # skip alias + pooled tensor: the two gradients are summed in the pool's backward
-        x2s, p2 = ops.fork_maxpool2(self.down1(None, pooled=p1))
-        x3s, p3 = ops.fork_maxpool2(self.down2(None, pooled=p2))
-        x4s, p4 = ops.fork_maxpool2(self.down3(None, pooled=p3))
+        # each level's output is the skip tensor AND, max-pooled, the next level's input: one node whose forward writes both and
+        # whose backward takes both gradients (ops.conv_bn_act_pool)
+        x1s, p1 = self.in_conv(x, pool=True)
+        x2s, p2 = self.down1(None, pooled=p1, pool=True)
+        x3s, p3 = self.down2(None, pooled=p2, pool=True)
+        x4s, p4 = self.down3(None, pooled=p3, pool=True)
         x5 = self.down4(None, pooled=p4)
         if self.ddp_boundary is not None:
             x5, x5d = ops.fork2(x5)                              # the decoder-side alias is the boundary tensor

@@ -89,6 +89,10 @@ int egm_conv_tile_mode(int mode);
 /* Diagnostics only (tools/conv_tile_diag.py): phase-elimination switches of the tile kernel, OR of 1 = no LDS-DMA, 2 = no MFMA phase,
  * 4 = no epilogue; outputs are wrong while any is set.  -1 = query.  Returns the previous value; 0 in production. */
 int egm_conv_tile_debug(int dbg);
+/* 7x7 kernel selection for 16 -> 16 channels (FusionConv's merged 3x3+5x5+7x7 conv at the 64-channel level, src/EGM-UNet.py:1210-1228):
+ * 1 = the weights-in-registers v_mfma_f32_16x16x32_bf16 kernel (csrc/conv7x7_c16.hip; default, env EGM_CONV_C7), 0 = the generic
+ * pipelined kernel, -1 = query only.  Returns the previous mode (A/B timing and parity tests). */
+int egm_conv_c7_mode(int mode);
 /* Name of the kernel egm_conv_fwd_pre launches for a shape, spelled like the rows of a rocprofv3 kernel trace (e.g.
  * "conv_igemm_pipe_kernel<2, 3, 3, 2, 0>"); returns its length, copies at most buflen-1 characters into buf (may be NULL). */
 int egm_conv_kernel_name(int dtype, int pre_mode, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen);
@@ -227,6 +231,27 @@ int egm_maxpool2_bwd(int dtype, const void* x, int ldx, const void* dy, int lddy
 /* egm_maxpool2_bwd with a second gradient of x summed in the same pass: dx = scatter(dy) + add (even H, W). */
 int egm_maxpool2_bwd_add(int dtype, const void* x, int ldx, const void* dy, int lddy, const void* add, int ldadd, void* dx, int lddx,
                          int N, int H, int W, int C, egm_stream_t s);
+/* The max pool at an encoder skip connection fused into its neighbours (csrc/pool_fused.hip; src/EGM-UNet.py:908 behind :44-55 at the
+ * top level and behind the EdgeEnhancedGRFB target gate :1319-1321 below it).  H, W = the full-resolution sizes, both even.
+ *   egm_bn_act_fwd_pool   : z = act(y*scale + shift) AND pooled = maxpool2(z)                      (egm_bn_act_fwd + egm_maxpool2_fwd)
+ *   egm_bn_pool_bwd_reduce: egm_bn_act_bwd_reduce with dz = gskip + scatter(gpool) computed on the fly (egm_maxpool2_bwd_add never runs);
+ *                           partials [egm_bn_pool_bwd_blocks()][2][C]
+ *   egm_bn_pool_bwd_apply : egm_bn_act_bwd_apply with the same on-the-fly dz
+ *   egm_gate3_fwd_pool    : out = x*(1 + mean_k sigmoid(t[k])) AND pooled = maxpool2(out)           (egm_gate3_fwd + egm_maxpool2_fwd)
+ *   egm_gate3_pool_bwd    : egm_gate3_bwd with g = gskip + scatter(gpool) computed on the fly */
+int egm_bn_act_fwd_pool(int dtype, const void* y, int ldy, const float* scale, const float* shift, int act, void* z, int ldz,
+                        void* pooled, int ldp, int N, int H, int W, int C, egm_stream_t s);
+int egm_bn_pool_bwd_blocks(int N, int H, int W, int C);
+int egm_bn_pool_bwd_reduce(int dtype, const void* gskip, int ldgs, const void* gpool, int ldgp, const void* y, int ldy,
+                           const float* scale, const float* shift, const float* save_mean, const float* save_rstd, int act,
+                           float* partials, int N, int H, int W, int C, egm_stream_t s);
+int egm_bn_pool_bwd_apply(int dtype, const void* gskip, int ldgs, const void* gpool, int ldgp, const void* y, int ldy,
+                          const float* scale, const float* shift, const float* save_mean, const float* save_rstd, int act, int train,
+                          const float* sums, void* dy, int lddy, int N, int H, int W, int C, egm_stream_t s);
+int egm_gate3_fwd_pool(int dtype, const void* x, int ldx, const void* t, int ldt, void* out, int ldo, void* pooled, int ldp, int N,
+                       int H, int W, int C, egm_stream_t s);
+int egm_gate3_pool_bwd(int dtype, const void* gskip, int ldgs, const void* gpool, int ldgp, const void* x, int ldx, const void* t,
+                       int ldt, void* dx, int lddx, void* dt, int lddt, int N, int H, int W, int C, egm_stream_t s);
 /* Up.forward front half (src/EGM-UNet.py:937-947): out = cat([skip, pad(bilinear_x2_align_corners(low))], C).
  * Writes BOTH halves of `out` (ld = ldo >= Cs + Cl): skip [N,Hs,Ws,Cs], low [N,Hl,Wl,Cl].
  * skip == NULL: the skip channels were produced straight into out[..., :Cs] by their own kernel; only the Cl upsampled channels are written. */

@@ -1,0 +1,53 @@
+"""The weights-in-registers 7x7 kernel for 16 -> 16 channels (csrc/conv7x7_c16.hip; FusionConv's merged multi-scale conv at the
+64-channel level, src/EGM-UNet.py:1210-1228) against the generic pipelined kernel and against torch, forward and data gradient."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 100), (1, 8, 64), (1, 5, 7), (3, 64, 192)])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_conv7x7_c16_matches_generic_kernel_and_torch(shape, with_bias):
+    from egm_unet_amd import ops
+    from egm_unet_amd._lib import dtype_code, lib
+    N, H, W = shape
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(N, H, W, 16, generator=g).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(16, 16, 7, 7, generator=g) * 0.05).to(DEV).requires_grad_(True)
+    b = (torch.randn(16, generator=g) * 0.1).to(DEV).requires_grad_(True) if with_bias else None
+    gy = torch.randn(N, H, W, 16, generator=g).to(DEV).to(torch.bfloat16)
+    L = lib()
+    buf = __import__("ctypes").create_string_buffer(96)
+    L.cdll.egm_conv_kernel_name(dtype_code(torch.bfloat16), 0, N, H, W, 16, 16, 7, 7, 1, buf, 96)
+    assert buf.value.decode() == "conv7x7_c16_kernel"       # the kernel under test is the one the shape takes
+    res = []
+    old = L.cdll.egm_conv_c7_mode(-1)
+    try:
+        for mode in (1, 0):
+            L.cdll.egm_conv_c7_mode(mode)
+            ops.bump_weight_generation()
+            w.grad = None
+            xa = x.clone().requires_grad_(True)
+            y = ops.conv2d(xa, w, b)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res.append((y.detach().clone(), xa.grad.clone(), w.grad.clone()))
+    finally:
+        L.cdll.egm_conv_c7_mode(old)
+        ops.bump_weight_generation()
+    (y1, dx1, dw1), (y0, dx0, dw0) = res
+    # same products, fp32 accumulation in a different order: agreement to bf16 rounding of the result
+    for a, r, what in ((y1, y0, "y"), (dx1, dx0, "dx")):
+        err = float((a.float() - r.float()).abs().max()) / max(1e-6, float(r.float().abs().max()))
+        assert err <= 1e-2, (what, err)
+    assert torch.equal(dw1, dw0)                                # the weight gradient does not take this kernel: same dy, same result
+    xr = x.float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wr = w.detach().to(torch.bfloat16).float()
+    yr = F.conv2d(xr, wr, None if b is None else b.detach(), padding=3)
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    ref, dref = yr.detach().permute(0, 2, 3, 1), xr.grad.permute(0, 2, 3, 1)
+    assert float((y1.float() - ref).abs().max()) <= 1e-2 * max(1.0, float(ref.abs().max()))
+    assert float((dx1.float() - dref).abs().max()) <= 1e-2 * max(1.0, float(dref.abs().max()))
