@@ -15,6 +15,7 @@
 // element in window scan order (the forward stencil records the arg-max/arg-min window positions as one byte per
 // element for the backward gather).
 #include "common.h"
+#include "prologue.h"
 #include <stdlib.h>
 
 namespace {
@@ -27,7 +28,10 @@ inline int stream_grid(long long total_threads) {
 }
 __device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); }
 
-// ---- pass 1: one block per image row (n,h).  MODE 0: sums of (a, a^2); MODE 1: sums of (a*b, (a*b)^2) ---------------
+// ---- pass 1: one block per image row (n,h).  MODE 0: sums of (a, a^2); MODE 1: sums of (a*b, (a*b)^2);
+//      MODE 2: a is the RAW output of the conv in front (src/EGM-UNet.py:893-896): z = act(scale*a + shift) is computed here, written
+//      to zout (rounded to the storage type, as egm_bn_act_fwd writes it) and summed as MODE 0 sums a -- the BatchNorm apply pass and
+//      the statistics pass over its result are one pass ---------------------------------------------------------------------
 //   sums [N][L][2], L = H+W+C: rows written directly at [n][h]
 //   colp [N][H][W][2]  sum over c   (still partial over h)
 //   chp  [N][H][C][2]  sum over w   (still partial over h)
@@ -35,7 +39,9 @@ __device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); 
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void mca_reduce_row_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b, int ldb,
                                                              float* __restrict__ sums, float* __restrict__ colp, float* __restrict__ chp,
-                                                             int H, int W, int C) {
+                                                             int H, int W, int C, const float* __restrict__ scale = nullptr,
+                                                             const float* __restrict__ shift = nullptr, int act = 0,
+                                                             T* __restrict__ zout = nullptr, int ldz = 0) {
     __shared__ float st[2 * 256 * 8];
     __shared__ float red[16];
     const int n = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, ncv = C >> 3, slots = 256 / ncv;
@@ -43,6 +49,11 @@ __global__ __launch_bounds__(256) void mca_reduce_row_kernel(const T* __restrict
     const long long rowbase = ((long long)n * H + h) * W;
     float s8[8], q8[8], ts = 0.f, tq = 0.f;
     zero8(s8); zero8(q8);
+    float sc8[8], sh8[8];
+    if (MODE == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc8[j] = scale[cv * 8 + j]; sh8[j] = shift[cv * 8 + j]; }
+    }
     for (int w0 = 0; w0 < W; w0 += slots) {
         const int w = w0 + slot;
         float ps = 0.f, pq = 0.f;
@@ -54,6 +65,11 @@ __global__ __launch_bounds__(256) void mca_reduce_row_kernel(const T* __restrict
                 load8(b + (rowbase + w) * ldb + cv * 8, u);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] *= u[j];
+            }
+            if (MODE == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<T>(bn_fwd_elem(v[j], sc8[j], sh8[j], act)));
+                store8(zout + (rowbase + w) * ldz + cv * 8, v);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s8[j] += v[j]; q8[j] += v[j] * v[j]; ps += v[j]; pq += v[j] * v[j]; }
@@ -587,6 +603,24 @@ extern "C" int egm_mca_reduce(int dtype, int mode, const void* a, int lda, const
     });
     hipLaunchKernelGGL(mca_reduce_h_kernel, dim3(((W + C) * 2 + 15) / 16, N), dim3(256), 0, st, colp, chp, sums, N, H, W, C);
     EGM_CHECK_LAUNCH("mca_reduce");
+    return EGM_OK;
+}
+
+/* egm_mca_reduce mode 0 on z = act(scale*y + shift), with z written out on the way (egm_bn_act_fwd + egm_mca_reduce in one pass) */
+extern "C" int egm_mca_reduce_bn(int dtype, const void* y, int ldy, const float* scale, const float* shift, int act, void* z, int ldz,
+                                 float* sums, void* workspace, int N, int H, int W, int C, egm_stream_t s) {
+    EGM_REQ_VEC("mca_reduce_bn", y, ldy, C);
+    EGM_REQ_VEC("mca_reduce_bn", z, ldz, C);
+    EGM_REQ_SHAPE("mca_reduce_bn");
+    EGM_REQUIRE(sums && workspace && scale && shift, "mca_reduce_bn: bad args");
+    EGM_REQUIRE(mca_c_ok(C), "mca_reduce_bn: C must be a power of two in [8, 512] (C=%d)", C);
+    float* colp = (float*)workspace;
+    float* chp = colp + (long long)N * H * W * 2;
+    hipStream_t st = (hipStream_t)s;
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((mca_reduce_row_kernel<T, 2>), dim3(H, N), dim3(256), 0, st, (const T*)y, ldy, (const T*)nullptr,
+                                                 0, sums, colp, chp, H, W, C, scale, shift, act, (T*)z, ldz));
+    hipLaunchKernelGGL(mca_reduce_h_kernel, dim3(((W + C) * 2 + 15) / 16, N), dim3(256), 0, st, colp, chp, sums, N, H, W, C);
+    EGM_CHECK_LAUNCH("mca_reduce_bn");
     return EGM_OK;
 }
 

@@ -451,9 +451,11 @@ class DoubleConv1(nn.Sequential):
 
     def forward(self, x, out=None, pool=False):
         o = 1 if self._mca else 0
-        x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU, lazy=not self._mca)   # the MCALayer needs the tensor; a conv does not
         if self._mca:
-            x = self[3](x)
+            # the MCALayer's three-axis statistics pass applies this BatchNorm+ReLU itself and writes the tensor on the way
+            x = self[3](ops.conv_bn_lazy(x, self[0], self[1], ACT_RELU) if ops.fuse_mca_bn() else ops.conv_bn_act(x, self[0], self[1], ACT_RELU))
+        else:
+            x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU, lazy=True)        # consumed by a conv
         # the second conv's BatchNorm+ReLU writes the GRFB's input straight into slot 0 of the GRFB's concat buffer
         grfb = self[6 + o]
         N, H, W = x.shape[0], x.shape[1], x.shape[2]

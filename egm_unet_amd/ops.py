@@ -644,6 +644,17 @@ class _ConvBN(Function):
 _FUSE_POOL = os.environ.get("EGM_FUSE_POOL", "1") != "0"
 
 
+_FUSE_MCA_BN = os.environ.get("EGM_FUSE_MCA_BN", "1") != "0"
+
+
+def fuse_mca_bn(enabled=None):
+    """Get / set whether the BatchNorm+ReLU in front of an MCALayer is applied by the layer's statistics pass (egm_mca_reduce_bn)."""
+    global _FUSE_MCA_BN
+    if enabled is not None:
+        _FUSE_MCA_BN = bool(enabled)
+    return _FUSE_MCA_BN
+
+
 def fuse_pool(enabled=None):
     """Get / set whether the skip-connection max pool is fused into the kernels on either side of it (tests compare both ways)."""
     global _FUSE_POOL
@@ -734,6 +745,21 @@ class _ConvBNPool(Function):
         ggamma = sums[1, :Cout] if ctx.needs_input_grad[3] else None
         gbeta = sums[0, :Cout] if ctx.needs_input_grad[4] else None
         return gx, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None, None
+
+
+def conv_bn_lazy(x, conv, bn, act, dil=1, groups=1):
+    """conv -> BatchNorm -> activation as an ops.Lazy whatever the fuse_bn() setting: for a consumer whose first pass materialises the
+    tensor itself (ops.mca_layer: BatchNorm apply + the three-axis statistics in one pass)."""
+    if bn.training and bn.num_batches_tracked is not None and not getattr(bn, "_egm_counter_managed", False):
+        bn.num_batches_tracked.add_(1)
+    training = bn.training or bn.running_mean is None
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    if not _FUSE_BN:
+        x = materialize(x)
+    xt, xc, xa = _unlazy(x)
+    y, coef = _ConvBN.apply(xt, xc, xa, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, act,
+                            training, dil, groups)
+    return Lazy(y, coef, act)
 
 
 def conv_bn_act_pool(x, conv, bn, act, dil=1, groups=1, out=None):
@@ -2067,14 +2093,21 @@ class _MCALayer(Function):
     """wc / kc None: MCALayer(no_spatial=True) -- two gates, x_out = x*(g_h+g_w)/2 (src/EGM-UNet.py:766-771)"""
 
     @staticmethod
-    def forward(ctx, x, wh, kh, ww, kw, wc, kc, training):
+    def forward(ctx, x, x_coef, x_act, wh, kh, ww, kw, wc, kc, training):
+        """x_coef / x_act: x is a Lazy's stand-in (the raw output of the conv in front; ops.Lazy): its BatchNorm + activation is applied
+        by the statistics pass, which writes the materialised tensor on the way (egm_mca_reduce_bn)."""
         x, ldx = _nhwc(x)
         N, H, W, C = x.shape
         L, dt, st, dev = lib(), dtype_code(x.dtype), stream(), x.device
         Lax = H + W + C
         ws = torch.empty(L.query("egm_mca_reduce_workspace", N, H, W, C) // 4 + 4, dtype=torch.float32, device=dev)
         sums = _f32((N, Lax, 2), dev)
-        L.call("egm_mca_reduce", dt, 0, ptr(x), ldx, None, 0, ptr(sums), ptr(ws), N, H, W, C, st)
+        if x_coef is not None:
+            z = torch.empty((N, H, W, C), dtype=x.dtype, device=dev)
+            L.call("egm_mca_reduce_bn", dt, ptr(x), ldx, ptr(x_coef[0]), ptr(x_coef[1]), x_act, ptr(z), C, ptr(sums), ptr(ws), N, H, W, C, st)
+            x, ldx = z, C
+        else:
+            L.call("egm_mca_reduce", dt, 0, ptr(x), ldx, None, 0, ptr(sums), ptr(ws), N, H, W, C, st)
         stats, o, gates = _f32((N, Lax, 2), dev), _f32((N, Lax), dev), _f32((N, Lax), dev)
         ps = [t.detach().contiguous() for t in (wh, kh, ww, kw, wc, kc) if t is not None]
         ns = int(wc is None)
@@ -2118,15 +2151,20 @@ class _MCALayer(Function):
         L.call("egm_mca_bwd_dx", dt, ptr(dxo), C, ptr(x), ldx, ptr(gates), ptr(coef), ptr(dx), C, N, H, W, C, ns, st)
         gk = [dks[a, :ks[a]].reshape(1, 1, 1, ks[a]) for a in range(2 if ns else 3)]
         if ns:
-            return dx, dwts[0], gk[0], dwts[1], gk[1], None, None, None
-        return dx, dwts[0], gk[0], dwts[1], gk[1], dwts[2], gk[2], None
+            return dx, None, None, dwts[0], gk[0], dwts[1], gk[1], None, None, None
+        return dx, None, None, dwts[0], gk[0], dwts[1], gk[1], dwts[2], gk[2], None
 
 
 def mca_layer(x, layer, training):
     """layer: an MCALayer parameter holder with gates h_cw, w_hc and -- unless layer.no_spatial -- c_hw
     (each: .weight [2], .conv.weight [1,1,1,k])."""
     c = (None, None) if layer.no_spatial else (layer.c_hw.weight, layer.c_hw.conv.weight)
-    return _MCALayer.apply(x, layer.h_cw.weight, layer.h_cw.conv.weight, layer.w_hc.weight, layer.w_hc.conv.weight, c[0], c[1], training)
+    xt, xc, xa = _unlazy(x)                   # a Lazy (conv_bn_lazy) is materialised by the layer's own statistics pass
+    C = xt.shape[3]
+    if xc is not None and not (8 <= C <= 512 and (C & (C - 1)) == 0):
+        xt, xc, xa = materialize(x), None, ACT_NONE
+    return _MCALayer.apply(xt, xc, xa, layer.h_cw.weight, layer.h_cw.conv.weight, layer.w_hc.weight, layer.w_hc.conv.weight, c[0], c[1],
+                           training)
 
 
 class _SAConv7(Function):

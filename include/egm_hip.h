@@ -367,6 +367,10 @@ int egm_merge357_pack(int dtype, const float* w3, const float* w5, const float* 
 long long egm_mca_reduce_workspace(int N, int H, int W, int C);
 int egm_mca_reduce(int dtype, int mode, const void* a, int lda, const void* b, int ldb, float* sums, void* workspace, int N,
                    int H, int W, int C, egm_stream_t s);
+/* egm_mca_reduce mode 0 over z = act(y*scale + shift), the BatchNorm(+ReLU) output of the conv in front of the MCALayer
+ * (src/EGM-UNet.py:893-896), which is WRITTEN to z on the way: egm_bn_act_fwd and the statistics pass over its result as one pass. */
+int egm_mca_reduce_bn(int dtype, const void* y, int ldy, const float* scale, const float* shift, int act, void* z, int ldz,
+                      float* sums, void* workspace, int N, int H, int W, int C, egm_stream_t s);
 /* sums -> stats [N][L][2] (mean, unbiased std), o [N][L] (pre-conv gate input), gates [N][L] (sigmoid outputs); L=H+W+C.
  * w_*: MCAGate.weight (2 floats); k_*: the 1 x ks conv kernel of each gate (h_cw, w_hc, c_hw).
  * ks_c == 0 is MCALayer(no_spatial=True) (src/EGM-UNet.py:700-703,766-771): there is no c_hw gate, w_c / k_c may be NULL, the channel

@@ -123,3 +123,36 @@ def test_model_with_fused_pool_equals_separate_pool(dtype):
         if float(b.norm()) > 1e-6:
             worst = max(worst, float((a - b).norm() / b.norm()))
     assert worst <= (1e-3 if dtype == torch.float32 else 0.2), worst
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_model_with_mca_statistics_pass_applying_batchnorm_is_identical(dtype):
+    """DoubleConv1's first BatchNorm+ReLU applied by the MCALayer's statistics pass (egm_mca_reduce_bn, ops.fuse_mca_bn) against the
+    separate apply pass: same values summed in the same order, so logits and every gradient are bit-identical."""
+    from egm_unet_amd import GRFBUNet, ops
+    from oracle import egm_ref as R
+    st = R.make_egm_unet_state(3, 2, 8, seed=9)
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 3, 64, 64, generator=g).to(DEV)
+    gl = torch.randn(2, 2, 64, 64, generator=g).to(DEV)
+    default = ops.fuse_mca_bn()
+    outs = []
+    try:
+        for fused in (True, False):
+            ops.fuse_mca_bn(fused)
+            m = GRFBUNet(3, 2, base_c=8)
+            m.load_state_dict(st, strict=True)
+            m.to(DEV).train().set_compute_dtype(dtype)
+            out = m(x)["out"]
+            out.backward(gl)
+            torch.cuda.synchronize()
+            outs.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
+                         {k: v.clone() for k, v in m.state_dict().items() if "running" in k}))
+    finally:
+        ops.fuse_mca_bn(default)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1].keys() == outs[1][1].keys()
+    for k in outs[0][1]:
+        assert torch.equal(outs[0][1][k], outs[1][1][k]), k
+    for k in outs[0][2]:
+        assert torch.equal(outs[0][2][k], outs[1][2][k]), k
