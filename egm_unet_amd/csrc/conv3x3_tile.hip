@@ -48,6 +48,7 @@ constexpr int TW = 32, PW = TW + 2, KC = 16;
 
 struct TileParams {
     const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y; float* stats;
+    bf16_t* y2; int ldy2, csplit;    // split output: couts >= csplit go to y2[..., c - csplit] (pixel stride ldy2); csplit = 0: one output
     int ldx, ldy, N, H, W, Cin, Cout, bias_n;
     int tiles_y, tiles_x, npt, nct, G;
     int dbg;        // ablation switches for tools/conv_tile_diag.py (0 in production): 1 = no DMA, 2 = no MFMA phase, 4 = no epilogue, 8 = no static priority
@@ -287,7 +288,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
             for (int it2 = 0; it2 < NV / 2; ++it2)                    // 32 pixels / (64 / NV pixel slots)
                 raw[it2] = *reinterpret_cast<const uint4*>(ot + (it2 * (64 / NV) + slot) * OROW + cv * 16);
             if (oy < p.H) {
-                bf16_t* yrow = p.y + ((long long)(t.n * p.H + oy) * p.W + t.ox0) * p.ldy + co0 + wc * NT * 32 + cv * 8;
+                // split output (the two halves of a concat gradient as two dense tensors): a lane's 8-cout vector lies in one half
+                const int cvec = co0 + wc * NT * 32 + cv * 8;
+                const bool second = p.csplit > 0 && cvec >= p.csplit;
+                const int ldo = second ? p.ldy2 : p.ldy;
+                bf16_t* yrow = (second ? p.y2 + (cvec - p.csplit) : p.y + cvec) + ((long long)(t.n * p.H + oy) * p.W + t.ox0) * ldo;
 #pragma unroll
                 for (int it2 = 0; it2 < NV / 2; ++it2) {
                     const int pl = it2 * (64 / NV) + slot;
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
                         rw.z = pack_bf16x2(b[4] + bias8[4], b[5] + bias8[5]); rw.w = pack_bf16x2(b[6] + bias8[6], b[7] + bias8[7]);
                     }
                     if (!ok) rw = make_uint4(0, 0, 0, 0);             // pixels right of the image: no store, nothing in the statistics
-                    if (ok) *reinterpret_cast<uint4*>(yrow + (long long)pl * p.ldy) = rw;
+                    if (ok) *reinterpret_cast<uint4*>(yrow + (long long)pl * ldo) = rw;
                     float v[8];
                     v[0] = __uint_as_float(rw.x << 16); v[1] = __uint_as_float(rw.x & 0xffff0000u);
                     v[2] = __uint_as_float(rw.y << 16); v[3] = __uint_as_float(rw.y & 0xffff0000u);
@@ -499,9 +504,10 @@ const char* egm_conv_tile_name(int cfg) {
 }
 
 int egm_conv_tile_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, float* stats, int N, int H,
-                         int W, int Cin, int Cout, int cfg, int nct, int G, egm_stream_t s) {
+                         int W, int Cin, int Cout, int cfg, int nct, int G, egm_stream_t s, void* y2, int ldy2, int csplit) {
     TileParams p;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)wf; p.bias = bias; p.y = (bf16_t*)y; p.stats = stats;
+    p.y2 = (bf16_t*)y2; p.ldy2 = ldy2; p.csplit = y2 ? csplit : 0;
     p.ldx = ldx; p.ldy = ldy; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.bias_n = bias ? bias_n : 0;
     p.dbg = g_tile_dbg;
     const int rows = kCfgs[cfg].rows;

@@ -48,7 +48,7 @@ const char* egm_conv_wreg_name(int Cin);
 int egm_conv_wreg_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, float* stats, int N, int H,
                          int W, int Cin, int Cout, int G, egm_stream_t s);
 int egm_conv_tile_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, float* stats, int N, int H,
-                         int W, int Cin, int Cout, int cfg, int nct, int G, egm_stream_t s);
+                         int W, int Cin, int Cout, int cfg, int nct, int G, egm_stream_t s, void* y2 = nullptr, int ldy2 = 0, int csplit = 0);
 // conv7x7_c16.hip: weights-in-registers 7x7 kernel for 16 -> 16 channels (FusionConv's merged multi-scale conv at the 64-channel level)
 int egm_conv_c7_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
 int egm_conv_c7_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, int N, int H, int W,
@@ -910,6 +910,21 @@ extern "C" int egm_conv_fwd(int dtype, const void* x, int ldx, const void* wf, c
                             float* stats, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, egm_stream_t s) {
     return egm_conv_fwd_pre(dtype, x, ldx, EGM_PRE_NONE, 0, nullptr, nullptr, 0, wf, bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, KH, KW,
                             dil, s);
+}
+
+/* 1 when egm_conv_fwd_split takes this shape (the 8-wave 3x3 tile kernel does, with the split on an 8-channel boundary) */
+extern "C" int egm_conv_split_ok(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int csplit) {
+    if (csplit <= 0 || csplit >= Cout || csplit % 8 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 8 || Cout % 8) return 0;
+    const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, EGM_PRE_NONE);
+    return (!c.c7 && !c.wreg && c.tile) ? 1 : 0;
+}
+extern "C" int egm_conv_fwd_split(int dtype, const void* x, int ldx, const void* wf, void* y, int ldy, void* y2, int ldy2, int csplit, int N,
+                                  int H, int W, int Cin, int Cout, int KH, int KW, int dil, egm_stream_t s) {
+    EGM_REQUIRE(x && wf && y && y2 && egm_aligned16(x) && egm_aligned16(wf) && egm_aligned16(y) && egm_aligned16(y2), "conv_fwd_split: bad pointers");
+    EGM_REQUIRE(egm_conv_split_ok(dtype, N, H, W, Cin, Cout, KH, KW, dil, csplit), "conv_fwd_split: shape not supported (egm_conv_split_ok)");
+    EGM_REQUIRE(ldx >= Cin && ldx % 8 == 0 && ldy >= csplit && ldy % 8 == 0 && ldy2 >= Cout - csplit && ldy2 % 8 == 0, "conv_fwd_split: bad ld");
+    const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, EGM_PRE_NONE);
+    return egm_conv_tile_launch(x, ldx, wf, nullptr, 0, y, ldy, nullptr, N, H, W, Cin, Cout, c.tile_cfg, c.nct, c.G, s, y2, ldy2, csplit);
 }
 
 extern "C" int egm_conv_fwd_pre(int dtype, const void* x, int ldx, int pre_mode, int pre_act, const float* pre_cf, const void* pre_aux,

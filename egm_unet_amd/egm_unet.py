@@ -46,8 +46,10 @@ class MCALayer(nn.Module):
         if not no_spatial:                                                      # :700-703: without it, x_out = (x_h + x_w) / 2
             self.c_hw = MCAGate(kernel)
 
-    def forward(self, x):
-        return ops.mca_layer(x, self, self.training and torch.is_grad_enabled())
+    def forward(self, x, exclusive=False):
+        """x: NHWC tensor, or an ops.Lazy the layer materialises in its statistics pass; exclusive: that Lazy feeds nothing else (then
+        the layer's last backward step is evaluated inside the BatchNorm backward of the conv in front)."""
+        return ops.mca_layer(x, self, self.training and torch.is_grad_enabled(), exclusive)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -453,7 +455,10 @@ class DoubleConv1(nn.Sequential):
         o = 1 if self._mca else 0
         if self._mca:
             # the MCALayer's three-axis statistics pass applies this BatchNorm+ReLU itself and writes the tensor on the way
-            x = self[3](ops.conv_bn_lazy(x, self[0], self[1], ACT_RELU) if ops.fuse_mca_bn() else ops.conv_bn_act(x, self[0], self[1], ACT_RELU))
+            if ops.fuse_mca_bn():
+                x = self[3](ops.conv_bn_lazy(x, self[0], self[1], ACT_RELU), exclusive=True)
+            else:
+                x = self[3](ops.conv_bn_act(x, self[0], self[1], ACT_RELU))
         else:
             x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU, lazy=True)        # consumed by a conv
         # the second conv's BatchNorm+ReLU writes the GRFB's input straight into slot 0 of the GRFB's concat buffer
@@ -521,4 +526,4 @@ class GRFBUNet(_SegNetBase):
         y = self.up2(y, x3s, bufs[2])
         y = self.up3(y, x2s, bufs[1])
         y = self.up4(y, x1s, bufs[0], lazy=True)                 # the 1x1 classifier applies up4's last BatchNorm+ReLU itself
-        return self._exit(self.out_conv(y))
+        return self._exit(self.out_conv(y, sole_consumer=True))

@@ -515,12 +515,47 @@ def _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, dy_pre, dy_out, weight, dil, gro
     return gw
 
 
+# ---- deferred dz: a BatchNorm backward that computes its incoming gradient from its producer's inputs (csrc/bn_dz_fused.hip) -------
+# The producer's backward (the 1x1 classifier's data gradient; the MCALayer's last step) does not run its kernel: it returns a STAND-IN
+# tensor of the right shape and registers what the BatchNorm backward needs under the stand-in's address; _ConvBN.backward picks it up.
+# Only used where the model code knows the tensor between the two nodes has exactly one consumer (so autograd hands the stand-in through
+# unchanged); an entry nobody consumed by the end of the backward pass is an error, not a silent garbage gradient.
+_FUSE_DZ = os.environ.get("EGM_FUSE_DZ", "1") != "0"
+_DEFERRED_DZ = {}
+
+
+def fuse_dz(enabled=None):
+    """Get / set whether BatchNorm backward computes dz on the fly from the classifier / MCALayer behind it (tests compare both ways)."""
+    global _FUSE_DZ
+    if enabled is not None:
+        _FUSE_DZ = bool(enabled)
+    return _FUSE_DZ
+
+
+def _check_deferred_dz():
+    if _DEFERRED_DZ:
+        kinds = [v[1][0] for v in _DEFERRED_DZ.values()]
+        _DEFERRED_DZ.clear()
+        raise RuntimeError(f"egm_unet_amd: deferred BatchNorm gradients {kinds} were never consumed (the tensor between the producer and "
+                           "its BatchNorm had another consumer); call ops.fuse_dz(False)")
+
+
+def _defer_dz(standin, payload):
+    if not _DEFERRED_DZ:
+        Variable._execution_engine.queue_callback(_check_deferred_dz)
+    _DEFERRED_DZ[standin.data_ptr()] = (standin, payload)          # the stand-in stays alive: its address cannot be recycled meanwhile
+
+
+def _dz_fusable(C):
+    return _FUSE_DZ and not _FUSE_BN_BWD and C % 8 == 0 and C <= 1024 and 256 % (C // 8) == 0
+
+
 class _Conv2d(Function):
     """nn.Conv2d (stride 1, same padding) on NHWC activations; weight stays the fp32 OIHW nn.Parameter.  The input may be a logical
     tensor (x = stand-in, x_coef / x_act = its BatchNorm + activation, applied by the kernels' operand prologue)."""
 
     @staticmethod
-    def forward(ctx, x, x_coef, x_act, weight, bias, dil, groups, want_stats, bias_grad_zero=False):
+    def forward(ctx, x, x_coef, x_act, weight, bias, dil, groups, want_stats, bias_grad_zero=False, defer_dgrad=False):
         x, ldx = _nhwc(x)
         Cout, Cin_g = weight.shape[0], weight.shape[1]
         y, stats, wd = _conv_forward(x, ldx, x_coef, x_act, weight, bias, dil, groups, want_stats)
@@ -529,6 +564,9 @@ class _Conv2d(Function):
         ctx.save_for_backward(x, weight, wd, x_coef)
         ctx.meta = (dil, groups, bias is not None, Cin_g * groups, Cout, x_act)
         ctx.bias_grad_zero = bias_grad_zero
+        # the caller vouches that x is the materialised output of a conv -> BatchNorm(+act) node and has no other consumer
+        ctx.defer_dgrad = bool(defer_dgrad and x_coef is None and weight.shape[2] == 1 and weight.shape[3] == 1 and groups == 1
+                               and Cout <= 8 and weight.is_contiguous() and _dz_fusable(x.shape[3]))
         ctx.set_materialize_grads(False)                # no zero-filled "gradient" for the non-differentiable stats output
         if want_stats:
             ctx.mark_non_differentiable(stats)
@@ -538,7 +576,7 @@ class _Conv2d(Function):
     @staticmethod
     def backward(ctx, gy, *_):
         if gy is None:
-            return (None,) * 9
+            return (None,) * 10
         x, weight, wd, x_coef = ctx.saved_tensors
         dil, groups, has_bias, Cin, Cout, x_act = ctx.meta
         gy, ldg = _nhwc(gy)
@@ -550,18 +588,41 @@ class _Conv2d(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=x.device)
-            L.call("egm_conv_fwd", dt, ptr(gy), ldg, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
+            if ctx.defer_dgrad and _FUSE_DZ:
+                # never written: the BatchNorm backward in front computes dz = gy * W per vector itself (egm_bn_cls_bwd_*)
+                _defer_dz(gx, ("cls", gy, ldg, weight.detach(), Cout, Cin))
+            else:
+                L.call("egm_conv_fwd", dt, ptr(gy), ldg, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
         if ctx.needs_input_grad[3]:
             gw = _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, None, None, weight, dil, groups, Cin, Cout)
         if has_bias and ctx.needs_input_grad[4]:
             gb = _zero_grad_vec(Cout, x.device) if ctx.bias_grad_zero else _channel_sum(gy)[0, :Cout]
-        return gx, None, None, gw, gb, None, None, None, None
+        return gx, None, None, gw, gb, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, dil=1, groups=1, want_stats=False, bias_grad_zero=False):
-    """x: NHWC tensor or Lazy (consumed through the conv's operand prologue, never materialised)."""
+def conv2d(x, weight, bias=None, dil=1, groups=1, want_stats=False, bias_grad_zero=False, defer_dgrad=False):
+    """x: NHWC tensor or Lazy (consumed through the conv's operand prologue, never materialised).
+    defer_dgrad: x is the materialised result of ops.conv_bn_act and feeds nothing else -- a 1x1 conv to <= 8 channels (the classifier)
+    then leaves its data gradient to that BatchNorm's backward (see _defer_dz)."""
     xt, xc, xa = _unlazy(x)
-    return _Conv2d.apply(xt, xc, xa, weight, bias, dil, groups, want_stats, bias_grad_zero)
+    return _Conv2d.apply(xt, xc, xa, weight, bias, dil, groups, want_stats, bias_grad_zero, defer_dgrad)
+
+
+def _conv_dgrad(dy, wd, N, H, W, CoutP, CinP, KH, KW, dil, x_split):
+    """Data gradient of a conv from dy [N,H,W,CoutP] (contiguous).  x_split > 0: written as two dense tensors (the gradients of the
+    two concatenated inputs) when the kernel supports it; the returned tensor is then a never-written stand-in registered for the
+    concat's backward."""
+    L, dt, st = lib(), dtype_code(dy.dtype), stream()
+    gx = torch.empty((N, H, W, CinP), dtype=dy.dtype, device=dy.device)
+    if x_split and _FUSE_DZ and L.cdll.egm_conv_split_ok(dt, N, H, W, CoutP, CinP, KH, KW, dil, x_split):
+        ga = torch.empty((N, H, W, x_split), dtype=dy.dtype, device=dy.device)
+        gb = torch.empty((N, H, W, CinP - x_split), dtype=dy.dtype, device=dy.device)
+        L.call("egm_conv_fwd_split", dt, ptr(dy), CoutP, ptr(wd), ptr(ga), x_split, ptr(gb), CinP - x_split, x_split, N, H, W, CoutP, CinP,
+               KH, KW, dil, st)
+        _defer_dz(gx, ("split", ga, gb))
+    else:
+        L.call("egm_conv_fwd", dt, ptr(dy), CoutP, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
+    return gx
 
 
 class _ConvBN(Function):
@@ -574,8 +635,12 @@ class _ConvBN(Function):
               pass in either direction."""
 
     @staticmethod
-    def forward(ctx, x, x_coef, x_act, weight, bias, gamma, beta, running_mean, running_var, eps, momentum, act, training, dil, groups):
+    def forward(ctx, x, x_coef, x_act, weight, bias, gamma, beta, running_mean, running_var, eps, momentum, act, training, dil, groups,
+                x_split=0):
+        """x_split = Cs > 0: x is a channel concatenation [Cs | rest] with no other consumer (ops.upcat): backward writes the gradient
+        as two dense tensors where the kernel can (egm_conv_fwd_split) and hands them to the concat's backward (see _defer_dz)."""
         x, ldx = _nhwc(x)
+        ctx.x_split = int(x_split) if (x_coef is None and x_split and 0 < x_split < x.shape[3] and x_split % 8 == 0) else 0
         Cout, Cin_g = weight.shape[0], weight.shape[1]
         y, stats, wd = _conv_forward(x, ldx, x_coef, x_act, weight, bias, dil, groups, training)
         CoutP, npix, dev = y.shape[3], _npix(y), y.device
@@ -598,9 +663,10 @@ class _ConvBN(Function):
     @staticmethod
     def backward(ctx, gz, _):
         if gz is None:
-            return (None,) * 15
+            return (None,) * 16
         x, weight, wd, x_coef, y, coef = ctx.saved_tensors
         dil, groups, has_bias, Cin, Cout, x_act, act, training = ctx.meta
+        pend = _DEFERRED_DZ.pop(gz.data_ptr(), None) if _DEFERRED_DZ else None      # gz is a stand-in: dz comes from its producer's inputs
         gz, ldg = _nhwc(gz)
         x, ldx = _nhwc(x)
         y, ldy = _nhwc(y)
@@ -611,13 +677,36 @@ class _ConvBN(Function):
         scale, shift, mean, rstd = coef[0], coef[1], coef[2], coef[3]
         nb = L.query("egm_channel_partials_blocks", npix, CoutP)
         part = _f32(nb * 2 * CoutP, dev)
-        L.call("egm_bn_act_bwd_reduce", dt, ptr(gz), ldg, ptr(y), ldy, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), act, ptr(part),
-               npix, CoutP, st)
         sums, cf4 = _f32((2, CoutP), dev), _f32((4, CoutP), dev)
-        L.call("egm_bn_bwd_coefs", ptr(part), nb, npix, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), 1 if training else 0, ptr(sums),
-               ptr(cf4), CoutP, st)
+        train = 1 if training else 0
         need_gx, need_gw = ctx.needs_input_grad[0], ctx.needs_input_grad[3]
         gx = gw = gb = dy = None
+        if pend is not None:
+            kind = pend[1][0]
+            dy = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev)
+            if kind == "cls":
+                _, dl, lddl, wcls, nc, ldw = pend[1]
+                head = ("egm_bn_cls", (dt, ptr(dl), lddl, ptr(wcls), nc, ldw), (npix, CoutP))
+            else:
+                _, dxo, ldd, gates, mcoef, ns, geo = pend[1]
+                head = ("egm_bn_mca", (dt, ptr(dxo), ldd, ptr(gates), ptr(mcoef), ns), geo + (CoutP,))
+            L.call(head[0] + "_bwd_reduce", *head[1], ptr(y), ldy, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), act, ptr(part), *head[2], st)
+            L.call("egm_bn_bwd_coefs", ptr(part), nb, npix, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), train, ptr(sums), ptr(cf4), CoutP, st)
+            L.call(head[0] + "_bwd_apply", *head[1], ptr(y), ldy, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), act, train, ptr(sums),
+                   ptr(dy), CoutP, *head[2], st)
+            if need_gw:
+                gw = _conv_wgrad(x, ldx, x_coef, x_act, dy, CoutP, None, None, weight, dil, groups, Cin, Cout)
+            if need_gx:
+                gx = _conv_dgrad(dy, wd, N, H, W, CoutP, CinP, KH, KW, dil, ctx.x_split)
+            if has_bias and ctx.needs_input_grad[4]:
+                gb = _zero_grad_vec(Cout, dev)
+            ggamma = sums[1, :Cout] if ctx.needs_input_grad[5] else None
+            gbeta = sums[0, :Cout] if ctx.needs_input_grad[6] else None
+            return gx, None, None, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None, None
+        L.call("egm_bn_act_bwd_reduce", dt, ptr(gz), ldg, ptr(y), ldy, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), act, ptr(part),
+               npix, CoutP, st)
+        L.call("egm_bn_bwd_coefs", ptr(part), nb, npix, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), train, ptr(sums),
+               ptr(cf4), CoutP, st)
         if need_gx:
             dy = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev)
         if need_gw and _FUSE_BN_BWD:
@@ -631,13 +720,12 @@ class _ConvBN(Function):
             if need_gw:
                 gw = _conv_wgrad(x, ldx, x_coef, x_act, dy, CoutP, None, None, weight, dil, groups, Cin, Cout)
         if need_gx:
-            gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=dev)
-            L.call("egm_conv_fwd", dt, ptr(dy), CoutP, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
+            gx = _conv_dgrad(dy, wd, N, H, W, CoutP, CinP, KH, KW, dil, ctx.x_split)
         if has_bias and ctx.needs_input_grad[4]:
             gb = _zero_grad_vec(Cout, dev)              # a conv bias feeding a BatchNorm has an identically zero gradient
         ggamma = sums[1, :Cout] if ctx.needs_input_grad[5] else None
         gbeta = sums[0, :Cout] if ctx.needs_input_grad[6] else None
-        return gx, None, None, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None
+        return gx, None, None, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None, None
 
 
 # environment switch for A/B runs: the max pool at a skip connection fused into its producer / consumer (csrc/pool_fused.hip)
@@ -1125,7 +1213,7 @@ def conv_bn_act(x, conv, bn, act, dil=1, groups=1, out=None, lazy=False):
         x = materialize(x)
     xt, xc, xa = _unlazy(x)
     y, coef = _ConvBN.apply(xt, xc, xa, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, act,
-                            training, dil, groups)
+                            training, dil, groups, getattr(x, "_egm_split", 0))
     z = Lazy(y, coef, act)
     return z if (lazy and out is None and _FUSE_BN) else z.materialize(out)
 
@@ -1227,8 +1315,17 @@ class _UpCat(Function):
     @staticmethod
     def backward(ctx, g):
         N, Hs, Ws, Cs, Hl, Wl, Cl = ctx.shape
-        g, ldo = _nhwc(g)
+        pend = _DEFERRED_DZ.pop(g.data_ptr(), None) if _DEFERRED_DZ else None
         gskip = glow = None
+        if pend is not None:                           # the conv behind the concat wrote the two halves of its gradient as dense tensors
+            _, ga, gb = pend[1]
+            if ctx.needs_input_grad[0]:
+                gskip = ga
+            if ctx.needs_input_grad[1]:
+                glow = torch.empty((N, Hl, Wl, Cl), dtype=gb.dtype, device=gb.device)
+                lib().call("egm_upcat_bwd_low", dtype_code(gb.dtype), ptr(gb), Cl, ptr(glow), Cl, N, Hs, Ws, 0, Hl, Wl, Cl, stream())
+            return gskip, glow, None
+        g, ldo = _nhwc(g)
         if ctx.needs_input_grad[0]:
             gskip = g[..., :Cs]                        # a view: consumers take (ptr, ld)
         if ctx.needs_input_grad[1]:
@@ -1239,7 +1336,11 @@ class _UpCat(Function):
 
 def upcat(skip, low, catbuf=None):
     """catbuf: the concat destination whose first channels ARE `skip` (see cat_slots), or None for a fresh tensor + copy."""
-    return _UpCat.apply(skip, low, None if catbuf is None else [catbuf])
+    out = _UpCat.apply(skip, low, None if catbuf is None else [catbuf])
+    # a hint for the conv that consumes the concatenation (its only consumer in Up.forward, src/EGM-UNet.py:947-949): the gradient may come
+    # back as two dense tensors, split at this channel (ops._conv_dgrad).  Lost -- harmlessly -- if the tensor passes through anything else.
+    out._egm_split = skip.shape[3]
+    return out
 
 
 class _Fork2(Function):
@@ -2093,7 +2194,7 @@ class _MCALayer(Function):
     """wc / kc None: MCALayer(no_spatial=True) -- two gates, x_out = x*(g_h+g_w)/2 (src/EGM-UNet.py:766-771)"""
 
     @staticmethod
-    def forward(ctx, x, x_coef, x_act, wh, kh, ww, kw, wc, kc, training):
+    def forward(ctx, x, x_coef, x_act, wh, kh, ww, kw, wc, kc, training, exclusive=False):
         """x_coef / x_act: x is a Lazy's stand-in (the raw output of the conv in front; ops.Lazy): its BatchNorm + activation is applied
         by the statistics pass, which writes the materialised tensor on the way (egm_mca_reduce_bn)."""
         x, ldx = _nhwc(x)
@@ -2123,6 +2224,9 @@ class _MCALayer(Function):
         if training:
             ctx.save_for_backward(x, xo, codes, stats, o, gates, *ps)
             ctx.ks = ks
+            # exclusive: the caller vouches that the conv -> BatchNorm stand-in this layer materialised feeds nothing else, so the last
+            # backward step (dx) can be left to that BatchNorm's backward (see _defer_dz)
+            ctx.defer_dx = bool(exclusive and x_coef is not None and _dz_fusable(C))
         return out
 
     @staticmethod
@@ -2147,15 +2251,19 @@ class _MCALayer(Function):
         dks = _f32((3, 8), dev, zero=True)
         L.call("egm_mca_gates_bwd", ptr(dG), ptr(stats), ptr(o), ptr(gates), ptr(wh), ptr(kh), ks[0], ptr(ww), ptr(kw), ks[1],
                None if ns else ptr(pc[0]), None if ns else ptr(pc[1]), ks[2], ptr(dz), ptr(coef), ptr(dwts), ptr(dks), N, H, W, C, st)
-        dx = torch.empty((N, H, W, C), dtype=x.dtype, device=dev)
-        L.call("egm_mca_bwd_dx", dt, ptr(dxo), C, ptr(x), ldx, ptr(gates), ptr(coef), ptr(dx), C, N, H, W, C, ns, st)
+        if ctx.defer_dx and _FUSE_DZ:
+            dx = dxo                                            # stand-in: the BatchNorm backward in front evaluates dx per vector itself
+            _defer_dz(dxo, ("mca", dxo, C, gates, coef, ns, (N, H, W)))
+        else:
+            dx = torch.empty((N, H, W, C), dtype=x.dtype, device=dev)
+            L.call("egm_mca_bwd_dx", dt, ptr(dxo), C, ptr(x), ldx, ptr(gates), ptr(coef), ptr(dx), C, N, H, W, C, ns, st)
         gk = [dks[a, :ks[a]].reshape(1, 1, 1, ks[a]) for a in range(2 if ns else 3)]
         if ns:
-            return dx, None, None, dwts[0], gk[0], dwts[1], gk[1], None, None, None
-        return dx, None, None, dwts[0], gk[0], dwts[1], gk[1], dwts[2], gk[2], None
+            return dx, None, None, dwts[0], gk[0], dwts[1], gk[1], None, None, None, None
+        return dx, None, None, dwts[0], gk[0], dwts[1], gk[1], dwts[2], gk[2], None, None
 
 
-def mca_layer(x, layer, training):
+def mca_layer(x, layer, training, exclusive=False):
     """layer: an MCALayer parameter holder with gates h_cw, w_hc and -- unless layer.no_spatial -- c_hw
     (each: .weight [2], .conv.weight [1,1,1,k])."""
     c = (None, None) if layer.no_spatial else (layer.c_hw.weight, layer.c_hw.conv.weight)
@@ -2164,7 +2272,7 @@ def mca_layer(x, layer, training):
     if xc is not None and not (8 <= C <= 512 and (C & (C - 1)) == 0):
         xt, xc, xa = materialize(x), None, ACT_NONE
     return _MCALayer.apply(xt, xc, xa, layer.h_cw.weight, layer.h_cw.conv.weight, layer.w_hc.weight, layer.w_hc.conv.weight, c[0], c[1],
-                           training)
+                           training, exclusive and xc is not None)
 
 
 class _SAConv7(Function):

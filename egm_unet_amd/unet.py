@@ -77,8 +77,10 @@ class OutConv(nn.Sequential):
     def __init__(self, in_channels, num_classes):
         super().__init__(nn.Conv2d(in_channels, num_classes, kernel_size=1))
 
-    def forward(self, x):
-        return ops.conv2d(x, self[0].weight, self[0].bias)
+    def forward(self, x, sole_consumer=False):
+        """sole_consumer: x is the materialised output of a DoubleConv and feeds nothing but this classifier (then the classifier's data
+        gradient is evaluated inside that BatchNorm's backward instead of being written out; ops.conv2d defer_dgrad)."""
+        return ops.conv2d(x, self[0].weight, self[0].bias, defer_dgrad=sole_consumer and not isinstance(x, ops.Lazy))
 
 
 class _SegNetBase(nn.Module):
@@ -156,4 +158,4 @@ class UNet(_SegNetBase):
         y = self.up2(y, x3s)
         y = self.up3(y, x2s)
         y = self.up4(y, x1s, lazy=True)                          # the 1x1 classifier applies up4's last BatchNorm+ReLU itself
-        return self._exit(self.out_conv(y))
+        return self._exit(self.out_conv(y, sole_consumer=True))

@@ -93,6 +93,13 @@ int egm_conv_tile_debug(int dbg);
  * 1 = the weights-in-registers v_mfma_f32_16x16x32_bf16 kernel (csrc/conv7x7_c16.hip; default, env EGM_CONV_C7), 0 = the generic
  * pipelined kernel, -1 = query only.  Returns the previous mode (A/B timing and parity tests). */
 int egm_conv_c7_mode(int mode);
+/* egm_conv_fwd with the output channels written to TWO tensors: couts [0, csplit) to y (pixel stride ldy), [csplit, Cout) to y2
+ * (pixel stride ldy2).  The data gradient of the conv behind a channel concatenation (Up, src/EGM-UNet.py:947-949) written as the
+ * gradients of the two concatenated tensors, each dense, instead of one interleaved tensor whose halves the consumers read as half
+ * cache lines.  No bias, no statistics.  Supported where egm_conv_split_ok() says so (the 8-wave 3x3 kernel, csplit % 8 == 0). */
+int egm_conv_split_ok(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int csplit);
+int egm_conv_fwd_split(int dtype, const void* x, int ldx, const void* wf, void* y, int ldy, void* y2, int ldy2, int csplit, int N,
+                       int H, int W, int Cin, int Cout, int KH, int KW, int dil, egm_stream_t s);
 /* Name of the kernel egm_conv_fwd_pre launches for a shape, spelled like the rows of a rocprofv3 kernel trace (e.g.
  * "conv_igemm_pipe_kernel<2, 3, 3, 2, 0>"); returns its length, copies at most buflen-1 characters into buf (may be NULL). */
 int egm_conv_kernel_name(int dtype, int pre_mode, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen);
@@ -180,6 +187,25 @@ int egm_bn_act_bwd_reduce(int dtype, const void* dz, int lddz, const void* y, in
 int egm_bn_act_bwd_apply(int dtype, const void* dz, int lddz, const void* y, int ldy, const float* scale,
                          const float* shift, const float* save_mean, const float* save_rstd, int act, int train,
                          const float* sums, void* dy, int lddy, long long npix, int C, egm_stream_t s);
+/* BatchNorm backward with dz computed on the fly from its producer (csrc/bn_dz_fused.hip), the two passes of egm_bn_act_bwd_reduce /
+ * egm_bn_act_bwd_apply (same partials geometry: egm_channel_partials_blocks(npix, C) blocks; C/8 must divide 256):
+ *   _cls_: dz[p][c] = sum_{k < nc} dlogits[p][k]*w_cls[k*ldw + c] -- the data gradient of the 1x1 classifier behind the last
+ *          BatchNorm+ReLU (OutConv, src/EGM-UNet.py:952-956): its conv launch and the tensor it wrote do not exist.  nc <= 8; w_cls is the
+ *          fp32 OIHW weight [nc][ldw] (rounded to `dtype` inside, like the conv's operand pack); dlogits has >= 8 channels per pixel.
+ *   _mca_: dz = dxo*(g_h + g_w + g_c)*inv + (A + B*x) -- the MCALayer's last backward step (egm_mca_bwd_dx) behind DoubleConv1's first
+ *          BatchNorm+ReLU (src/EGM-UNet.py:893-896), x being this BatchNorm's own output, recomputed from y. */
+int egm_bn_cls_bwd_reduce(int dtype, const void* dlogits, int lddl, const float* w_cls, int nc, int ldw, const void* y, int ldy,
+                          const float* scale, const float* shift, const float* save_mean, const float* save_rstd, int act,
+                          float* partials, long long npix, int C, egm_stream_t s);
+int egm_bn_cls_bwd_apply(int dtype, const void* dlogits, int lddl, const float* w_cls, int nc, int ldw, const void* y, int ldy,
+                         const float* scale, const float* shift, const float* save_mean, const float* save_rstd, int act, int train,
+                         const float* sums, void* dy, int lddy, long long npix, int C, egm_stream_t s);
+int egm_bn_mca_bwd_reduce(int dtype, const void* dxo, int ldd, const float* gates, const float* coef, int no_spatial, const void* y,
+                          int ldy, const float* scale, const float* shift, const float* save_mean, const float* save_rstd, int act,
+                          float* partials, int N, int H, int W, int C, egm_stream_t s);
+int egm_bn_mca_bwd_apply(int dtype, const void* dxo, int ldd, const float* gates, const float* coef, int no_spatial, const void* y,
+                         int ldy, const float* scale, const float* shift, const float* save_mean, const float* save_rstd, int act,
+                         int train, const float* sums, void* dy, int lddy, int N, int H, int W, int C, egm_stream_t s);
 /* Second stage of the backward when dy is consumed as a logical tensor (EGM_PRE_BN_BWD): partial tiles of egm_bn_act_bwd_reduce
  * -> sums [2][C] (dbeta | dgamma) and cf [4][C] = scale | shift | cb | cc with dy = scale*dzp + cb + cc*y; replaces
  * egm_reduce_tiles + egm_bn_act_bwd_apply (same arithmetic: the two forms of dy agree bit for bit). */

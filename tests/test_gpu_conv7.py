@@ -51,3 +51,26 @@ def test_conv7x7_c16_matches_generic_kernel_and_torch(shape, with_bias):
     ref, dref = yr.detach().permute(0, 2, 3, 1), xr.grad.permute(0, 2, 3, 1)
     assert float((y1.float() - ref).abs().max()) <= 1e-2 * max(1.0, float(ref.abs().max()))
     assert float((dx1.float() - dref).abs().max()) <= 1e-2 * max(1.0, float(dref.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(8, 128, 128, 32, 64, 32), (2, 256, 256, 32, 64, 32), (4, 64, 64, 128, 256, 128), (2, 100, 132, 64, 128, 64)])
+def test_conv_fwd_split_equals_one_output(shape):
+    """egm_conv_fwd_split (the data gradient behind a channel concatenation written as two dense tensors) == the channel slices of
+    egm_conv_fwd's single output, bit for bit."""
+    from egm_unet_amd._lib import dtype_code, lib, ptr, stream
+    N, H, W, Cin, Cout, cs = shape
+    L, dt = lib(), dtype_code(torch.bfloat16)
+    if not L.cdll.egm_conv_split_ok(dt, N, H, W, Cin, Cout, 3, 3, 1, cs):
+        pytest.skip("shape does not take the tile kernel")
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(N, H, W, Cin, generator=g).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(DEV)
+    wf = torch.empty(9 * Cout * Cin, dtype=torch.bfloat16, device=DEV)
+    L.call("egm_conv_pack", dt, ptr(w), ptr(wf), None, Cout, Cin, 3, 3, 1, stream())
+    y = torch.empty(N, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+    L.call("egm_conv_fwd", dt, ptr(x), Cin, ptr(wf), None, 0, ptr(y), Cout, None, N, H, W, Cin, Cout, 3, 3, 1, stream())
+    ya = torch.full((N, H, W, cs), 7.0, dtype=torch.bfloat16, device=DEV)
+    yb = torch.full((N, H, W, Cout - cs), 7.0, dtype=torch.bfloat16, device=DEV)
+    L.call("egm_conv_fwd_split", dt, ptr(x), Cin, ptr(wf), ptr(ya), cs, ptr(yb), Cout - cs, cs, N, H, W, Cin, Cout, 3, 3, 1, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(ya, y[..., :cs]) and torch.equal(yb, y[..., cs:])

@@ -156,3 +156,40 @@ def test_model_with_mca_statistics_pass_applying_batchnorm_is_identical(dtype):
         assert torch.equal(outs[0][1][k], outs[1][1][k]), k
     for k in outs[0][2]:
         assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+
+
+@pytest.mark.parametrize("model_kind", ["egm", "unet"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_model_with_deferred_dz_matches_separate_kernels(dtype, model_kind):
+    """BatchNorm backward computing dz from the classifier's / the MCALayer's inputs (csrc/bn_dz_fused.hip, ops.fuse_dz) against the
+    separate data-gradient conv / egm_mca_bwd_dx kernels: identical logits, every gradient to rounding / summation-order noise."""
+    from egm_unet_amd import GRFBUNet, UNet, ops
+    from oracle import egm_ref as R
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(2, 3, 64, 64, generator=g).to(DEV)
+    gl = torch.randn(2, 2, 64, 64, generator=g).to(DEV)
+    st = R.make_egm_unet_state(3, 2, 8, seed=13) if model_kind == "egm" else None
+    default = ops.fuse_dz()
+    outs = []
+    try:
+        for fused in (True, False):
+            ops.fuse_dz(fused)
+            torch.manual_seed(3)
+            m = GRFBUNet(3, 2, base_c=8) if model_kind == "egm" else UNet(3, 2, base_c=8)
+            if st is not None:
+                m.load_state_dict(st, strict=True)
+            m.to(DEV).train().set_compute_dtype(dtype)
+            out = m(x)["out"]
+            out.backward(gl)
+            torch.cuda.synchronize()
+            outs.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    finally:
+        ops.fuse_dz(default)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1].keys() == outs[1][1].keys()
+    worst, big = 0.0, max(float(v.float().norm()) for v in outs[1][1].values())
+    for k in outs[0][1]:
+        a, b = outs[0][1][k].float(), outs[1][1][k].float()
+        if float(b.norm()) > 1e-5 * big:
+            worst = max(worst, float((a - b).norm() / b.norm()))
+    assert worst <= (2e-4 if dtype == torch.float32 else 0.1), worst
