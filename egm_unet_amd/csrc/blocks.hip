@@ -27,8 +27,8 @@ __device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); 
 template <typename T>
 __global__ void highpass3_kernel(const T* __restrict__ x, int ldx, T* __restrict__ out, int ldo, int N, int H, int W, int C) {
     PIX_LOOP((long long)N * H * W * ncv) {
-        const int cv = (int)(i % ncv); const long long p = i / ncv;
-        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
+        int xx, yy; egm_pix_yx(p, H, W, yy, xx);
         float s[8], c[8], v[8];
         zero8(s);
         load8(x + p * ldx + cv * 8, c);
@@ -52,7 +52,7 @@ template <typename T>
 __global__ void gate_mul_fwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ w, int ldw, T* __restrict__ out, int ldo,
                                     long long npix, int C) {
     PIX_LOOP(npix * ncv) {
-        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
         float a[8], b[8];
         load8(x + p * ldx + cv * 8, a); load8(w + p * ldw + cv * 8, b);
 #pragma unroll
@@ -64,7 +64,7 @@ template <typename T>
 __global__ void gate_mul_bwd_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ x, int ldx, const T* __restrict__ w, int ldw,
                                     T* __restrict__ dx, int lddx, T* __restrict__ dw, int lddw, long long npix, int C) {
     PIX_LOOP(npix * ncv) {
-        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
         float gg[8], a[8], b[8], o1[8], o2[8];
         load8(g + p * ldg + cv * 8, gg); load8(x + p * ldx + cv * 8, a); load8(w + p * ldw + cv * 8, b);
 #pragma unroll
@@ -78,7 +78,7 @@ template <typename T>
 __global__ void scale_add_relu_fwd_kernel(const T* __restrict__ a, int lda, float alpha, const T* __restrict__ b, int ldb,
                                           T* __restrict__ out, int ldo, long long npix, int C) {
     PIX_LOOP(npix * ncv) {
-        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
         float u[8], v[8];
         load8(a + p * lda + cv * 8, u); load8(b + p * ldb + cv * 8, v);
 #pragma unroll
@@ -90,7 +90,7 @@ template <typename T>   // mask from the stored output (> 0)
 __global__ void scale_add_relu_bwd_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ out, int ldo, float alpha,
                                           T* __restrict__ da, int ldda, T* __restrict__ db, int lddb, long long npix, int C) {
     PIX_LOOP(npix * ncv) {
-        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
         float gg[8], o[8], u[8];
         load8(g + p * ldg + cv * 8, gg); load8(out + p * ldo + cv * 8, o);
 #pragma unroll
@@ -113,7 +113,7 @@ template <typename T>
 __global__ void gate3_fwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ t, int ldt, T* __restrict__ out, int ldo,
                                  long long npix, int C) {
     PIX_LOOP(npix * ncv) {
-        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
         float a[8], tv[8];
         load8(x + p * ldx + cv * 8, a); load8(t + p * ldt, tv);
         const float m = 1.f + (sigm(tv[0]) + sigm(tv[1]) + sigm(tv[2])) * (1.f / 3.f);
@@ -159,7 +159,7 @@ template <typename T>
 __global__ void bcast_gate_fwd_kernel(const T* __restrict__ a, int lda, const T* __restrict__ gl, int ldgl, T* __restrict__ out, int ldo,
                                       long long npix, int C) {
     PIX_LOOP(npix * ncv) {
-        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
         float u[8];
         load8(a + p * lda + cv * 8, u);
         const float s = sigm(to_f32(gl[p * ldgl]));
@@ -200,7 +200,7 @@ __global__ void bcast_gate_bwd_kernel(const T* __restrict__ g, int ldg, const T*
 template <typename T>
 __global__ void gelu_fwd_kernel(const T* __restrict__ x, int ldx, T* __restrict__ out, int ldo, long long npix, int C) {
     PIX_LOOP(npix * ncv) {
-        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
         float v[8];
         load8(x + p * ldx + cv * 8, v);
 #pragma unroll
@@ -212,7 +212,7 @@ template <typename T>
 __global__ void gelu_bwd_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ x, int ldx, T* __restrict__ dx, int lddx,
                                 long long npix, int C) {
     PIX_LOOP(npix * ncv) {
-        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
         float gg[8], v[8];
         load8(g + p * ldg + cv * 8, gg); load8(x + p * ldx + cv * 8, v);
 #pragma unroll
@@ -350,7 +350,7 @@ template <typename T>
 __global__ void global_pool_bwd_kernel(const T* __restrict__ gout, const int* __restrict__ argidx, T* __restrict__ dx, int lddx, int N,
                                        long long HW, int C) {
     PIX_LOOP((long long)N * HW * ncv) {
-        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
         const long long n = p / HW, pp = p - n * HW;
         float ga[8], gm[8], o[8];
         load8(gout + n * C + cv * 8, ga); load8(gout + (N + n) * C + cv * 8, gm);
@@ -365,7 +365,7 @@ template <typename T>
 __global__ void fusion_combine_fwd_kernel(const T* __restrict__ f, int ldf, const T* __restrict__ sv, int lds, const T* __restrict__ sa,
                                           int ldsa, const T* __restrict__ ca, T* __restrict__ out, int ldo, int N, long long HW, int C) {
     PIX_LOOP((long long)N * HW * ncv) {
-        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
         const long long n = p / HW;
         float a[8], b[8], c1[8], c2[8];
         load8(f + p * ldf + cv * 8, a); load8(sv + p * lds + cv * 8, b);
@@ -484,7 +484,7 @@ template <typename T>
 __global__ void sa_conv7_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, T* __restrict__ y, int ldy, int N, int H, int W) {
     const long long total = (long long)N * H * W;
     for (long long p = blockIdx.x * 256LL + threadIdx.x; p < total; p += (long long)gridDim.x * 256) {
-        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        int xx, yy; egm_pix_yx(p, H, W, yy, xx);
         float acc = 0.f;
 #pragma unroll
         for (int r = 0; r < 7; ++r) {
@@ -509,7 +509,7 @@ __global__ void sa_conv7_bwd_data_kernel(const T* __restrict__ dy, int lddy, con
                                          int H, int W) {
     const long long total = (long long)N * H * W;
     for (long long p = blockIdx.x * 256LL + threadIdx.x; p < total; p += (long long)gridDim.x * 256) {
-        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        int xx, yy; egm_pix_yx(p, H, W, yy, xx);
         float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int r = 0; r < 7; ++r) {

@@ -65,8 +65,8 @@ template <typename T> struct DzCtx<T, DZ_MCA> {
     int cur_n;
     __device__ __forceinline__ void init(const DzArgs&, int, int) { cur_n = -1; }
     __device__ __forceinline__ void dz(const DzArgs& d, long long p, int cv, const float (&z)[8], float (&g)[8]) {
-        const int w = (int)(p % d.W); const long long r = p / d.W;
-        const int h = (int)(r % d.H), n = (int)(r / d.H);
+        const unsigned pu = (unsigned)p, r = pu / (unsigned)d.W;            // npix < 2^31 (checked by the launcher): 32-bit divisions
+        const int w = (int)(pu - r * (unsigned)d.W), n = (int)(r / (unsigned)d.H), h = (int)(r - (unsigned)n * (unsigned)d.H);
         const float* gt = d.gates + (long long)n * d.L;
         const float* cf = d.coef + (long long)n * d.L * 2;
         if (n != cur_n) {
@@ -188,7 +188,8 @@ int fill_cls(DzArgs& d, const void* dl, int lddl, const float* w, int nc, int ld
     return EGM_OK;
 }
 int fill_mca(DzArgs& d, const void* dxo, int ldd, const float* gates, const float* coef, int N, int H, int W, int C, int no_spatial) {
-    EGM_REQUIRE(dxo && egm_aligned16(dxo) && ldd >= C && ldd % 8 == 0 && gates && coef && N > 0 && H > 0 && W > 0, "bn_mca_bwd: bad args");
+    EGM_REQUIRE(dxo && egm_aligned16(dxo) && ldd >= C && ldd % 8 == 0 && gates && coef && N > 0 && H > 0 && W > 0 &&
+                (long long)N * H * W < (1LL << 31), "bn_mca_bwd: bad args");
     d.a = dxo; d.lda = ldd; d.w = nullptr; d.nc = 0; d.ldw = 0; d.gates = gates; d.coef = coef; d.H = H; d.W = W; d.L = H + W + C;
     d.inv = no_spatial ? 0.5f : 1.f / 3.f;
     return EGM_OK;

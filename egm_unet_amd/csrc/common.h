@@ -121,6 +121,27 @@ static inline int egm_partial_blocks(long long npix, int C) {
     return (int)b;
 }
 
+// Index arithmetic of the streaming kernels without 64-bit divisions.  A 64-bit divide by a run-time value is ~60 VALU instructions on
+// this part (no hardware divider): the (item -> pixel, channel vector) and (pixel -> row, column) splits of an element-wise or stencil
+// kernel cost more than its arithmetic.  Channel-vector counts are powers of two in every network here (a shift); everything else is
+// a 32-bit divide whenever the index fits 32 bits (always, at these sizes); the 64-bit form remains as the exact fallback.
+__device__ __forceinline__ long long egm_udiv(long long a, int b) {
+    if ((b & (b - 1)) == 0) return a >> (31 - __builtin_clz((unsigned)b));
+    if ((unsigned long long)a < (1ull << 32)) return (long long)((unsigned)a / (unsigned)b);
+    return a / b;
+}
+__device__ __forceinline__ void egm_divmod(long long a, int b, long long& q, int& r) { q = egm_udiv(a, b); r = (int)(a - q * b); }
+// pixel index p of an [N, H, W] grid -> (row y, column x); n = p / (H*W) via egm_pix_nyx
+__device__ __forceinline__ void egm_pix_yx(long long p, int H, int W, int& y, int& x) {
+    long long r; egm_divmod(p, W, r, x);
+    long long n; egm_divmod(r, H, n, y);
+}
+__device__ __forceinline__ void egm_pix_nyx(long long p, int H, int W, int& n, int& y, int& x) {
+    long long r; egm_divmod(p, W, r, x);
+    long long nn; egm_divmod(r, H, nn, y);
+    n = (int)nn;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 // dtype dispatch for host launchers: body sees `T`

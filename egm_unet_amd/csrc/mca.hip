@@ -223,8 +223,8 @@ __global__ void mca_xout_kernel(const T* __restrict__ x, int ldx, const float* _
     const int ncv = C >> 3, L = H + W + C;
     const long long total = (long long)N * H * W * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv); const long long p = i / ncv;
-        const int w = (int)(p % W), h = (int)((p / W) % H), n = (int)(p / ((long long)W * H));
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
+        int w, h, n; egm_pix_nyx(p, H, W, n, h, w);
         const float* g = gates + (long long)n * L;
         const float ghw = g[h] + g[H + w];
         float v[8];
@@ -245,8 +245,8 @@ __global__ void mca_stencil1_kernel(const T* __restrict__ xo, int ld, T* __restr
     const int ncv = C >> 3;
     const long long total = (long long)N * H * W * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv); const long long p = i / ncv;
-        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
+        int xx, yy; egm_pix_yx(p, H, W, yy, xx);
         float c[8], mx[8], mn[8], s[8], v[8];
         int amx[8], amn[8];
         load8(xo + p * ld + cv * 8, c);
@@ -289,8 +289,8 @@ __global__ void add_avg3_kernel(const T* __restrict__ a, int lda, const T* __res
     const int ncv = C >> 3;
     const long long total = (long long)N * H * W * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv); const long long p = i / ncv;
-        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
+        int xx, yy; egm_pix_yx(p, H, W, yy, xx);
         float c[8], s[8], v[8];
         load8(a + p * lda + cv * 8, c);
         zero8(s);
@@ -486,8 +486,8 @@ __global__ void mca_bwd_du_kernel(const T* __restrict__ xo, int ld, const T* __r
     const int ncv = C >> 3;
     const long long total = (long long)N * H * W * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv); const long long p = i / ncv;
-        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
+        int xx, yy; egm_pix_yx(p, H, W, yy, xx);
         float c[8], s[8], sg[8], v[8];
         load8(xo + p * ld + cv * 8, c);
         zero8(s); zero8(sg);
@@ -515,8 +515,8 @@ __global__ void mca_bwd_dxo_kernel(const unsigned char* __restrict__ codes, cons
     const int ncv = C >> 3;
     const long long total = (long long)N * H * W * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv); const long long p = i / ncv;
-        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
+        int xx, yy; egm_pix_yx(p, H, W, yy, xx);
         float acc[8], sd[8], v[8], gp[8];
         zero8(acc); zero8(sd);
 #pragma unroll
@@ -554,8 +554,8 @@ __global__ void mca_bwd_dx_kernel(const T* __restrict__ dxo, int ldd, const T* _
     const int ncv = C >> 3, L = H + W + C;
     const long long total = (long long)N * H * W * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv); const long long p = i / ncv;
-        const int w = (int)(p % W), h = (int)((p / W) % H), n = (int)(p / ((long long)W * H));
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
+        int w, h, n; egm_pix_nyx(p, H, W, n, h, w);
         const float* g = gates + (long long)n * L;
         const float* cf = coef + (long long)n * L * 2;
         const float ghw = g[h] + g[H + w];

@@ -26,9 +26,10 @@ inline int stream_grid(long long total_threads) {
 }
 
 // window w of an [N, H, W] image grid with even H, W -> pixel index of its top-left corner and of the pooled pixel
-__device__ __forceinline__ void window_of(long long w, int Ho, int Wo, int W, long long& base, long long& pooled) {
-    const int ox = (int)(w % Wo); const long long r = w / Wo;            // r = n*Ho + oy
-    base = (r * 2) * W + 2 * ox;                                          // (n*H + 2*oy)*W + 2*ox with H = 2*Ho
+// (32-bit arithmetic: the launchers require N*H*W*C/8 < 2^31; a 64-bit division per item costs more than the item's arithmetic)
+__device__ __forceinline__ void window_of(unsigned w, int Ho, int Wo, int W, long long& base, long long& pooled) {
+    const unsigned r = w / (unsigned)Wo, ox = w - r * (unsigned)Wo;      // r = n*Ho + oy
+    base = ((long long)r * 2) * W + 2 * ox;                               // (n*H + 2*oy)*W + 2*ox with H = 2*Ho
     pooled = w;
 }
 
@@ -56,10 +57,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_pool_kernel(const T* __restric
     __syncthreads();
     const int ncv = C >> 3, W = Wo * 2;
     const long long total = nwin * ncv;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {
+        const unsigned wi = i / (unsigned)ncv;
+        const int cv = (int)(i - wi * (unsigned)ncv);
         long long base, pooled;
-        window_of(i / ncv, Ho, Wo, W, base, pooled);
+        window_of(wi, Ho, Wo, W, base, pooled);
         const long long off[4] = {base, base + 1, base + W, base + W + 1};
         float v[4][8], sc[8], sh[8], m[8];
 #pragma unroll
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T* __rest
     if (row < rows) {
         for (long long w = (long long)blockIdx.x * rows + row; w < nwin; w += (long long)gridDim.x * rows) {
             long long base, pooled;
-            window_of(w, Ho, Wo, W, base, pooled);
+            window_of((unsigned)w, Ho, Wo, W, base, pooled);
             const long long off[4] = {base, base + 1, base + W, base + W + 1};
             float yv[4][8], zr[4][8], gs[4][8], gp[8];
 #pragma unroll
@@ -151,10 +153,11 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
     __syncthreads();
     const int ncv = C >> 3, W = Wo * 2;
     const long long total = nwin * ncv;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {
+        const unsigned wi = i / (unsigned)ncv;
+        const int cv = (int)(i - wi * (unsigned)ncv);
         long long base, pooled;
-        window_of(i / ncv, Ho, Wo, W, base, pooled);
+        window_of(wi, Ho, Wo, W, base, pooled);
         const long long off[4] = {base, base + 1, base + W, base + W + 1};
         float yv[4][8], zr[4][8], gs[4][8], gp[8], sc[8], sh[8], cb[8], cc[8];
 #pragma unroll
@@ -182,10 +185,11 @@ __global__ __launch_bounds__(256) void gate3_fwd_pool_kernel(const T* __restrict
                                                              int ldo, T* __restrict__ pool, int ldp, long long nwin, int Ho, int Wo, int C) {
     const int ncv = C >> 3, W = Wo * 2;
     const long long total = nwin * ncv;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {
+        const unsigned wi = i / (unsigned)ncv;
+        const int cv = (int)(i - wi * (unsigned)ncv);
         long long base, pooled;
-        window_of(i / ncv, Ho, Wo, W, base, pooled);
+        window_of(wi, Ho, Wo, W, base, pooled);
         const long long off[4] = {base, base + 1, base + W, base + W + 1};
         float v[4][8], tv[4][8], m[8];
 #pragma unroll
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256) void gate3_pool_bwd_kernel(const T* __restrict
 #pragma unroll
         for (int k = 0; k < 4; ++k) zero8(tv[k]);
         if (w < nwin) {
-            window_of(w, Ho, Wo, W, base, pooled);
+            window_of((unsigned)w, Ho, Wo, W, base, pooled);
             const long long off[4] = {base, base + 1, base + W, base + W + 1};
             float gm[4];
 #pragma unroll
@@ -277,7 +281,8 @@ inline int group_for(int ncv) { int g = 1; while (g < ncv && g < 64) g <<= 1; re
     EGM_REQUIRE((ptr) != nullptr && egm_aligned16(ptr) && (C) > 0 && (C) % 8 == 0 && (ld) >= (C) && (ld) % 8 == 0, \
                 name ": bad tensor (ptr/alignment/C=%d/ld=%d)", (int)(C), (int)(ld))
 #define EGM_REQ_POOL_SHAPE(name) \
-    EGM_REQUIRE(N > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && C <= 1024, name ": H and W must be even, C <= 1024 (got %d x %d, C=%d)", H, W, C)
+    EGM_REQUIRE(N > 0 && H >= 2 && W >= 2 && !(H & 1) && !(W & 1) && C <= 1024 && (long long)N * H * W * (C / 8) < (1LL << 31), \
+                name ": H and W must be even, C <= 1024, N*H*W*C/8 < 2^31 (got %d x %d, C=%d)", H, W, C)
 #define EGM_GROUP_SWITCH(G, ...)                                                                \
     switch (G) { case 1: { constexpr int GROUP = 1; __VA_ARGS__; break; } case 2: { constexpr int GROUP = 2; __VA_ARGS__; break; } \
                  case 4: { constexpr int GROUP = 4; __VA_ARGS__; break; } case 8: { constexpr int GROUP = 8; __VA_ARGS__; break; } \

@@ -48,8 +48,8 @@ __global__ void maxpool2_fwd_kernel(const T* __restrict__ x, int ldx, T* __restr
     const int ncv = C >> 3, Ho = H >> 1, Wo = W >> 1;
     const long long total = (long long)N * Ho * Wo * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv); long long p = i / ncv;
-        const int ox = (int)(p % Wo); p /= Wo; const int oy = (int)(p % Ho); const int n = (int)(p / Ho);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
+        int n, oy, ox; egm_pix_nyx(p, Ho, Wo, n, oy, ox);
         const T* b = x + (((long long)n * H + 2 * oy) * W + 2 * ox) * ldx + cv * 8;
         float a[8], v[8];
         load8(b, a);
@@ -73,8 +73,8 @@ __global__ void maxpool2_bwd_kernel(const T* __restrict__ x, int ldx, const T* _
     const int ncv = C >> 3, Ho = H >> 1, Wo = W >> 1;
     const long long total = (long long)N * Ho * Wo * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv); long long p = i / ncv;
-        const int ox = (int)(p % Wo); p /= Wo; const int oy = (int)(p % Ho); const int n = (int)(p / Ho);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
+        int n, oy, ox; egm_pix_nyx(p, Ho, Wo, n, oy, ox);
         const long long base = (((long long)n * H + 2 * oy) * W + 2 * ox);
         float v[4][8], g[8], o[4][8];
         load8(x + base * ldx + cv * 8, v[0]);
@@ -113,8 +113,8 @@ __global__ void zero_tail_kernel(T* __restrict__ dx, int lddx, int N, int H, int
     const long long total = (long long)N * H * W * ncv;
     float z[8]; zero8(z);
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv); long long p = i / ncv;
-        const int xx = (int)(p % W); const int yy = (int)((p / W) % H);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
+        int xx, yy; egm_pix_yx(p, H, W, yy, xx);
         if (yy >= (H & ~1) || xx >= (W & ~1)) store8(dx + p * lddx + cv * 8, z);
     }
 }
@@ -147,7 +147,7 @@ __global__ void upcat_fwd_kernel(const T* __restrict__ skip, int lds, const T* _
         if (cv < ncs) {
             load8(skip + p * lds + cv * 8, v);
         } else {
-            const int x = (int)(p % Ws), y = (int)((p / Ws) % Hs), n = (int)(p / ((long long)Ws * Hs));
+            int x, y, n; egm_pix_nyx(p, Hs, Ws, n, y, x);
             const int uy = y - py, ux = x - px, c = (cv - ncs) * 8;
             zero8(v);
             if (uy >= 0 && uy < Hu && ux >= 0 && ux < Wu) {
@@ -181,7 +181,7 @@ __global__ void upcat_bwd_low_kernel(const T* __restrict__ dout, int ldo, T* __r
     const long long total = (long long)N * Hl * Wl * ncl;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int cv = (int)(i % ncl); long long p = i / ncl;
-        const int xl = (int)(p % Wl), yl = (int)((p / Wl) % Hl), n = (int)(p / ((long long)Wl * Hl));
+        int xl, yl, n; egm_pix_nyx(p, Hl, Wl, n, yl, xl);
         float acc[8]; zero8(acc);
         // the <= 6 candidate rows and columns of the up-sampled grid and their weights for THIS low-res pixel, computed once (the
         // first version evaluated the column interpolation inside the row loop: 42 coordinate computations per vector instead of 12,
@@ -307,8 +307,8 @@ __global__ void dwconv3_fwd_kernel(const T* __restrict__ x, int ldx, const float
     const long long total = (long long)N * H * W * ncv;
     const float sc = scale ? scale[0] : 1.f;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv); const long long p = i / ncv;
-        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
+        int xx, yy; egm_pix_yx(p, H, W, yy, xx);
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = b[cv * 8 + j];
@@ -339,8 +339,8 @@ __global__ void dwconv3_bwd_data_kernel(const T* __restrict__ dy, int lddy, cons
     const long long total = (long long)N * H * W * ncv;
     const float sc = scale ? scale[0] : 1.f;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv); const long long p = i / ncv;
-        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
+        int xx, yy; egm_pix_yx(p, H, W, yy, xx);
         float acc[8]; zero8(acc);
         for (int r = -1; r <= 1; ++r) {
             if (yy - r < 0 || yy - r >= H) continue;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void dwconv3_bwd_param_kernel(const T* __restr
     const long long npix = (long long)N * H * W;
     if (row < rows) {
         for (long long p = (long long)blockIdx.x * rows + row; p < npix; p += (long long)gridDim.x * rows) {
-            const int xx = (int)(p % W), yy = (int)((p / W) % H);
+            int xx, yy; egm_pix_yx(p, H, W, yy, xx);
             float g[8], conv[8];
             load8(dy + p * lddy + cv * 8, g);
 #pragma unroll
@@ -448,7 +448,7 @@ __global__ void axpby_kernel(const T* __restrict__ a, int lda, float alpha, cons
     const int ncv = C >> 3;
     const long long total = npix * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
         float v[8], u[8];
         load8(a + p * lda + cv * 8, v);
         if (b != nullptr) {
@@ -469,7 +469,7 @@ __global__ void sum4_kernel(const T* __restrict__ a, int lda, const T* __restric
     const int ncv = C >> 3;
     const long long total = npix * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
         float v[8], u[8];
         load8(a + p * lda + cv * 8, v);
         load8(b + p * ldb + cv * 8, u);
@@ -495,8 +495,8 @@ __global__ void sum4_hp_kernel(const T* __restrict__ a, int lda, const T* __rest
     const int ncv = C >> 3;
     const long long total = (long long)N * H * W * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long p = i / ncv; const int cv = (int)(i - p * ncv);
-        const int xx = (int)(p % W), yy = (int)((p / W) % H);
+        long long p; int cv; egm_divmod(i, ncv, p, cv);
+        int xx, yy; egm_pix_yx(p, H, W, yy, xx);
         float v[8], u[8], s8[8];
         zero8(s8);
         load8(a + p * lda + cv * 8, v);
@@ -696,8 +696,8 @@ __global__ void shuffle2x2_fwd_kernel(const T* __restrict__ y4, int ld4, const f
     const int ncv = C >> 3;
     const long long total = (long long)N * Ho * Wo * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv); const long long q = i / ncv;
-        const int X = (int)(q % Wo), Y = (int)((q / Wo) % Ho), n = (int)(q / ((long long)Wo * Ho));
+        long long q; int cv; egm_divmod(i, ncv, q, cv);
+        int X, Y, n; egm_pix_nyx(q, Ho, Wo, n, Y, X);
         const int yy = Y - oy, xx = X - ox;
         float v[8];
         zero8(v);
@@ -716,9 +716,9 @@ __global__ void shuffle2x2_bwd_kernel(const T* __restrict__ g, int ldg, T* __res
     const int ncv = C >> 3;
     const long long total = (long long)N * H * W * 4 * ncv;
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int cv = (int)(i % ncv); long long q = i / ncv;
+        long long q; int cv; egm_divmod(i, ncv, q, cv);
         const int ij = (int)(q % 4); q /= 4;
-        const int x = (int)(q % W), y = (int)((q / W) % H), n = (int)(q / ((long long)W * H));
+        int x, y, n; egm_pix_nyx(q, H, W, n, y, x);
         const int Y = 2 * y + (ij >> 1) + oy, X = 2 * x + (ij & 1) + ox;
         float v[8];
         zero8(v);
