@@ -546,7 +546,15 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
         // ---- producer state: 16-byte vector i = ptid + 256 k of the dy image / the x image (block-major [32-ch block][pixel][4 vectors])
         constexpr int DYVEC = ((DROW ? 1 : 2) * TH * TW * VPR + 255) / 256;
         constexpr int XVEC = ((DROW ? 1 : 2) * PH * PWC * VPR + 255) / 256;
-        uint4 rdy[DYVEC], rya[PRE ? DYVEC : 1], rx[XVEC];
+        // one tile's staging registers.  Without prologues there are TWO sets, i.e. two tiles in flight from memory behind the one
+        // being written to LDS: a tile is 16-38 KB per CU and a round trip ~2 us, so ONE tile in flight caps the HBM-bound layers
+        // (<= 64 channels at 512^2 / 256^2) near 3 TB/s whatever the consumers do; the prologue forms keep one (register budget).
+        struct Regs { uint4 dy[DYVEC], ya[PRE ? DYVEC : 1], x[XVEC]; };
+#ifndef EGM_WGRAD_DEEP
+#define EGM_WGRAD_DEEP 1          // 0: one staging set everywhere (A/B builds)
+#endif
+        constexpr bool DEEP = !PRE && EGM_WGRAD_DEEP;
+        Regs ra, rb;
         const bool dy_writer = PRE && og != nullptr && cit == 0 && grp == p.out_grp;
         const bool dy_bwd = PRE && p.predy.mode == EGM_PRE_BN_BWD, x_act = PRE && p.prex.mode != EGM_PRE_NONE;
         const int v4 = ptid & 3;                                        // the thread's vector inside a 32-channel row (same for all its slots)
@@ -579,7 +587,8 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
             const int iy = iy0 + py, ix = ix0 + px;
             return pk >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         };
-        auto issue_tile = [&](int n, int oy_, int ox_) __attribute__((always_inline)) {
+        auto issue_tile = [&](Regs& rg, int n, int oy_, int ox_) __attribute__((always_inline)) {
+            uint4 (&rdy)[DYVEC] = rg.dy; uint4 (&rya)[PRE ? DYVEC : 1] = rg.ya; uint4 (&rx)[XVEC] = rg.x;
             tix = opaque(ptid);
             const long long o_dy = (long long)(n * p.H + oy_) * p.W + ox_;                // first pixel of the dy tile (inside the image)
             const long long o_x = (long long)(n * p.H + oy_ + offy) * p.W + ox_ + offx;   // first pixel of the x patch (may be outside)
@@ -619,7 +628,8 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
                 }
             }
         };
-        auto write_tile = [&](int buf, int n, int oy_, int ox_) __attribute__((always_inline)) {
+        auto write_tile = [&](Regs& rg, int buf, int n, int oy_, int ox_) __attribute__((always_inline)) {
+            uint4 (&rdy)[DYVEC] = rg.dy; uint4 (&rya)[PRE ? DYVEC : 1] = rg.ya; uint4 (&rx)[XVEC] = rg.x;
             tix = opaque(ptid);
             unsigned char* dyb = smem + buf * img_bytes;
             unsigned char* xb = dyb + p.A * (TH * TW) * RB;
@@ -679,12 +689,44 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
                     if (tix + k * 256 < nx) *reinterpret_cast<uint4*>(xb + (tix + k * 256) * 16) = rx[k];
             }
         };
+        if constexpr (DEEP) {
+            // Producers run one tile ahead in LDS and THREE ahead in registers: set `cur` holds tile pt1 (written to LDS this iteration,
+            // then re-used for tile pt3), set `oth` holds tile pt2.  The loop is unrolled by two so the sets swap roles by name.
+            int n2 = 0, oy2 = 0, ox2 = 0;
+            int pt2 = pt1 < p.npt ? next_tile(pt1 + p.nsplit, n2, oy2, ox2) : p.npt;
+            if (pt0 < p.npt) issue_tile(ra, n0, oy0, ox0);
+            __syncthreads();                                            // (coefficient rows: none here; the consumers' barrier count)
+            if (pt0 < p.npt) {
+                write_tile(ra, 0, n0, oy0, ox0);
+                if (pt1 < p.npt) issue_tile(ra, n1, oy1, ox1);
+                if (pt2 < p.npt) issue_tile(rb, n2, oy2, ox2);
+            }
+            __syncthreads();
+            int buf = 0;
+            auto step = [&](Regs& cur) __attribute__((always_inline)) {
+                int n3 = 0, oy3 = 0, ox3 = 0;
+                const int pt3 = pt2 < p.npt ? next_tile(pt2 + p.nsplit, n3, oy3, ox3) : p.npt;
+                if (pt1 < p.npt) {
+                    write_tile(cur, buf ^ 1, n1, oy1, ox1);             // registers -> the image pair the consumers are NOT reading
+                    if (pt3 < p.npt) issue_tile(cur, n3, oy3, ox3);     // the freed set takes the tile three ahead
+                }
+                __syncthreads();
+                buf ^= 1;
+                pt0 = pt1; pt1 = pt2; n1 = n2; oy1 = oy2; ox1 = ox2;
+                pt2 = pt3; n2 = n3; oy2 = oy3; ox2 = ox3;
+            };
+            while (pt0 < p.npt) {
+                step(ra);
+                if (pt0 >= p.npt) break;
+                step(rb);
+            }
+        } else {
         // Producers run one tile ahead in LDS and two ahead in registers.
-        if (pt0 < p.npt) issue_tile(n0, oy0, ox0);
+        if (pt0 < p.npt) issue_tile(ra, n0, oy0, ox0);
         __syncthreads();                                                // coefficient rows visible
         if (pt0 < p.npt) {
-            write_tile(0, n0, oy0, ox0);
-            if (pt1 < p.npt) issue_tile(n1, oy1, ox1);
+            write_tile(ra, 0, n0, oy0, ox0);
+            if (pt1 < p.npt) issue_tile(ra, n1, oy1, ox1);
         }
         __syncthreads();
         int buf = 0;
@@ -692,12 +734,13 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
             int n2 = 0, oy2 = 0, ox2 = 0;
             const int pt2 = pt1 < p.npt ? next_tile(pt1 + p.nsplit, n2, oy2, ox2) : p.npt;
             if (pt1 < p.npt) {
-                write_tile(buf ^ 1, n1, oy1, ox1);                      // registers -> the image pair the consumers are NOT reading
-                if (pt2 < p.npt) issue_tile(n2, oy2, ox2);              // the freed registers take the tile after next
+                write_tile(ra, buf ^ 1, n1, oy1, ox1);                  // registers -> the image pair the consumers are NOT reading
+                if (pt2 < p.npt) issue_tile(ra, n2, oy2, ox2);          // the freed registers take the tile after next
             }
             __syncthreads();
             buf ^= 1;
             pt0 = pt1; pt1 = pt2; n1 = n2; oy1 = oy2; ox1 = ox2;
+        }
         }
         for (int r = 1; r < p.C; ++r) { __syncthreads(); __syncthreads(); }   // the consumers' cross-wave reduction
         return;

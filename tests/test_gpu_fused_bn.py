@@ -247,8 +247,15 @@ def test_model_fused_equals_materialised(dtype, which):
     t = torch.randint(0, 2, (2, 96, 128), generator=g).to(DEV)
     lw = torch.tensor([1.0, 2.0], device=DEV)
     res = []
+    # the round-3 fusions (pool in the BatchNorm passes, dz on the fly, BatchNorm inside the MCA statistics pass) only exist on the
+    # materialised path and accumulate the BatchNorm partial sums in another pixel order: switched off for the bit-for-bit comparison
+    # of the operand-prologue path (they have their own on/off tests in test_gpu_pool_fused.py)
+    r3 = [(ops.fuse_pool, ops.fuse_pool()), (ops.fuse_dz, ops.fuse_dz()), (ops.fuse_mca_bn, ops.fuse_mca_bn())]
     for fuse in (True, False):
         toggle(fuse)
+        if which == "prologue":
+            for f, _ in r3:
+                f(False)
         try:
             m.load_state_dict(state0)
             for p in m.parameters():
@@ -261,6 +268,8 @@ def test_model_fused_equals_materialised(dtype, which):
                         {n: b.clone() for n, b in m.named_buffers()}))
         finally:
             toggle(default)
+            for f, v in r3:
+                f(v)
     (o1, l1, g1, b1), (o2, l2, g2, b2) = res
     assert torch.equal(o1, o2) and torch.equal(l1, l2)
     same = (lambda a, b: torch.equal(a, b)) if (dtype == torch.float32 or which != "prologue") else \
