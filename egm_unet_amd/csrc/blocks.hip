@@ -458,8 +458,10 @@ __global__ void merge357_fwd_kernel(const float* __restrict__ w3, const float* _
     }
 }
 __global__ void merge357_bwd_kernel(const float* __restrict__ gw, float* __restrict__ d3, float* __restrict__ d5, float* __restrict__ d7,
-                                    int Co, int Ci) {
+                                    const float* __restrict__ gb, float* __restrict__ gb3, int Co, int Ci) {
     const int total = Co * Ci * 49;
+    if (gb != nullptr)                                              // d(b3) = d(b5) = d(b7) = d(b): three rows for the three parameters
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 3 * Co; i += gridDim.x * blockDim.x) gb3[i] = gb[i % Co];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int t = i % 49, oc = i / 49, r = t / 7, s = t % 7;
         const float v = gw[i];
@@ -1004,9 +1006,9 @@ extern "C" int egm_merge357_pack(int dtype, const float* w3, const float* w5, co
     EGM_CHECK_LAUNCH("merge357_pack");
     return EGM_OK;
 }
-extern "C" int egm_merge357_bwd(const float* gw, float* d3, float* d5, float* d7, int Co, int Ci, egm_stream_t s) {
-    EGM_REQUIRE(gw && d3 && d5 && d7 && Co > 0 && Ci > 0, "merge357_bwd: bad args");
-    hipLaunchKernelGGL(merge357_bwd_kernel, dim3((Co * Ci * 49 + 255) / 256), dim3(256), 0, (hipStream_t)s, gw, d3, d5, d7, Co, Ci);
+extern "C" int egm_merge357_bwd(const float* gw, float* d3, float* d5, float* d7, const float* gb, float* gb3, int Co, int Ci, egm_stream_t s) {
+    EGM_REQUIRE(gw && d3 && d5 && d7 && Co > 0 && Ci > 0 && ((gb == nullptr) == (gb3 == nullptr)), "merge357_bwd: bad args");
+    hipLaunchKernelGGL(merge357_bwd_kernel, dim3((Co * Ci * 49 + 255) / 256), dim3(256), 0, (hipStream_t)s, gw, d3, d5, d7, gb, gb3, Co, Ci);
     EGM_CHECK_LAUNCH("merge357_bwd");
     return EGM_OK;
 }

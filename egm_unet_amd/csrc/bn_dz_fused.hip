@@ -176,6 +176,67 @@ __global__ __launch_bounds__(256) void bn_dz_bwd_apply_kernel(DzArgs d, const T*
     }
 }
 
+// ---- forward twin of DZ_CLS: z = act(scale*y + shift) written out AND the 1x1 classifier applied to it in the same pass ------------------
+// logits[n][k][h][w] (fp32 NCHW, the module's output layout) = round_T(sum_c z[c]*W[k][c] + b[k]): egm_bn_act_fwd + the classifier's conv
+// launch + egm_nhwc_to_nchw as ONE pass over y (the classifier re-read the 134 MB tensor the apply pass had just written).
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void bn_act_cls_fwd_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int act, T* __restrict__ z, int ldz,
+                                                             const float* __restrict__ w, int nc, int ldw, const float* __restrict__ bias,
+                                                             float* __restrict__ logits, long long npix, long long HW, int C) {
+    const int ncv = C >> 3, cv = threadIdx.x % ncv, ppb = 256 / ncv;        // 256 % ncv == 0, ncv a power of two <= 64 (launcher)
+    float sc[8], sh[8], wr[NC][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = scale[cv * 8 + j]; sh[j] = shift[cv * 8 + j]; }
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int c = cv * 8 + j; wr[k][j] = (k < nc && c < ldw) ? to_f32(from_f32<T>(w[k * ldw + c])) : 0.f; }
+    // two pixels in flight per thread (as bn_act_fwd); the lanes of a pixel share p, so they leave the loop together and the shuffles
+    // below always see their whole group
+    const long long stride = (long long)gridDim.x * ppb;
+    auto finish = [&](long long p, const float (&v)[8]) __attribute__((always_inline)) {
+        float part[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s = fmaf(v[j], wr[k][j], s);
+            for (int o = ncv >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            part[k] = s;
+        }
+        if (cv == 0) {
+            const long long n = egm_udiv(p, (int)HW), hw = p - n * HW;
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                if (k < nc) logits[(n * nc + k) * HW + hw] = to_f32(from_f32<T>(part[k] + (bias != nullptr ? bias[k] : 0.f)));
+        }
+    };
+    long long p = (long long)blockIdx.x * ppb + threadIdx.x / ncv;
+    for (; p + stride < npix; p += 2 * stride) {
+        float v[8], u[8];
+        load8(y + p * ldy + cv * 8, v);
+        load8(y + (p + stride) * ldy + cv * 8, u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = to_f32(from_f32<T>(bn_fwd_elem(v[j], sc[j], sh[j], act)));
+            u[j] = to_f32(from_f32<T>(bn_fwd_elem(u[j], sc[j], sh[j], act)));
+        }
+        store8(z + p * ldz + cv * 8, v);
+        store8(z + (p + stride) * ldz + cv * 8, u);
+        finish(p, v);
+        finish(p + stride, u);
+    }
+    if (p < npix) {
+        float v[8];
+        load8(y + p * ldy + cv * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<T>(bn_fwd_elem(v[j], sc[j], sh[j], act)));
+        store8(z + p * ldz + cv * 8, v);
+        finish(p, v);
+    }
+}
+
 int check_common(const char* name, const void* y, int ldy, long long npix, int C) {
     EGM_REQUIRE(y != nullptr && egm_aligned16(y) && C > 0 && C % 8 == 0 && C <= 1024 && ldy >= C && ldy % 8 == 0 && npix > 0 && 256 % (C / 8) == 0,
                 "%s: bad BatchNorm tensor (C=%d must be a multiple of 8 with C/8 a divisor of 256, <= 1024; ld=%d)", name, C, ldy);
@@ -253,4 +314,26 @@ extern "C" int egm_bn_mca_bwd_apply(int dtype, const void* dxo, int ldd, const f
     int rc = check_common("bn_mca_bwd_apply", y, ldy, npix, C); if (rc) return rc;
     rc = fill_mca(d, dxo, ldd, gates, coef, N, H, W, C, no_spatial); if (rc) return rc;
     return launch_apply<DZ_MCA>(dtype, d, y, ldy, scale, shift, save_mean, save_rstd, act, train, sums, dy, lddy, npix, C, s);
+}
+
+extern "C" int egm_bn_act_cls_fwd(int dtype, const void* y, int ldy, const float* scale, const float* shift, int act, void* z, int ldz,
+                                  const float* w_cls, int nc, int ldw, const float* bias, float* logits_nchw, int N, int H, int W, int C,
+                                  egm_stream_t s) {
+    const long long npix = (long long)N * H * W;
+    int rc = check_common("bn_act_cls_fwd", y, ldy, npix, C); if (rc) return rc;
+    EGM_REQUIRE((long long)H * W < (1LL << 31), "bn_act_cls_fwd: image too large");
+    EGM_REQUIRE(z && egm_aligned16(z) && ldz >= C && ldz % 8 == 0 && scale && shift && w_cls && logits_nchw && nc >= 1 && nc <= 8 &&
+                ldw >= 1 && ldw <= C && C / 8 <= 64 && ((C / 8) & (C / 8 - 1)) == 0,
+                "bn_act_cls_fwd: bad args (nc=%d <= 8, C/8 = %d a power of two <= 64)", nc, C / 8);
+    const int grid = stream_grid(npix * (C / 8));
+    const long long HW = (long long)H * W;
+    if (nc <= 2) {
+        EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_cls_fwd_kernel<T, 2>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)y, ldy, scale,
+                                                     shift, act, (T*)z, ldz, w_cls, nc, ldw, bias, logits_nchw, npix, HW, C));
+    } else {
+        EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bn_act_cls_fwd_kernel<T, 8>), dim3(grid), dim3(256), 0, (hipStream_t)s, (const T*)y, ldy, scale,
+                                                     shift, act, (T*)z, ldz, w_cls, nc, ldw, bias, logits_nchw, npix, HW, C));
+    }
+    EGM_CHECK_LAUNCH("bn_act_cls_fwd");
+    return EGM_OK;
 }

@@ -167,6 +167,7 @@ __global__ void mca_gates_bwd_kernel(const float* __restrict__ dG, const float* 
     __shared__ float sk[3][8], sab[3][2];                           // gate parameters once into LDS (see mca_gates_fwd_kernel)
     if (threadIdx.x < 24) { const int a = threadIdx.x >> 3, t = threadIdx.x & 7; sk[a][t] = t < gp.ks[a] ? gp.k[a][t] : 0.f; }
     else if (threadIdx.x >= 32 && threadIdx.x < 38) { const int a = (threadIdx.x - 32) >> 1, j = (threadIdx.x - 32) & 1; sab[a][j] = gp.ks[a] > 0 ? 0.5f + sigm(gp.w[a][j]) : 0.f; }
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 24) dks[threadIdx.x - 64] = 0.f;       // taps beyond a gate's kernel size: zero gradient (no host-side fill)
     for (int e = threadIdx.x; e < total; e += blockDim.x) dz[e] = dG[e * 2] * gp.inv * gates[e] * (1.f - gates[e]);   // absent axis: gates = 0 -> dz = 0
     __syncthreads();
     // per-thread partials of everything that is summed over the entries: d(alpha), d(beta) per axis and the <= 7 kernel taps

@@ -525,5 +525,5 @@ class GRFBUNet(_SegNetBase):
         y = self.up1(x5, x4s, bufs[3])
         y = self.up2(y, x3s, bufs[2])
         y = self.up3(y, x2s, bufs[1])
-        y = self.up4(y, x1s, bufs[0], lazy=True)                 # the 1x1 classifier applies up4's last BatchNorm+ReLU itself
+        y = self.up4(y, x1s, bufs[0], lazy="force" if ops.fuse_cls() else True)   # the 1x1 classifier applies up4's last BatchNorm+ReLU itself
         return self._exit(self.out_conv(y, sole_consumer=True))

@@ -91,6 +91,7 @@ class GraphedTrainStep:
                         st["momentum_buffer"].zero_()  # created by the warm-up: v = 0, so the first real step gives v = g as torch does
             ops.bump_weight_generation()
         self.opt.zero_grad(set_to_none=True)
+        self._one = torch.ones((), dtype=torch.float32, device=dev)
         if self.reducer is not None:
             self.reducer.hooks_enabled = False       # no collectives inside a captured graph
         # With a process group alive, the RCCL watchdog THREAD polls the events of recent collectives (hipEventQuery every ~100 ms,
@@ -107,7 +108,7 @@ class GraphedTrainStep:
             self.graph = torch.cuda.CUDAGraph()
             with self._ns, torch.cuda.graph(self.graph, capture_error_mode=self._cap_mode):
                 loss = criterion(self.model(self.x), self.t, self.lw, num_classes=self.nc, ignore_index=self.ign)
-                loss.backward()
+                loss.backward(self._one)                  # the seed gradient is a resident tensor, not a fill launch per replay
                 if self.reducer is None:
                     self.opt.step()
                 self.loss = loss.detach()
@@ -124,7 +125,7 @@ class GraphedTrainStep:
             loss = criterion(model(self.x), self.t, self.lw, num_classes=self.nc, ignore_index=self.ign)
             bnd = list(model.ddp_boundary)
             # the decoder half of backward: stops at the boundary tensors (their gradients land in .grad) and at bucket 0's parameters
-            torch.autograd.backward(loss, inputs=list(b0) + bnd, retain_graph=True)
+            torch.autograd.backward(loss, self._one, inputs=list(b0) + bnd, retain_graph=True)
             red.gather_bucket(0)
             self.loss = loss.detach()
             bgrads = [b.grad for b in bnd]

@@ -625,6 +625,75 @@ def _conv_dgrad(dy, wd, N, H, W, CoutP, CinP, KH, KW, dil, x_split):
     return gx
 
 
+_FUSE_CLS = os.environ.get("EGM_FUSE_CLS", "1") != "0"
+
+
+def fuse_cls(enabled=None):
+    """Get / set whether the 1x1 classifier runs inside the BatchNorm apply pass of the layer in front (tests compare both ways)."""
+    global _FUSE_CLS
+    if enabled is not None:
+        _FUSE_CLS = bool(enabled)
+    return _FUSE_CLS
+
+
+class _BnActCls(Function):
+    """Lazy (conv -> BatchNorm -> act stand-in) -> 1x1 classifier -> fp32 NCHW logits as ONE node (OutConv behind up4's DoubleConv,
+    src/EGM-UNet.py:952-956 + :1536-1540): the BatchNorm apply pass writes z (kept for the classifier's weight gradient) and computes
+    the logits from it (egm_bn_act_cls_fwd).  backward: classifier weight / bias gradients from (z, dlogits); the data gradient is
+    left to the BatchNorm backward in front (_defer_dz "cls") or, with that switched off, computed by the conv kernel."""
+
+    @staticmethod
+    def forward(ctx, y, coef, act, weight, bias):
+        y, ldy = _nhwc(y)
+        N, H, W, C = y.shape
+        nc, Cin = weight.shape[0], weight.shape[1]
+        L, dt, st, dev = lib(), dtype_code(y.dtype), stream(), y.device
+        z = torch.empty((N, H, W, C), dtype=y.dtype, device=dev)
+        logits = torch.empty((N, nc, H, W), dtype=torch.float32, device=dev)
+        L.call("egm_bn_act_cls_fwd", dt, ptr(y), ldy, ptr(coef[0]), ptr(coef[1]), act, ptr(z), C, ptr(weight.detach()), nc, Cin,
+               ptr(bias.detach()) if bias is not None else None, ptr(logits), N, H, W, C, st)
+        if ctx.needs_input_grad[3]:
+            _note_conv_use(weight)
+        ctx.save_for_backward(z, weight)
+        ctx.meta = (nc, Cin, bias is not None)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        z, weight = ctx.saved_tensors
+        nc, Cin, has_bias = ctx.meta
+        N, H, W, C = z.shape
+        L, dt, st, dev = lib(), dtype_code(z.dtype), stream(), z.device
+        g = g.contiguous().float()
+        dl = torch.empty((N, H, W, 8), dtype=z.dtype, device=dev)            # NHWC, channels nc..7 zero-filled
+        L.call("egm_nchw_to_nhwc", dt, ptr(g), ptr(dl), 8, N, nc, H, W, st)
+        gy = gw = gb = None
+        if ctx.needs_input_grad[3]:
+            gw = _conv_wgrad(z, C, None, ACT_NONE, dl, 8, None, None, weight, 1, 1, Cin, nc)
+        if has_bias and ctx.needs_input_grad[4]:
+            gb = _channel_sum(dl)[0, :nc]
+        if ctx.needs_input_grad[0]:
+            gy = torch.empty((N, H, W, C), dtype=z.dtype, device=dev)
+            if _FUSE_DZ and _dz_fusable(C):
+                _defer_dz(gy, ("cls", dl, 8, weight.detach(), nc, Cin))     # never written: see _defer_dz
+            else:
+                _, wd = _packed_weights(weight, 1, z.dtype)
+                L.call("egm_conv_fwd", dt, ptr(dl), 8, ptr(wd), None, 0, ptr(gy), C, None, N, H, W, 8, C, 1, 1, 1, st)
+        return gy, None, None, gw, gb
+
+
+def bn_act_cls_ok(x, weight):
+    """True when ops.bn_act_cls applies: x an ops.Lazy, a 1x1 classifier to <= 8 classes, channel count a power of two <= 512."""
+    C = x.shape[3] if isinstance(x, Lazy) else 0
+    return (_FUSE_CLS and isinstance(x, Lazy) and weight.dim() == 4 and weight.shape[2] == 1 and weight.shape[3] == 1 and weight.shape[0] <= 8
+            and pad8(weight.shape[1]) == C and C % 8 == 0 and C // 8 <= 64 and (C // 8) & (C // 8 - 1) == 0 and weight.is_contiguous())
+
+
+def bn_act_cls(x, weight, bias):
+    """Lazy x -> fp32 NCHW logits of the 1x1 classifier (weight, bias); x's only consumer."""
+    return _BnActCls.apply(x.y, x.coef, x.act, weight, bias)
+
+
 class _ConvBN(Function):
     """conv -> BatchNorm (-> act, applied by whoever consumes the result) as ONE autograd node.
 
@@ -1215,7 +1284,9 @@ def conv_bn_act(x, conv, bn, act, dil=1, groups=1, out=None, lazy=False):
     y, coef = _ConvBN.apply(xt, xc, xa, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, act,
                             training, dil, groups, getattr(x, "_egm_split", 0))
     z = Lazy(y, coef, act)
-    return z if (lazy and out is None and _FUSE_BN) else z.materialize(out)
+    if out is None and (lazy == "force" or (lazy and _FUSE_BN)):    # "force": the consumer materialises the tensor in a pass of its own
+        return z
+    return z.materialize(out)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -1964,8 +2035,15 @@ class _Merge357(Function):
         d3 = torch.empty((Co, Ci, 3, 3), dtype=torch.float32, device=dev)
         d5 = torch.empty((Co, Ci, 5, 5), dtype=torch.float32, device=dev)
         d7 = torch.empty((Co, Ci, 7, 7), dtype=torch.float32, device=dev)
-        lib().call("egm_merge357_bwd", ptr(gw.contiguous()), ptr(d3), ptr(d5), ptr(d7), Co, Ci, stream())
-        return d3, d5, d7, gb, gb, gb, None
+        # the bias gradient goes to three parameters: handed out as three tensors (the same tensor three times makes autograd clone it
+        # twice: two copy launches per FusionConv)
+        gb3 = None
+        if gb is not None:
+            gb3 = torch.empty((3, Co), dtype=torch.float32, device=dev)
+        lib().call("egm_merge357_bwd", ptr(gw.contiguous()), ptr(d3), ptr(d5), ptr(d7), ptr(gb), ptr(gb3), Co, Ci, stream())
+        if gb3 is None:
+            return d3, d5, d7, None, None, None, None
+        return d3, d5, d7, gb3[0], gb3[1], gb3[2], None
 
 
 def merge357(w3, w5, w7, b3, b5, b7, pack_dtype=None):
@@ -2248,7 +2326,7 @@ class _MCALayer(Function):
         dz = _f32((N, Lax), dev)
         coef = _f32((N, Lax, 2), dev)
         dwts = _f32((3, 2), dev)
-        dks = _f32((3, 8), dev, zero=True)
+        dks = _f32((3, 8), dev)                                  # zeroed by the kernel itself
         L.call("egm_mca_gates_bwd", ptr(dG), ptr(stats), ptr(o), ptr(gates), ptr(wh), ptr(kh), ks[0], ptr(ww), ptr(kw), ks[1],
                None if ns else ptr(pc[0]), None if ns else ptr(pc[1]), ks[2], ptr(dz), ptr(coef), ptr(dwts), ptr(dks), N, H, W, C, st)
         if ctx.defer_dx and _FUSE_DZ:

@@ -30,10 +30,13 @@ class _Criterion(Function):
         ctx.save_for_backward(x, t, w, ws, signs)
         ctx.meta = (int(ignore_index), 1 if dice else 0)
         ctx.mark_non_differentiable(loss6)
+        ctx.set_materialize_grads(False)               # no zero-filled "gradient" (a fill launch per step) for the non-differentiable terms
         return loss6[0], loss6
 
     @staticmethod
     def backward(ctx, g, _g6):
+        if g is None:
+            return None, None, None, None, None
         x, t, w, ws, signs = ctx.saved_tensors
         ignore_index, dice = ctx.meta
         N, C, H, W = x.shape

@@ -78,8 +78,15 @@ class OutConv(nn.Sequential):
         super().__init__(nn.Conv2d(in_channels, num_classes, kernel_size=1))
 
     def forward(self, x, sole_consumer=False):
-        """sole_consumer: x is the materialised output of a DoubleConv and feeds nothing but this classifier (then the classifier's data
-        gradient is evaluated inside that BatchNorm's backward instead of being written out; ops.conv2d defer_dgrad)."""
+        """sole_consumer: x is the output of a DoubleConv and feeds nothing but this classifier.  As an ops.Lazy it is materialised
+        by the classifier itself (BatchNorm apply + 1x1 conv in one pass, ops.bn_act_cls) and the result is the fp32 NCHW logits tensor;
+        as a tensor, the classifier's data gradient is evaluated inside that BatchNorm's backward (ops.conv2d defer_dgrad).
+        -> NHWC activation, or (marked by the attribute _egm_nchw_logits) the final NCHW logits."""
+        if sole_consumer and ops.bn_act_cls_ok(x, self[0].weight):
+            out = ops.bn_act_cls(x, self[0].weight, self[0].bias)
+            out._egm_nchw_logits = True
+            return out
+        x = ops.materialize(x) if (isinstance(x, ops.Lazy) and not ops.fuse_bn()) else x
         return ops.conv2d(x, self[0].weight, self[0].bias, defer_dgrad=sole_consumer and not isinstance(x, ops.Lazy))
 
 
@@ -120,6 +127,8 @@ class _SegNetBase(nn.Module):
         return ops.to_nhwc(x, self.compute_dtype)
 
     def _exit(self, y) -> Dict[str, torch.Tensor]:
+        if getattr(y, "_egm_nchw_logits", False):              # the fused classifier wrote the module's output layout itself
+            return {"out": y}
         return {"out": ops.to_nchw(y, self.num_classes)}
 
 
@@ -157,5 +166,5 @@ class UNet(_SegNetBase):
         y = self.up1(x5, x4s)
         y = self.up2(y, x3s)
         y = self.up3(y, x2s)
-        y = self.up4(y, x1s, lazy=True)                          # the 1x1 classifier applies up4's last BatchNorm+ReLU itself
+        y = self.up4(y, x1s, lazy="force" if ops.fuse_cls() else True)   # the 1x1 classifier applies up4's last BatchNorm+ReLU itself
         return self._exit(self.out_conv(y, sole_consumer=True))

@@ -194,6 +194,12 @@ int egm_bn_act_bwd_apply(int dtype, const void* dz, int lddz, const void* y, int
  *          fp32 OIHW weight [nc][ldw] (rounded to `dtype` inside, like the conv's operand pack); dlogits has >= 8 channels per pixel.
  *   _mca_: dz = dxo*(g_h + g_w + g_c)*inv + (A + B*x) -- the MCALayer's last backward step (egm_mca_bwd_dx) behind DoubleConv1's first
  *          BatchNorm+ReLU (src/EGM-UNet.py:893-896), x being this BatchNorm's own output, recomputed from y. */
+/* Forward twin of _cls_: z = act(y*scale + shift) written to z AND the classifier applied in the same pass,
+ * logits_nchw[n][k][h][w] (fp32, the module's output layout) = sum_c z[c]*w_cls[k*ldw + c] + bias[k], rounded to `dtype` like the conv
+ * kernel's output (egm_bn_act_fwd + the 1x1 conv launch + egm_nhwc_to_nchw as one pass).  nc <= 8, C/8 a power of two <= 64. */
+int egm_bn_act_cls_fwd(int dtype, const void* y, int ldy, const float* scale, const float* shift, int act, void* z, int ldz,
+                       const float* w_cls, int nc, int ldw, const float* bias, float* logits_nchw, int N, int H, int W, int C,
+                       egm_stream_t s);
 int egm_bn_cls_bwd_reduce(int dtype, const void* dlogits, int lddl, const float* w_cls, int nc, int ldw, const void* y, int ldy,
                           const float* scale, const float* shift, const float* save_mean, const float* save_rstd, int act,
                           float* partials, long long npix, int C, egm_stream_t s);
@@ -380,7 +386,7 @@ int egm_fold2_fwd(const float* w, float* out, int rows, int K, egm_stream_t s);
 int egm_fold2_bwd(const float* g, float* dw, int rows, int K, egm_stream_t s);
 int egm_merge357_fwd(const float* w3, const float* w5, const float* w7, const float* b3, const float* b5, const float* b7,
                      float* w, float* b, int Co, int Ci, egm_stream_t s);
-int egm_merge357_bwd(const float* gw, float* d3, float* d5, float* d7, int Co, int Ci, egm_stream_t s);
+int egm_merge357_bwd(const float* gw, float* d3, float* d5, float* d7, const float* gb, float* gb3, int Co, int Ci, egm_stream_t s);
 /* egm_fold2_fwd / egm_merge357_fwd that ALSO write the operand packs (egm_conv_pack layouts, groups = 1) of the derived weight:
  * wf [taps][CoutP][CinP], wd [taps flipped][CinP][CoutP] in `dtype`, CoutP/CinP = the counts rounded up to 8. */
 int egm_fold2_pack(int dtype, const float* w, float* out, void* wf, void* wd, int rows, int K, egm_stream_t s);

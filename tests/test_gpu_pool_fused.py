@@ -193,3 +193,47 @@ def test_model_with_deferred_dz_matches_separate_kernels(dtype, model_kind):
         if float(b.norm()) > 1e-5 * big:
             worst = max(worst, float((a - b).norm() / b.norm()))
     assert worst <= (2e-4 if dtype == torch.float32 else 0.1), worst
+
+
+@pytest.mark.parametrize("model_kind", ["egm", "unet"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_model_with_classifier_in_batchnorm_apply_pass_matches_separate_conv(dtype, model_kind):
+    """The 1x1 classifier evaluated inside up4's last BatchNorm apply pass (egm_bn_act_cls_fwd, ops.fuse_cls) against the separate
+    apply pass + conv launch + layout conversion: logits to accumulation-order / rounding noise, gradients likewise."""
+    from egm_unet_amd import GRFBUNet, UNet, ops
+    from oracle import egm_ref as R
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn(2, 3, 64, 64, generator=g).to(DEV)
+    gl = torch.randn(2, 2, 64, 64, generator=g).to(DEV)
+    st = R.make_egm_unet_state(3, 2, 8, seed=15) if model_kind == "egm" else None
+    default = ops.fuse_cls()
+    outs = []
+    try:
+        for fused in (True, False):
+            ops.fuse_cls(fused)
+            torch.manual_seed(4)
+            m = GRFBUNet(3, 2, base_c=8) if model_kind == "egm" else UNet(3, 2, base_c=8)
+            if st is not None:
+                m.load_state_dict(st, strict=True)
+            m.to(DEV).train().set_compute_dtype(dtype)
+            out = m(x)["out"]
+            assert out.shape == (2, 2, 64, 64) and out.dtype == torch.float32 and out.is_contiguous()
+            out.backward(gl)
+            torch.cuda.synchronize()
+            outs.append((out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+            with torch.no_grad():
+                m.eval()
+                ev = m(x)["out"]
+                assert ev.shape == (2, 2, 64, 64) and bool(torch.isfinite(ev).all())
+    finally:
+        ops.fuse_cls(default)
+    a, b = outs[0][0], outs[1][0]
+    lerr = float((a - b).abs().max()) / max(1e-6, float(b.abs().max()))
+    assert lerr <= (1e-5 if dtype == torch.float32 else 1e-2), lerr
+    assert outs[0][1].keys() == outs[1][1].keys()
+    worst, big = 0.0, max(float(v.float().norm()) for v in outs[1][1].values())
+    for k in outs[0][1]:
+        p, q = outs[0][1][k].float(), outs[1][1][k].float()
+        if float(q.norm()) > 1e-5 * big:
+            worst = max(worst, float((p - q).norm() / q.norm()))
+    assert worst <= (2e-4 if dtype == torch.float32 else 0.1), worst
