@@ -112,6 +112,145 @@ __global__ __launch_bounds__(256, 2) void conv7x7_c16_kernel(C7Params p) {
     }
 }
 
+// ---- weight gradient of the same layer: dW[r*7+s][co][ci] = sum_{n,y,x} dy[n,y,x,co] * x[n, y+r-3, x+s-3, ci] ------------------------
+// On the generic wave-specialised kernel this shape pads both channel counts to 32 (a quarter of every MFMA is real work) and walks
+// the tensors once per kernel row: 117 us at 8 x 256^2.  Here
+//   * v_mfma_f32_16x16x32_bf16 with M = 16 couts, N = 16 cins, K = 32 pixels of one image row; both operands are "channel x 8
+//     pixels per lane", i.e. TRANSPOSED reads of the [pixel][16 channels] LDS images (ds_read_b64_tr_b16, two per fragment).  The K
+//     index is a free permutation of the 32 pixels as long as A and B agree: lane group q takes pixels 4q..4q+3 and 16+4q..16+4q+3, so
+//     the two groups of a 32-lane half read 256 contiguous bytes (conflict-free; 8 consecutive pixels per group would put the two
+//     groups 256 bytes apart, on the same banks);
+//   * a wave owns a 32-pixel column strip and all 49 taps (49 accumulators of 4 registers); a workgroup = 4 strips x a band of 4 rows.
+//     Row rotation: the fragment of patch row rho, shift s meets the dy fragments of output rows rho - r, r = 0..6, so a band step is
+//     7 x-fragment reads + nothing else per up to 28 MFMAs, and the 4 dy fragments of the band stay in registers;
+//   * persistent over bands; at the end the four waves are summed through LDS in fixed order and the workgroup writes ONE slab
+//     [49][16][16] fp32 (egm_wgrad_reduce sums the slabs in fixed order, like every other weight gradient).
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+constexpr int W7_RB = 4, W7_TW = 64, W7_PH = W7_RB + 6, W7_PW = W7_TW + 8;      // band rows, band width, patch rows, patch columns (64 + 6, padded)
+constexpr int W7_XSLOTS = W7_PH * W7_PW * 2, W7_DSLOTS = W7_RB * W7_TW * 2;      // 16-byte slots of the x patch / the dy band
+constexpr int W7_XLD = (W7_XSLOTS + 255) / 256, W7_DLD = (W7_DSLOTS + 255) / 256;
+
+struct W7Params {
+    const bf16_t* x; const bf16_t* dy; float* slab;
+    int ldx, lddy, N, H, W, tiles_y, tiles_x, nbands;
+};
+
+// fragment: lane (q = lane >> 4, c = lane & 15) <- channel c of pixels pix0 + {4q..4q+3, 16+4q..16+4q+3} of a [pixel][16 ch] image
+__device__ __forceinline__ bf16x8_t w7_frag(const unsigned char* img, int pix0, int lane) {
+    const int q = lane >> 4, t = lane & 15;
+    const unsigned char* a = img + (pix0 + 4 * q + (t >> 2)) * 32 + (t & 3) * 8;
+    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(a));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(a + 16 * 32));
+    const s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// the MFMAs of one staged band for a wave that owns kernel rows R0 .. R0+NR-1 of one 32-pixel strip
+template <int R0, int NR>
+__device__ __forceinline__ void w7_band(const unsigned char* xb, const unsigned char* db, int strip, int lane, f32x4_t (&acc)[4][7]) {
+    bf16x8_t fa[W7_RB];                                             // dy^T fragments of the band's rows
+#pragma unroll
+    for (int y = 0; y < W7_RB; ++y) fa[y] = w7_frag(db, y * W7_TW + strip * 32, lane);
+#pragma unroll
+    for (int rho = R0; rho < R0 + NR + W7_RB - 1; ++rho) {          // patch rows that meet one of this wave's kernel rows
+#pragma unroll
+        for (int s2 = 0; s2 < 7; ++s2) {
+            const bf16x8_t fb = w7_frag(xb, rho * W7_PW + strip * 32 + s2, lane);
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                const int y = rho - (R0 + rr);
+                if (y >= 0 && y < W7_RB) acc[rr][s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[y], fb, acc[rr][s2], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// everything a wave does, for the wave kind (R0, NR) = kernel rows R0 .. R0+NR-1: the two kinds are two separate programs (own
+// accumulators, own unrolled MFMA schedule), chosen once by a wave-uniform branch in the kernel
+template <int R0, int NR>
+__device__ __forceinline__ void w7_body(const W7Params& p, uint4* ximg, uint4* dimg, int strip) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    f32x4_t acc[4][7];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s2 = 0; s2 < 7; ++s2) acc[r][s2] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int tpi = p.tiles_y * p.tiles_x;
+    for (int band = blockIdx.x; band < p.nbands; band += gridDim.x) {
+        const int n = band / tpi, trem = band - n * tpi, ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+        const int y0 = ty * W7_RB, x0 = tx * W7_TW;
+        // ---- stage the x patch (rows y0-3 .. y0+RB+2, columns x0-3 .. x0+TW+4) and the dy band, zero outside the image
+        uint4 rx[W7_XLD], rd[W7_DLD];
+#pragma unroll
+        for (int k = 0; k < W7_XLD; ++k) {
+            const int slot = tid + k * 256, pix = slot >> 1, h = slot & 1, prow = pix / W7_PW, col = pix - prow * W7_PW;
+            const int iy = y0 - 3 + prow, ix = x0 - 3 + col;
+            rx[k] = make_uint4(0, 0, 0, 0);
+            if (slot < W7_XSLOTS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                rx[k] = *reinterpret_cast<const uint4*>(p.x + ((long long)(n * p.H + iy) * p.W + ix) * p.ldx + h * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < W7_DLD; ++k) {
+            const int slot = tid + k * 256, pix = slot >> 1, h = slot & 1, prow = pix / W7_TW, col = pix - prow * W7_TW;
+            const int iy = y0 + prow, ix = x0 + col;
+            rd[k] = make_uint4(0, 0, 0, 0);
+            if (slot < W7_DSLOTS && iy < p.H && ix < p.W)
+                rd[k] = *reinterpret_cast<const uint4*>(p.dy + ((long long)(n * p.H + iy) * p.W + ix) * p.lddy + h * 8);
+        }
+        __syncthreads();                                            // the previous band's fragments have been read
+#pragma unroll
+        for (int k = 0; k < W7_XLD; ++k) { const int slot = tid + k * 256; if (slot < W7_XSLOTS) ximg[slot] = rx[k]; }
+#pragma unroll
+        for (int k = 0; k < W7_DLD; ++k) { const int slot = tid + k * 256; if (slot < W7_DSLOTS) dimg[slot] = rd[k]; }
+        __syncthreads();
+        w7_band<R0, NR>(reinterpret_cast<const unsigned char*>(ximg), reinterpret_cast<const unsigned char*>(dimg), strip, lane, acc);
+    }
+    // ---- the two strips of a kernel-row half are summed through LDS (the images are free now): first the rows 0-3 pair, then the
+    // rows 4-6 pair, 28 KiB each; strip 0 writes the workgroup's slab rows.  (Without it the layer writes 1024 slabs of 50 KB and the
+    // slab reduction costs three times the kernel.)
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(ximg);
+    static_assert(28 * 64 * 16 <= (W7_XSLOTS + W7_DSLOTS) * 16, "reduction buffer fits the images");
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        if ((R0 != 0) == (half != 0) && strip == 1) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int s2 = 0; s2 < 7; ++s2) red[(r * 7 + s2) * 64 + lane] = acc[r][s2];
+        }
+        __syncthreads();
+        if ((R0 != 0) == (half != 0) && strip == 0) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int s2 = 0; s2 < 7; ++s2) acc[r][s2] += red[(r * 7 + s2) * 64 + lane];
+        }
+    }
+    if (strip == 0) {
+        // D layout: lane l holds rows (couts) 4*(l>>4) + i, column (cin) l & 15
+        float* slab = p.slab + (long long)blockIdx.x * 49 * 256;
+        const int q = lane >> 4, ci = lane & 15;
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < 7; ++s2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) slab[(((R0 + r) * 7 + s2) * 16 + 4 * q + i) * 16 + ci] = acc[r][s2][i];
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv7x7_c16_wgrad_kernel(W7Params p) {
+    __shared__ __attribute__((aligned(16))) uint4 img7[W7_XSLOTS + W7_DSLOTS];      // x patch | dy band (30.5 KiB)
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = wv & 1;                                       // wave = (32-pixel strip, kernel rows 0-3 | 4-6)
+    if ((wv >> 1) == 0) w7_body<0, 4>(p, img7, img7 + W7_XSLOTS, strip);
+    else w7_body<4, 3>(p, img7, img7 + W7_XSLOTS, strip);
+}
+
 }  // namespace
 
 static int g_c7_mode = -1;
@@ -137,5 +276,22 @@ int egm_conv_c7_launch(const void* x, int ldx, const void* wf, const float* bias
     p.tiles_y = egm_cdiv(H, C7_R); p.tiles_x = egm_cdiv(W, C7_TW);
     hipLaunchKernelGGL(conv7x7_c16_kernel, dim3(N * p.tiles_y * p.tiles_x), dim3(256), 0, (hipStream_t)s, p);
     EGM_CHECK_LAUNCH("conv7x7_c16");
+    return EGM_OK;
+}
+
+/* workgroups (= slabs) of the weight-gradient kernel for a shape it takes, else 0 */
+int egm_conv_c7_wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil) {
+    if (!egm_conv_c7_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil)) return 0;
+    const long long nb = (long long)N * egm_cdiv(H, W7_RB) * egm_cdiv(W, W7_TW);
+    if (nb >= (1LL << 31)) return 0;
+    return (int)(nb < 512 ? nb : 512);                  // two workgroups per CU, persistent over bands; one slab per workgroup
+}
+
+int egm_conv_c7_wgrad_launch(const void* x, int ldx, const void* dy, int lddy, float* slab, int nslab, int N, int H, int W, egm_stream_t s) {
+    W7Params p;
+    p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.slab = slab; p.ldx = ldx; p.lddy = lddy; p.N = N; p.H = H; p.W = W;
+    p.tiles_y = egm_cdiv(H, W7_RB); p.tiles_x = egm_cdiv(W, W7_TW); p.nbands = N * p.tiles_y * p.tiles_x;
+    hipLaunchKernelGGL(conv7x7_c16_wgrad_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)s, p);
+    EGM_CHECK_LAUNCH("conv7x7_c16_wgrad");
     return EGM_OK;
 }

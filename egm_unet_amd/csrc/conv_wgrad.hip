@@ -33,6 +33,10 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
+// conv7x7_c16.hip: weight gradient of the 16 -> 16 channel 7x7 conv (transposed 16x16x32 MFMA operands, all taps in one wave)
+int egm_conv_c7_wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
+int egm_conv_c7_wgrad_launch(const void* x, int ldx, const void* dy, int lddy, float* slab, int nslab, int N, int H, int W, egm_stream_t s);
+
 namespace {
 
 constexpr int TH = 8, TW = 32;
@@ -902,6 +906,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 
+// the same for MANY slabs of a SMALL gradient (the 16 x 16 x 49 layer writes 512 slabs of 50 KB: 196 blocks of the kernel above, each
+// thread walking 128 slabs, took three times the weight-gradient kernel itself): 16 slab lanes per element instead of 4.  Fixed order:
+// lane sl adds slabs sl, sl+16, ...; the lanes are combined by a balanced tree.
+__global__ __launch_bounds__(1024) void wgrad_reduce_wide_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nslab, int taps,
+                                                                 int CoutP, int CinP, int CoutR, int CinR, int groups, int accumulate) {
+    __shared__ float red[1024];
+    const long long total = (long long)taps * CoutP * CinP;
+    const int cin_g = CinR / groups, cout_g = CoutR / groups;
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;
+    float s = 0.f;
+    if (i < total)
+        for (int k = sl; k < nslab; k += 16) s += slab[(long long)k * total + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 8; w > 0; w >>= 1) {
+        if (sl < w) red[threadIdx.x] += red[threadIdx.x + w * 64];
+        __syncthreads();
+    }
+    if (sl == 0 && i < total) {
+        s = red[e];
+        const int ci = (int)(i % CinP), co = (int)((i / CinP) % CoutP), tap = (int)(i / ((long long)CinP * CoutP));
+        if (co < CoutR && ci < CinR && (co / cout_g) == (ci / cin_g)) {
+            const long long o = ((long long)co * cin_g + (ci % cin_g)) * taps + tap;
+            dw[o] = accumulate ? dw[o] + s : s;
+        }
+    }
+}
+
 // deferred reduction of MANY convolutions' slabs in one launch (end of backward): block -> (conv, 64-element chunk)
 struct WredEntry { const float* slab; float* dw; int nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate, chunk0, pad; };
 // block = kWredElems consecutive packed elements of one conv: 64 float4 columns x 4 slab lanes, two slabs per lane in flight.  (One
@@ -950,11 +983,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WredEntry
     }
 }
 
-struct WgradPlan { int A, B, C, ntaps, ngroups, nsplit, nco_tiles, nci_tiles, npt, tiles_y, tiles_x, dma, ws, cf_off; size_t smem; long long slab_bytes; };
+struct WgradPlan { int A, B, C, ntaps, ngroups, nsplit, nco_tiles, nci_tiles, npt, tiles_y, tiles_x, dma, ws, cf_off, c7; size_t smem; long long slab_bytes; };
 
 // smooth: a prologue with a sigmoid / SiLU activation (rare: the 4-wave kernel takes it; the slab count does not depend on it)
 int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, WgradPlan* pl, bool pre = false, bool smooth = false) {
     if (KH == 1 && KW == 1) dil = 1;
+    pl->c7 = 0;
+    if (!pre) {
+        // 16 -> 16 channels, 7x7 (conv7x7_c16.hip): its own kernel, its own slab count; nothing else of the plan is used
+        const int ns = egm_conv_c7_wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil);
+        if (ns > 0) {
+            memset(pl, 0, sizeof(*pl));
+            pl->c7 = 1; pl->ntaps = 7; pl->ngroups = 7; pl->nsplit = ns; pl->A = pl->B = 1; pl->C = 4;
+            pl->slab_bytes = (long long)ns * KH * KW * Cout * Cin * (long long)sizeof(float);
+            return EGM_OK;
+        }
+    }
     if (dil == 1) {
         if (KH == 3 && KW == 3) { pl->ntaps = 9; pl->ngroups = 1; }
         else if (KH == 1 && KW == 1) { pl->ntaps = 1; pl->ngroups = 1; }
@@ -1157,7 +1201,8 @@ extern "C" int egm_conv_wgrad_kernel_name(int dtype, int pre, int N, int H, int 
     if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl, pre != 0) != EGM_OK) return -1;
     char tmp[96];
     static const bool rot_on = getenv("EGM_WGRAD_ROT") ? atoi(getenv("EGM_WGRAD_ROT")) != 0 : true;
-    if (dtype == EGM_BF16 && pl.ws)
+    if (pl.c7) snprintf(tmp, sizeof(tmp), "conv7x7_c16_wgrad_kernel");
+    else if (dtype == EGM_BF16 && pl.ws)
         snprintf(tmp, sizeof(tmp), "conv_wgrad_ws_kernel<%d, %s, %s>", pl.ntaps, pre ? "true" : "false", (pl.ntaps == 9 && pl.C == 1 && rot_on) ? "true" : "false");
     else
         snprintf(tmp, sizeof(tmp), "conv_wgrad_kernel<%s, %d, %s>", dtype == EGM_BF16 ? "bf16_t" : "float", pl.ntaps, pre ? "true" : "false");
@@ -1234,7 +1279,8 @@ extern "C" int egm_conv_wgrad_pre(int dtype, const void* x, int ldx, int xpre_mo
     // inside a launch group only the slab-only form is recorded: with dw the reduction below needs the slabs at once
     const bool paused = dw != nullptr && egm_group_recording();
     if (paused) egm_group_set_recording(false);
-    if (dtype == EGM_BF16) rc = dispatch_wgrad<bf16_t>(p, pl, st);
+    if (pl.c7) rc = egm_conv_c7_wgrad_launch(x, ldx, dy, lddy, (float*)workspace, pl.nsplit, N, H, W, s);
+    else if (dtype == EGM_BF16) rc = dispatch_wgrad<bf16_t>(p, pl, st);
     else if (dtype == EGM_F32) rc = dispatch_wgrad<float>(p, pl, st);
     else rc = EGM_ERR_ARG;
     if (paused) egm_group_set_recording(true);
@@ -1243,8 +1289,12 @@ extern "C" int egm_conv_wgrad_pre(int dtype, const void* x, int ldx, int xpre_mo
     if (dw == nullptr) return EGM_OK;                  // slabs only: the caller reduces later with egm_wgrad_reduce_multi
     const long long total = (long long)KH * KW * Cout * Cin;
     const int grid = (int)((total + 63) / 64);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)workspace, dw, pl.nsplit,
-                       KH * KW, Cout, Cin, CoutR, CinR, groups, accumulate);
+    if (pl.nsplit >= 256 && grid < 1024)               // many slabs of a small gradient: more slab lanes per element
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(grid), dim3(1024), 0, st, (const float*)workspace, dw, pl.nsplit,
+                           KH * KW, Cout, Cin, CoutR, CinR, groups, accumulate);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)workspace, dw, pl.nsplit,
+                           KH * KW, Cout, Cin, CoutR, CinR, groups, accumulate);
     EGM_CHECK_LAUNCH("wgrad_reduce");
     return EGM_OK;
 }
