@@ -251,6 +251,98 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     else w7_body<4, 3>(p, img7, img7 + W7_XSLOTS, strip);
 }
 
+// ---- weight gradient of the DILATED 3x3 convs on 16 channels (EdgeEnhancedGRFB branches at the 64-channel level, dilation 12 / 24 /
+// 36, src/EGM-UNet.py:1256-1278): dW[r*3+s][co][ci] = sum dy[n,y,x,co] * x[n, y+(r-1)d, x+(s-1)d, ci].  Same operand scheme as the 7x7
+// kernel above (16x16x32 MFMA, K = 32 pixels of a row, transposed reads); nine accumulators per wave.  The taps are d pixels apart,
+// so nothing is shared between neighbouring output rows: a band is 2 rows x 128 pixels, staged as three x row-bands (one per kernel
+// row, each 128 + 2d pixels wide) + the dy band, 46 KiB at d = 36; the kernel is an L2 -> LDS copy with a handful of MFMAs attached
+// (the generic kernel walked the same data with 32x32x16 tiles, a quarter of each real).  Four strips summed in LDS, one slab per workgroup.
+constexpr int WD_RB = 2, WD_TW = 128, WD_MAXD = 36, WD_PWMAX = WD_TW + 2 * WD_MAXD;
+constexpr int WD_XSLOTS_MAX = 3 * WD_RB * WD_PWMAX * 2, WD_DSLOTS = WD_RB * WD_TW * 2;
+constexpr int WD_XLD = (WD_XSLOTS_MAX + 255) / 256, WD_DLD = (WD_DSLOTS + 255) / 256;
+
+struct WDParams {
+    const bf16_t* x; const bf16_t* dy; float* slab;
+    int ldx, lddy, N, H, W, dil, tiles_y, tiles_x, nbands;
+};
+
+__global__ __launch_bounds__(256) void conv3x3d_c16_wgrad_kernel(WDParams p) {
+    __shared__ __attribute__((aligned(16))) uint4 imgd[WD_XSLOTS_MAX + WD_DSLOTS];
+    uint4* const ximg = imgd;
+    uint4* const dimg = imgd + WD_XSLOTS_MAX;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);        // the wave's 32-pixel strip
+    const int d = p.dil, PW = WD_TW + 2 * d, xslots = 3 * WD_RB * PW * 2;
+    f32x4_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int tpi = p.tiles_y * p.tiles_x;
+    for (int band = blockIdx.x; band < p.nbands; band += gridDim.x) {
+        const int n = band / tpi, trem = band - n * tpi, ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+        const int y0 = ty * WD_RB, x0 = tx * WD_TW;
+        // x image: [kernel row r][band row][PW pixels][2 halves]; pixel column c <-> image column x0 - d + c
+        uint4 rx[WD_XLD], rd[WD_DLD];
+#pragma unroll
+        for (int k = 0; k < WD_XLD; ++k) {
+            const int slot = tid + k * 256, pix = slot >> 1, h = slot & 1, prow = pix / PW, col = pix - prow * PW;
+            const int r = prow / WD_RB, yy = prow - r * WD_RB;
+            const int iy = y0 + yy + (r - 1) * d, ix = x0 - d + col;
+            rx[k] = make_uint4(0, 0, 0, 0);
+            if (slot < xslots && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                rx[k] = *reinterpret_cast<const uint4*>(p.x + ((long long)(n * p.H + iy) * p.W + ix) * p.ldx + h * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < WD_DLD; ++k) {
+            const int slot = tid + k * 256, pix = slot >> 1, h = slot & 1, prow = pix / WD_TW, col = pix - prow * WD_TW;
+            const int iy = y0 + prow, ix = x0 + col;
+            rd[k] = make_uint4(0, 0, 0, 0);
+            if (slot < WD_DSLOTS && iy < p.H && ix < p.W)
+                rd[k] = *reinterpret_cast<const uint4*>(p.dy + ((long long)(n * p.H + iy) * p.W + ix) * p.lddy + h * 8);
+        }
+        __syncthreads();                                            // the previous band's fragments have been read
+#pragma unroll
+        for (int k = 0; k < WD_XLD; ++k) { const int slot = tid + k * 256; if (slot < xslots) ximg[slot] = rx[k]; }
+#pragma unroll
+        for (int k = 0; k < WD_DLD; ++k) { const int slot = tid + k * 256; if (slot < WD_DSLOTS) dimg[slot] = rd[k]; }
+        __syncthreads();
+        const unsigned char* xb = reinterpret_cast<const unsigned char*>(ximg);
+        const unsigned char* db = reinterpret_cast<const unsigned char*>(dimg);
+#pragma unroll
+        for (int yy = 0; yy < WD_RB; ++yy) {
+            const bf16x8_t fa = w7_frag(db, yy * WD_TW + wv * 32, lane);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s2 = 0; s2 < 3; ++s2) {
+                    const bf16x8_t fb = w7_frag(xb, (r * WD_RB + yy) * PW + wv * 32 + s2 * d, lane);
+                    acc[r * 3 + s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[r * 3 + s2], 0, 0, 0);
+                }
+        }
+    }
+    // ---- the four strips summed through LDS in wave order; wave 0 writes the slab
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(imgd);
+    for (int w = 1; w < 4; ++w) {
+        __syncthreads();
+        if (wv == w) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) red[t * 64 + lane] = acc[t];
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] += red[t * 64 + lane];
+        }
+    }
+    if (wv == 0) {
+        float* slab = p.slab + (long long)blockIdx.x * 9 * 256;
+        const int q = lane >> 4, ci = lane & 15;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) slab[(t * 16 + 4 * q + i) * 16 + ci] = acc[t][i];
+    }
+}
+
 }  // namespace
 
 static int g_c7_mode = -1;
@@ -293,5 +385,23 @@ int egm_conv_c7_wgrad_launch(const void* x, int ldx, const void* dy, int lddy, f
     p.tiles_y = egm_cdiv(H, W7_RB); p.tiles_x = egm_cdiv(W, W7_TW); p.nbands = N * p.tiles_y * p.tiles_x;
     hipLaunchKernelGGL(conv7x7_c16_wgrad_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)s, p);
     EGM_CHECK_LAUNCH("conv7x7_c16_wgrad");
+    return EGM_OK;
+}
+
+/* workgroups (= slabs) of the dilated-3x3 16-channel weight-gradient kernel for a shape it takes, else 0 (same switch as the 7x7 kernels) */
+int egm_conv_c16d_wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil) {
+    if (dtype != EGM_BF16 || KH != 3 || KW != 3 || dil < 2 || dil > WD_MAXD || Cin != 16 || Cout != 16 || !egm_conv_c7_mode(-1)) return 0;
+    const long long nb = (long long)N * egm_cdiv(H, WD_RB) * egm_cdiv(W, WD_TW);
+    if (nb >= (1LL << 31)) return 0;
+    return (int)(nb < 512 ? nb : 512);
+}
+
+int egm_conv_c16d_wgrad_launch(const void* x, int ldx, const void* dy, int lddy, float* slab, int nslab, int N, int H, int W, int dil,
+                               egm_stream_t s) {
+    WDParams p;
+    p.x = (const bf16_t*)x; p.dy = (const bf16_t*)dy; p.slab = slab; p.ldx = ldx; p.lddy = lddy; p.N = N; p.H = H; p.W = W; p.dil = dil;
+    p.tiles_y = egm_cdiv(H, WD_RB); p.tiles_x = egm_cdiv(W, WD_TW); p.nbands = N * p.tiles_y * p.tiles_x;
+    hipLaunchKernelGGL(conv3x3d_c16_wgrad_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)s, p);
+    EGM_CHECK_LAUNCH("conv3x3d_c16_wgrad");
     return EGM_OK;
 }

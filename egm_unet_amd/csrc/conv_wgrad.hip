@@ -36,6 +36,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 // conv7x7_c16.hip: weight gradient of the 16 -> 16 channel 7x7 conv (transposed 16x16x32 MFMA operands, all taps in one wave)
 int egm_conv_c7_wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
 int egm_conv_c7_wgrad_launch(const void* x, int ldx, const void* dy, int lddy, float* slab, int nslab, int N, int H, int W, egm_stream_t s);
+int egm_conv_c16d_wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
+int egm_conv_c16d_wgrad_launch(const void* x, int ldx, const void* dy, int lddy, float* slab, int nslab, int N, int H, int W, int dil,
+                               egm_stream_t s);
 
 namespace {
 
@@ -998,6 +1001,13 @@ int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW
             pl->slab_bytes = (long long)ns * KH * KW * Cout * Cin * (long long)sizeof(float);
             return EGM_OK;
         }
+        const int nd = egm_conv_c16d_wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil);
+        if (nd > 0) {                                       // 16 -> 16 channels, dilated 3x3: likewise
+            memset(pl, 0, sizeof(*pl));
+            pl->c7 = 2; pl->ntaps = 3; pl->ngroups = 3; pl->nsplit = nd; pl->A = pl->B = 1; pl->C = 4;
+            pl->slab_bytes = (long long)nd * KH * KW * Cout * Cin * (long long)sizeof(float);
+            return EGM_OK;
+        }
     }
     if (dil == 1) {
         if (KH == 3 && KW == 3) { pl->ntaps = 9; pl->ngroups = 1; }
@@ -1201,7 +1211,7 @@ extern "C" int egm_conv_wgrad_kernel_name(int dtype, int pre, int N, int H, int 
     if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl, pre != 0) != EGM_OK) return -1;
     char tmp[96];
     static const bool rot_on = getenv("EGM_WGRAD_ROT") ? atoi(getenv("EGM_WGRAD_ROT")) != 0 : true;
-    if (pl.c7) snprintf(tmp, sizeof(tmp), "conv7x7_c16_wgrad_kernel");
+    if (pl.c7) snprintf(tmp, sizeof(tmp), pl.c7 == 1 ? "conv7x7_c16_wgrad_kernel" : "conv3x3d_c16_wgrad_kernel");
     else if (dtype == EGM_BF16 && pl.ws)
         snprintf(tmp, sizeof(tmp), "conv_wgrad_ws_kernel<%d, %s, %s>", pl.ntaps, pre ? "true" : "false", (pl.ntaps == 9 && pl.C == 1 && rot_on) ? "true" : "false");
     else
@@ -1279,7 +1289,8 @@ extern "C" int egm_conv_wgrad_pre(int dtype, const void* x, int ldx, int xpre_mo
     // inside a launch group only the slab-only form is recorded: with dw the reduction below needs the slabs at once
     const bool paused = dw != nullptr && egm_group_recording();
     if (paused) egm_group_set_recording(false);
-    if (pl.c7) rc = egm_conv_c7_wgrad_launch(x, ldx, dy, lddy, (float*)workspace, pl.nsplit, N, H, W, s);
+    if (pl.c7 == 1) rc = egm_conv_c7_wgrad_launch(x, ldx, dy, lddy, (float*)workspace, pl.nsplit, N, H, W, s);
+    else if (pl.c7 == 2) rc = egm_conv_c16d_wgrad_launch(x, ldx, dy, lddy, (float*)workspace, pl.nsplit, N, H, W, dil, s);
     else if (dtype == EGM_BF16) rc = dispatch_wgrad<bf16_t>(p, pl, st);
     else if (dtype == EGM_F32) rc = dispatch_wgrad<float>(p, pl, st);
     else rc = EGM_ERR_ARG;

@@ -82,3 +82,38 @@ def test_conv_fwd_split_equals_one_output(shape):
     L.call("egm_conv_fwd_split", dt, ptr(x), Cin, ptr(wf), ptr(ya), cs, ptr(yb), Cout - cs, cs, N, H, W, Cin, Cout, 3, 3, 1, stream())
     torch.cuda.synchronize()
     assert torch.equal(ya, y[..., :cs]) and torch.equal(yb, y[..., cs:])
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 160), (1, 40, 100), (2, 37, 129), (1, 128, 128)])
+@pytest.mark.parametrize("dil", [12, 24, 36])
+def test_dilated_c16_weight_gradient_matches_generic_kernel_and_torch(shape, dil):
+    """conv3x3d_c16_wgrad_kernel (16 -> 16 channels, dilation 12 / 24 / 36: the EdgeEnhancedGRFB branch convs, src/EGM-UNet.py:1256-1278)
+    against the generic weight-gradient kernel and torch autograd."""
+    from egm_unet_amd import ops
+    from egm_unet_amd._lib import lib
+    N, H, W = shape
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(N, H, W, 16, generator=g).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(16, 16, 3, 3, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    gy = torch.randn(N, H, W, 16, generator=g).to(DEV).to(torch.bfloat16)
+    L = lib()
+    old = L.cdll.egm_conv_c7_mode(-1)
+    res = []
+    try:
+        for mode in (1, 0):
+            L.cdll.egm_conv_c7_mode(mode)
+            ops.bump_weight_generation()
+            w.grad = None
+            xa = x.clone().requires_grad_(True)
+            ops.conv2d(xa, w, None, dil=dil).backward(gy)
+            torch.cuda.synchronize()
+            res.append(w.grad.clone())
+    finally:
+        L.cdll.egm_conv_c7_mode(old)
+        ops.bump_weight_generation()
+    dw1, dw0 = res
+    werr = float((dw1 - dw0).abs().max()) / max(1e-12, float(dw0.abs().max()))
+    assert werr <= 2e-5, werr
+    ww = w.detach().clone().requires_grad_(True)
+    F.conv2d(x.float().permute(0, 3, 1, 2), ww, None, padding=dil, dilation=dil).backward(gy.float().permute(0, 3, 1, 2))
+    assert float((dw1 - ww.grad).abs().max()) <= 1e-4 * max(1e-6, float(ww.grad.abs().max()))
