@@ -343,6 +343,108 @@ __global__ __launch_bounds__(256) void conv3x3d_c16_wgrad_kernel(WDParams p) {
     }
 }
 
+// ---- forward / data gradient of the same dilated 3x3 convs: y[p][co] = sum_{r,s,ci} x[p + ((r-1)d, (s-1)d)][ci] * wf[r*3+s][co][ci] ----------
+// The LDS-free kernel (conv_direct.hip) reads nine 32-byte taps per pixel straight from L2 into MFMA operands: 288 B per pixel of
+// latency-bound gathers, 75 us for three branches at 8 x 256^2.  Here a workgroup stages the three input row bands of its 2 x 128-pixel
+// output band once (the staging of the weight-gradient kernel above: 3.6-4.7x the band instead of 9x, whole rows), and the MFMA is the
+// 7x7 kernel's: M = 16 couts, N = 16 pixels, K = 32 = two taps x 16 channels, 5 MFMAs per 16 pixels (the tenth tap slot carries zero
+// weights), weights in 20 registers.  BatchNorm partial sums (of the rounded outputs) per workgroup, as the other conv kernels write them.
+struct CDParams {
+    const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y; float* stats;
+    int ldx, ldy, N, H, W, dil, bias_n, tiles_y, tiles_x;
+};
+
+__global__ __launch_bounds__(256) void conv3x3d_c16_kernel(CDParams p) {
+    __shared__ __attribute__((aligned(16))) uint4 imgd[WD_XSLOTS_MAX];
+    __shared__ float sred[4 * 2 * 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);        // the wave's 32-pixel strip
+    const int px = lane & 15, q = lane >> 4;
+    const int d = p.dil, PW = WD_TW + 2 * d, xslots = 3 * WD_RB * PW * 2;
+    int b = blockIdx.x;
+    const int tx = b % p.tiles_x; b /= p.tiles_x;
+    const int ty = b % p.tiles_y; const int n = b / p.tiles_y;
+    const int y0 = ty * WD_RB, x0 = tx * WD_TW;
+    uint4 rx[WD_XLD];
+#pragma unroll
+    for (int k = 0; k < WD_XLD; ++k) {
+        const int slot = tid + k * 256, pix = slot >> 1, h = slot & 1, prow = pix / PW, col = pix - prow * PW;
+        const int r = prow / WD_RB, yy = prow - r * WD_RB;
+        const int iy = y0 + yy + (r - 1) * d, ix = x0 - d + col;
+        rx[k] = make_uint4(0, 0, 0, 0);
+        if (slot < xslots && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            rx[k] = *reinterpret_cast<const uint4*>(p.x + ((long long)(n * p.H + iy) * p.W + ix) * p.ldx + h * 8);
+    }
+    // A fragments: lane (q, co = px) holds wf[tap 2k + (q>>1)][co][8*(q&1) .. +8]; tap 9 does not exist: zero weights
+    bf16x8_t wa[5];
+    int boff[5];            // the lane's byte offset of tap-pair k inside the image, relative to (band row 0 of kernel row 0, column 0)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int t = 2 * k + (q >> 1);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t < 9) v = *reinterpret_cast<const uint4*>(p.w + (t * 16 + px) * 16 + (q & 1) * 8);
+        wa[k] = *reinterpret_cast<const bf16x8_t*>(&v);
+        const int tt = t < 9 ? t : 8, r = tt / 3, s2 = tt - 3 * r;  // the zero tap re-reads tap 8's (finite) data
+        boff[k] = ((r * WD_RB) * PW + s2 * d) * 32 + (q & 1) * 16;
+    }
+#pragma unroll
+    for (int k = 0; k < WD_XLD; ++k) { const int slot = tid + k * 256; if (slot < xslots) imgd[slot] = rx[k]; }
+    __syncthreads();
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(imgd);
+    f32x4_t acc[WD_RB][2];
+#pragma unroll
+    for (int yy = 0; yy < WD_RB; ++yy)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            acc[yy][nb] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            const int pbase = (yy * PW + wv * 32 + nb * 16 + px) * 32;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const uint4 v = *reinterpret_cast<const uint4*>(xb + pbase + boff[k]);
+                acc[yy][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[k], *reinterpret_cast<const bf16x8_t*>(&v), acc[yy][nb], 0, 0, 0);
+            }
+        }
+    // ---- epilogue: lane holds couts 4q .. 4q+3 of pixel (y0 + yy, x0 + 32 wv + 16 nb + px)
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bs[i] = (4 * q + i) < p.bias_n ? p.bias[4 * q + i] : 0.f;
+    }
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int yy = 0; yy < WD_RB; ++yy)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int oy = y0 + yy, ox = x0 + 32 * wv + 16 * nb + px;
+            if (oy < p.H && ox < p.W) {
+                uint2 o;
+                o.x = (uint32_t)f32_to_bf16(acc[yy][nb][0] + bs[0]) | ((uint32_t)f32_to_bf16(acc[yy][nb][1] + bs[1]) << 16);
+                o.y = (uint32_t)f32_to_bf16(acc[yy][nb][2] + bs[2]) | ((uint32_t)f32_to_bf16(acc[yy][nb][3] + bs[3]) << 16);
+                *reinterpret_cast<uint2*>(p.y + ((long long)(n * p.H + oy) * p.W + ox) * p.ldy + 4 * q) = o;
+                const float v0 = __uint_as_float(o.x << 16), v1 = __uint_as_float(o.x & 0xffff0000u);
+                const float v2 = __uint_as_float(o.y << 16), v3 = __uint_as_float(o.y & 0xffff0000u);
+                ssum[0] += v0; ssum[1] += v1; ssum[2] += v2; ssum[3] += v3;
+                ssq[0] = fmaf(v0, v0, ssq[0]); ssq[1] = fmaf(v1, v1, ssq[1]); ssq[2] = fmaf(v2, v2, ssq[2]); ssq[3] = fmaf(v3, v3, ssq[3]);
+            }
+        }
+    if (p.stats != nullptr) {
+        // lanes with equal q hold the same four couts: sum over the 16 pixel lanes, then over the four waves in fixed order
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            for (int o = 1; o < 16; o <<= 1) { ssum[i] += __shfl_xor(ssum[i], o, 64); ssq[i] += __shfl_xor(ssq[i], o, 64); }
+        if (px == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sred[(wv * 2 + 0) * 16 + 4 * q + i] = ssum[i]; sred[(wv * 2 + 1) * 16 + 4 * q + i] = ssq[i]; }
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const int which = tid >> 4, c = tid & 15;
+            const float v = (sred[(0 * 2 + which) * 16 + c] + sred[(1 * 2 + which) * 16 + c]) + (sred[(2 * 2 + which) * 16 + c] + sred[(3 * 2 + which) * 16 + c]);
+            p.stats[((long long)blockIdx.x * 2 + which) * 16 + c] = v;
+        }
+    }
+}
+
 }  // namespace
 
 static int g_c7_mode = -1;
@@ -403,5 +505,23 @@ int egm_conv_c16d_wgrad_launch(const void* x, int ldx, const void* dy, int lddy,
     p.tiles_y = egm_cdiv(H, WD_RB); p.tiles_x = egm_cdiv(W, WD_TW); p.nbands = N * p.tiles_y * p.tiles_x;
     hipLaunchKernelGGL(conv3x3d_c16_wgrad_kernel, dim3(nslab), dim3(256), 0, (hipStream_t)s, p);
     EGM_CHECK_LAUNCH("conv3x3d_c16_wgrad");
+    return EGM_OK;
+}
+
+/* statistics rows (= workgroups) of the dilated-3x3 16-channel forward / data-gradient kernel for a shape it takes, else 0 */
+int egm_conv_c16d_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil) {
+    if (dtype != EGM_BF16 || KH != 3 || KW != 3 || dil < 2 || dil > WD_MAXD || Cin != 16 || Cout != 16 || !egm_conv_c7_mode(-1)) return 0;
+    const long long nb = (long long)N * egm_cdiv(H, WD_RB) * egm_cdiv(W, WD_TW);
+    return nb < (1LL << 30) ? (int)nb : 0;
+}
+
+int egm_conv_c16d_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, float* stats, int N, int H,
+                         int W, int dil, egm_stream_t s) {
+    CDParams p;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)wf; p.bias = bias; p.y = (bf16_t*)y; p.stats = stats;
+    p.ldx = ldx; p.ldy = ldy; p.N = N; p.H = H; p.W = W; p.dil = dil; p.bias_n = bias ? bias_n : 0;
+    p.tiles_y = egm_cdiv(H, WD_RB); p.tiles_x = egm_cdiv(W, WD_TW);
+    hipLaunchKernelGGL(conv3x3d_c16_kernel, dim3(N * p.tiles_y * p.tiles_x), dim3(256), 0, (hipStream_t)s, p);
+    EGM_CHECK_LAUNCH("conv3x3d_c16");
     return EGM_OK;
 }

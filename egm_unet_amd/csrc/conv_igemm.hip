@@ -53,6 +53,9 @@ int egm_conv_tile_launch(const void* x, int ldx, const void* wf, const float* bi
 int egm_conv_c7_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
 int egm_conv_c7_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, int N, int H, int W,
                        egm_stream_t s);
+int egm_conv_c16d_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
+int egm_conv_c16d_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy, float* stats, int N, int H,
+                         int W, int dil, egm_stream_t s);
 
 namespace {
 
@@ -815,7 +818,7 @@ int launch_pipe(ConvParams& p, int G, hipStream_t st) {
 }
 
 // One place decides kernel, tile shape and grouping, so the stats-tile count the caller allocates always matches the launch.
-struct ConvPlan { bool pipe, direct, tile, wreg, c7; int tile_cfg; int R, NT, tiles_y, tiles_x, npt, nct, G; size_t smem; };
+struct ConvPlan { bool pipe, direct, tile, wreg, c7, c16d = false; int tile_cfg; int R, NT, tiles_y, tiles_x, npt, nct, G; size_t smem; };
 ConvPlan conv_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int pre_mode = EGM_PRE_NONE) {
     ConvPlan c;
     if (KH == 1 && KW == 1) dil = 1;
@@ -825,6 +828,9 @@ ConvPlan conv_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, in
     // taken at launch when no BatchNorm statistics are asked for (the kernel has no statistics epilogue); the rest of the plan stays
     // that of the generic kernel, so a caller's statistics-tile count does not depend on it
     c.c7 = pre_mode == EGM_PRE_NONE && !egm_group_recording() && egm_conv_c7_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil) != 0;
+    // dilated 3x3 on 16 channels (conv7x7_c16.hip): launched at once, also inside a launch group (it has no merged form)
+    const int c16d = pre_mode == EGM_PRE_NONE ? egm_conv_c16d_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil) : 0;
+    if (c16d > 0) { c.c16d = true; c.pipe = c.direct = c.tile = c.wreg = false; c.R = 0; c.NT = 1; c.nct = 1; c.tiles_y = c.tiles_x = c.npt = 0; c.smem = 0; c.G = c16d; return c; }
     c.wreg = pre_mode == EGM_PRE_NONE && egm_conv_wreg_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.G) != 0;
     if (c.wreg) { c.pipe = c.direct = c.tile = false; c.R = 2; c.NT = 1; c.nct = 1; c.tiles_y = c.tiles_x = c.npt = 0; c.smem = 0; return c; }
     c.tile = pre_mode == EGM_PRE_NONE && egm_conv_tile_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.tile_cfg, &c.nct, &c.G) != 0;
@@ -864,7 +870,8 @@ extern "C" int egm_conv_kernel_name(int dtype, int pre_mode, int N, int H, int W
     const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, pre_mode);
     char tmp[96];
     const int pre = pre_mode == EGM_PRE_NONE ? 0 : 1;
-    if (c.c7) snprintf(tmp, sizeof(tmp), "conv7x7_c16_kernel");
+    if (c.c16d) snprintf(tmp, sizeof(tmp), "conv3x3d_c16_kernel");
+    else if (c.c7) snprintf(tmp, sizeof(tmp), "conv7x7_c16_kernel");
     else if (c.wreg) snprintf(tmp, sizeof(tmp), "%s", egm_conv_wreg_name(Cin));
     else if (c.tile) snprintf(tmp, sizeof(tmp), "%s", egm_conv_tile_name(c.tile_cfg));
     else if (c.direct) snprintf(tmp, sizeof(tmp), "conv_direct_kernel<%d, %d, %s>", c.NT, pre, KH == 1 ? "true" : "false");
@@ -950,6 +957,7 @@ extern "C" int egm_conv_fwd_pre(int dtype, const void* x, int ldx, int pre_mode,
     p.wl = egm_w_layout(dtype, KH, KW, Cin, Cout);
     p.pre.mode = pre_mode; p.pre.act = pre_act; p.pre.cf = pre_cf; p.pre.aux = pre_aux; p.pre.ld_aux = pre_ld_aux; p.pre.C = Cin;
     const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, pre_mode);
+    if (c.c16d) return egm_conv_c16d_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, dil, s);
     if (c.c7 && stats == nullptr) return egm_conv_c7_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, N, H, W, s);
     if (c.wreg) return egm_conv_wreg_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, c.G, s);
     if (c.tile) return egm_conv_tile_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, c.tile_cfg, c.nct, c.G, s);

@@ -86,9 +86,9 @@ def test_conv_fwd_split_equals_one_output(shape):
 
 @pytest.mark.parametrize("shape", [(2, 64, 160), (1, 40, 100), (2, 37, 129), (1, 128, 128)])
 @pytest.mark.parametrize("dil", [12, 24, 36])
-def test_dilated_c16_weight_gradient_matches_generic_kernel_and_torch(shape, dil):
-    """conv3x3d_c16_wgrad_kernel (16 -> 16 channels, dilation 12 / 24 / 36: the EdgeEnhancedGRFB branch convs, src/EGM-UNet.py:1256-1278)
-    against the generic weight-gradient kernel and torch autograd."""
+def test_dilated_c16_kernels_match_generic_kernels_and_torch(shape, dil):
+    """conv3x3d_c16_kernel / conv3x3d_c16_wgrad_kernel (16 -> 16 channels, dilation 12 / 24 / 36: the EdgeEnhancedGRFB branch convs,
+    src/EGM-UNet.py:1256-1278): forward with statistics, data gradient and weight gradient against the generic kernels and torch."""
     from egm_unet_amd import ops
     from egm_unet_amd._lib import lib
     N, H, W = shape
@@ -105,15 +105,27 @@ def test_dilated_c16_weight_gradient_matches_generic_kernel_and_torch(shape, dil
             ops.bump_weight_generation()
             w.grad = None
             xa = x.clone().requires_grad_(True)
-            ops.conv2d(xa, w, None, dil=dil).backward(gy)
+            y, stats = ops.conv2d(xa, w, None, dil=dil, want_stats=True)          # forward with BatchNorm partial sums, as BasicConv runs it
+            y.backward(gy)
             torch.cuda.synchronize()
-            res.append(w.grad.clone())
+            res.append((w.grad.clone(), y.detach().clone(), xa.grad.clone(), stats.double().sum(0).clone()))
     finally:
         L.cdll.egm_conv_c7_mode(old)
         ops.bump_weight_generation()
-    dw1, dw0 = res
+    (dw1, y1, dx1, st1), (dw0, y0, dx0, st0) = res
     werr = float((dw1 - dw0).abs().max()) / max(1e-12, float(dw0.abs().max()))
     assert werr <= 2e-5, werr
+    for a, r, what in ((y1, y0, "y"), (dx1, dx0, "dx")):                           # conv3x3d_c16_kernel vs the LDS-free kernel
+        err = float((a.float() - r.float()).abs().max()) / max(1e-6, float(r.float().abs().max()))
+        assert err <= 1e-2, (what, err)
+    # the statistics rows are the sums of the ROUNDED outputs the kernel stored
+    ref_st = torch.stack([y1.double().sum((0, 1, 2)), (y1.double() ** 2).sum((0, 1, 2))])
+    assert float((st1 - ref_st).abs().max()) <= 1e-4 * float(ref_st.abs().max())
     ww = w.detach().clone().requires_grad_(True)
-    F.conv2d(x.float().permute(0, 3, 1, 2), ww, None, padding=dil, dilation=dil).backward(gy.float().permute(0, 3, 1, 2))
+    xr = x.float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yr = F.conv2d(xr, ww, None, padding=dil, dilation=dil)
+    yr.backward(gy.float().permute(0, 3, 1, 2))
     assert float((dw1 - ww.grad).abs().max()) <= 1e-4 * max(1e-6, float(ww.grad.abs().max()))
+    wb = w.detach().to(torch.bfloat16).float()
+    yb = F.conv2d(x.float().permute(0, 3, 1, 2), wb, None, padding=dil, dilation=dil).permute(0, 2, 3, 1)
+    assert float((y1.float() - yb).abs().max()) <= 1e-2 * max(1.0, float(yb.abs().max()))
