@@ -482,51 +482,82 @@ template <> __device__ __forceinline__ void load2<bf16_t>(const bf16_t* p, float
     const uint32_t v = *reinterpret_cast<const uint32_t*>(p);
     a = __uint_as_float(v << 16); b = __uint_as_float(v & 0xffff0000u);
 }
+// Forward and data gradient are LDS-tiled like the weight gradient below: a workgroup owns a 16 x 64 pixel tile, the input tile with
+// its 3-pixel halo sits in LDS as fp32 and the 49 window reads per pixel are LDS reads of consecutive lanes.  (As 49 global loads
+// per lane the two kernels were L1-latency bound: 31 us each at 8 x 256^2 for 8 MB of data.)
+constexpr int SAF_TY = 16, SAF_TX = 64, SAF_PY = SAF_TY + 6, SAF_PX = SAF_TX + 6;
 template <typename T>
-__global__ void sa_conv7_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, T* __restrict__ y, int ldy, int N, int H, int W) {
-    const long long total = (long long)N * H * W;
-    for (long long p = blockIdx.x * 256LL + threadIdx.x; p < total; p += (long long)gridDim.x * 256) {
-        int xx, yy; egm_pix_yx(p, H, W, yy, xx);
-        float acc = 0.f;
+__global__ __launch_bounds__(256) void sa_conv7_fwd_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ w, T* __restrict__ y, int ldy, int N, int H, int W) {
+    __shared__ float2 sx[SAF_PY * SAF_PX];
+    __shared__ float sw[98];
+    if (threadIdx.x < 98) sw[threadIdx.x] = w[threadIdx.x];
+    const int tiles_x = (W + SAF_TX - 1) / SAF_TX, tiles_y = (H + SAF_TY - 1) / SAF_TY, ntiles = N * tiles_x * tiles_y;
+    const int tx = threadIdx.x & 63, ty0 = threadIdx.x >> 6;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int n = t / (tiles_x * tiles_y), tr = t - n * tiles_x * tiles_y;
+        const int y0 = (tr / tiles_x) * SAF_TY, x0 = (tr % tiles_x) * SAF_TX;
+        const long long img = (long long)n * H * W;
+        __syncthreads();                                           // previous tile's readers are done (and sw is visible)
+        for (int i = threadIdx.x; i < SAF_PY * SAF_PX; i += 256) {
+            const int py = i / SAF_PX, px = i - py * SAF_PX, gy = y0 + py - 3, gx = x0 + px - 3;
+            float a = 0.f, b2 = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) load2(x + (img + (long long)gy * W + gx) * ldx, a, b2);
+            sx[i] = make_float2(a, b2);
+        }
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            const int y2 = yy + r - 3;
-            if (y2 < 0 || y2 >= H) continue;
+        for (int k4 = 0; k4 < SAF_TY / 4; ++k4) {
+            const int ly = ty0 + 4 * k4, gy = y0 + ly, gx = x0 + tx;
+            float acc = 0.f;
 #pragma unroll
-            for (int q = 0; q < 7; ++q) {
-                const int x2 = xx + q - 3;
-                if (x2 < 0 || x2 >= W) continue;
-                float a, b;
-                load2(x + (p + (long long)(r - 3) * W + (q - 3)) * ldx, a, b);
-                acc += a * w[r * 7 + q] + b * w[49 + r * 7 + q];
+            for (int r = 0; r < 7; ++r)
+#pragma unroll
+                for (int q = 0; q < 7; ++q) {
+                    const float2 v = sx[(ly + r) * SAF_PX + tx + q];        // zero outside the image = the conv's zero padding
+                    acc += v.x * sw[r * 7 + q] + v.y * sw[49 + r * 7 + q];
+                }
+            if (gy < H && gx < W) {
+                float o[8]; zero8(o); o[0] = acc;
+                store8(y + (img + (long long)gy * W + gx) * ldy, o);
             }
         }
-        float o[8]; zero8(o); o[0] = acc;
-        store8(y + p * ldy, o);
     }
 }
 // dx[q][c] = sum_taps w[c][r][s] * dy[q - (r-3, s-3)]
 template <typename T>
-__global__ void sa_conv7_bwd_data_kernel(const T* __restrict__ dy, int lddy, const float* __restrict__ w, T* __restrict__ dx, int lddx, int N,
-                                         int H, int W) {
-    const long long total = (long long)N * H * W;
-    for (long long p = blockIdx.x * 256LL + threadIdx.x; p < total; p += (long long)gridDim.x * 256) {
-        int xx, yy; egm_pix_yx(p, H, W, yy, xx);
-        float a0 = 0.f, a1 = 0.f;
+__global__ __launch_bounds__(256) void sa_conv7_bwd_data_kernel(const T* __restrict__ dy, int lddy, const float* __restrict__ w, T* __restrict__ dx, int lddx, int N,
+                                                                int H, int W) {
+    __shared__ float sg[SAF_PY * SAF_PX];
+    __shared__ float sw[98];
+    if (threadIdx.x < 98) sw[threadIdx.x] = w[threadIdx.x];
+    const int tiles_x = (W + SAF_TX - 1) / SAF_TX, tiles_y = (H + SAF_TY - 1) / SAF_TY, ntiles = N * tiles_x * tiles_y;
+    const int tx = threadIdx.x & 63, ty0 = threadIdx.x >> 6;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int n = t / (tiles_x * tiles_y), tr = t - n * tiles_x * tiles_y;
+        const int y0 = (tr / tiles_x) * SAF_TY, x0 = (tr % tiles_x) * SAF_TX;
+        const long long img = (long long)n * H * W;
+        __syncthreads();
+        for (int i = threadIdx.x; i < SAF_PY * SAF_PX; i += 256) {
+            const int py = i / SAF_PX, px = i - py * SAF_PX, gy = y0 + py - 3, gx = x0 + px - 3;
+            sg[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? to_f32(dy[(img + (long long)gy * W + gx) * lddy]) : 0.f;
+        }
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 7; ++r) {
-            const int y2 = yy - (r - 3);
-            if (y2 < 0 || y2 >= H) continue;
+        for (int k4 = 0; k4 < SAF_TY / 4; ++k4) {
+            const int ly = ty0 + 4 * k4, gy = y0 + ly, gx = x0 + tx;
+            float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-            for (int q = 0; q < 7; ++q) {
-                const int x2 = xx - (q - 3);
-                if (x2 < 0 || x2 >= W) continue;
-                const float g = to_f32(dy[(p - (long long)(r - 3) * W - (q - 3)) * lddy]);
-                a0 += g * w[r * 7 + q]; a1 += g * w[49 + r * 7 + q];
+            for (int r = 0; r < 7; ++r)
+#pragma unroll
+                for (int q = 0; q < 7; ++q) {
+                    const float g = sg[(ly + 6 - r) * SAF_PX + tx + 6 - q];    // dy at (pixel - (r-3, q-3)); zero outside the image
+                    a0 += g * sw[r * 7 + q]; a1 += g * sw[49 + r * 7 + q];
+                }
+            if (gy < H && gx < W) {
+                float o[8]; zero8(o); o[0] = a0; o[1] = a1;
+                store8(dx + (img + (long long)gy * W + gx) * lddx, o);
             }
         }
-        float o[8]; zero8(o); o[0] = a0; o[1] = a1;
-        store8(dx + p * lddx, o);
     }
 }
 // dw[c][r][s] = sum_p dy[p] * x[p + (r-3, s-3)][c]; per-block partials [nblk][98].
@@ -1013,11 +1044,15 @@ extern "C" int egm_merge357_bwd(const float* gw, float* d3, float* d5, float* d7
     return EGM_OK;
 }
 
+static int sa_tile_grid(int N, int H, int W) {            // workgroups of the tiled forward / data-gradient kernels: one per 16 x 64 tile, capped
+    const long long t = (long long)N * ((H + SAF_TY - 1) / SAF_TY) * ((W + SAF_TX - 1) / SAF_TX);
+    return (int)(t > 4096 ? 4096 : (t < 1 ? 1 : t));
+}
 static int sa_blocks(long long npix) { long long b = (npix + 255) / 256; if (b > 512) b = 512; return (int)(b < 1 ? 1 : b); }   // partial rows (upper bound of the launch)
 extern "C" int egm_sa_conv7_fwd(int dtype, const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, egm_stream_t s) {
     EGM_REQ_VEC("sa_conv7_fwd", x, ldx, 8); EGM_REQ_VEC("sa_conv7_fwd", y, ldy, 8);
     EGM_REQUIRE(w && N > 0 && H > 0 && W > 0, "sa_conv7_fwd: bad args");
-    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sa_conv7_fwd_kernel<T>), dim3(stream_grid((long long)N * H * W)), dim3(256), 0, (hipStream_t)s,
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sa_conv7_fwd_kernel<T>), dim3(sa_tile_grid(N, H, W)), dim3(256), 0, (hipStream_t)s,
                                                  (const T*)x, ldx, w, (T*)y, ldy, N, H, W));
     EGM_CHECK_LAUNCH("sa_conv7_fwd");
     return EGM_OK;
@@ -1033,7 +1068,7 @@ extern "C" int egm_sa_conv7_bwd(int dtype, const void* x, int ldx, const void* d
     const long long npix = (long long)N * H * W;
     const int nb = sa_blocks(npix);
     EGM_DISPATCH_DTYPE(dtype, {
-        hipLaunchKernelGGL((sa_conv7_bwd_data_kernel<T>), dim3(stream_grid(npix)), dim3(256), 0, (hipStream_t)s, (const T*)dy, lddy, w, (T*)dx, lddx,
+        hipLaunchKernelGGL((sa_conv7_bwd_data_kernel<T>), dim3(sa_tile_grid(N, H, W)), dim3(256), 0, (hipStream_t)s, (const T*)dy, lddy, w, (T*)dx, lddx,
                            N, H, W);
         hipLaunchKernelGGL((sa_conv7_bwd_w_kernel<T>), dim3(nb), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, (const T*)dy, lddy,
                            (float*)workspace, N, H, W);
