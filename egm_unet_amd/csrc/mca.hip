@@ -130,8 +130,12 @@ __device__ __forceinline__ float axis_count(int ax, int H, int W, int C) {
     return ax == 0 ? (float)C * (float)W : (ax == 1 ? (float)C * (float)H : (float)H * (float)W);
 }
 // sums [N][L][2] -> stats [N][L][2] (mean, std), o [N][L], gates [N][L]
+// LDS_O: the gate inputs o[] of all entries also sit in LDS (dynamic, total floats) for the conv1d pass: in a one-workgroup kernel
+// every read of the global copy is an exposed L2 round trip.
+template <bool LDS_O>
 __global__ void mca_gates_fwd_kernel(const float* __restrict__ sums, GateParams gp, float* __restrict__ stats, float* __restrict__ o,
                                      float* __restrict__ gates, int N, int H, int W, int C) {
+    extern __shared__ float gate_lds[];
     const int L = H + W + C, total = N * L;
     // gate parameters once into LDS: read through gp's pointers inside the loops they were two dependent global round trips (and two
     // expf) per element of a one-workgroup kernel that is pure latency
@@ -148,27 +152,44 @@ __global__ void mca_gates_fwd_kernel(const float* __restrict__ sums, GateParams 
         if (var < 0.0) var = 0.0;
         const float sd = (float)sqrt(var);
         stats[e * 2] = (float)mean; stats[e * 2 + 1] = sd;
-        o[e] = sab[ax][0] * (float)mean + sab[ax][1] * sd;
+        const float ov = sab[ax][0] * (float)mean + sab[ax][1] * sd;
+        o[e] = ov;
+        if (LDS_O) gate_lds[e] = ov;
     }
     __syncthreads();
+    const float* os = LDS_O ? gate_lds : o;
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         int ax, idx, len; axis_of(e, H, W, C, ax, idx, len);
         const int ks = gp.ks[ax], pad = (ks - 1) / 2;
         float z = 0.f;
-        for (int t = 0; t < ks; ++t) { const int j = idx + t - pad; if (j >= 0 && j < len) z += sk[ax][t] * o[e - idx + j]; }
+        for (int t = 0; t < ks; ++t) { const int j = idx + t - pad; if (j >= 0 && j < len) z += sk[ax][t] * os[e - idx + j]; }
         gates[e] = ks > 0 ? sigm(z) : 0.f;                         // absent axis (no_spatial): contributes nothing to x * (sum of gates)
     }
 }
 // dG [N][L][2] (slot 0 = sum over the slice of dx_out*x) -> coef [N][L][2] (A, B), dwts [3][2], dks [3][8]; dz scratch [N][L]
+// LDS_IN: dz, o and the (mean, std) pairs of all entries are staged in LDS (dynamic, 4 * total floats) -- the loop below reads up to
+// 7 + 7 + 2 of them per entry, and from global memory each is an exposed round trip in this one-workgroup kernel (25 us per launch).
+template <bool LDS_IN>
 __global__ void mca_gates_bwd_kernel(const float* __restrict__ dG, const float* __restrict__ stats, const float* __restrict__ o,
                                      const float* __restrict__ gates, GateParams gp, float* __restrict__ dz, float* __restrict__ coef,
                                      float* __restrict__ dwts, float* __restrict__ dks, int N, int H, int W, int C) {
+    extern __shared__ float gate_lds[];
     const int L = H + W + C, total = N * L;
+    if (LDS_IN) {
+        float* sdz = gate_lds; float* so = gate_lds + total; float* sst = gate_lds + 2 * total;
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+            sdz[e] = dG[e * 2] * gp.inv * gates[e] * (1.f - gates[e]);
+            so[e] = o[e];
+            sst[2 * e] = stats[2 * e]; sst[2 * e + 1] = stats[2 * e + 1];
+        }
+        dz = sdz; o = so; stats = sst;                              // (the generic address space: the loops below are the same code)
+    }
     __shared__ float sk[3][8], sab[3][2];                           // gate parameters once into LDS (see mca_gates_fwd_kernel)
     if (threadIdx.x < 24) { const int a = threadIdx.x >> 3, t = threadIdx.x & 7; sk[a][t] = t < gp.ks[a] ? gp.k[a][t] : 0.f; }
     else if (threadIdx.x >= 32 && threadIdx.x < 38) { const int a = (threadIdx.x - 32) >> 1, j = (threadIdx.x - 32) & 1; sab[a][j] = gp.ks[a] > 0 ? 0.5f + sigm(gp.w[a][j]) : 0.f; }
     if (threadIdx.x >= 64 && threadIdx.x < 64 + 24) dks[threadIdx.x - 64] = 0.f;       // taps beyond a gate's kernel size: zero gradient (no host-side fill)
-    for (int e = threadIdx.x; e < total; e += blockDim.x) dz[e] = dG[e * 2] * gp.inv * gates[e] * (1.f - gates[e]);   // absent axis: gates = 0 -> dz = 0
+    if (!LDS_IN)
+        for (int e = threadIdx.x; e < total; e += blockDim.x) dz[e] = dG[e * 2] * gp.inv * gates[e] * (1.f - gates[e]);   // absent axis: gates = 0 -> dz = 0
     __syncthreads();
     // per-thread partials of everything that is summed over the entries: d(alpha), d(beta) per axis and the <= 7 kernel taps
     // per axis (dk[a][t] = sum_e dz[e] * o[e + t - pad]); one LDS reduction at the end instead of one per scalar
@@ -641,7 +662,9 @@ extern "C" int egm_mca_gates_fwd(const float* sums, const float* w_h, const floa
     EGM_REQUIRE(gate_params(gp, w_h, k_h, ks_h, w_w, k_w, ks_w, w_c, k_c, ks_c), "mca_gates_fwd: bad gate parameters");
     EGM_REQUIRE(sums && stats && o && gates, "mca_gates_fwd: null pointer");
     EGM_REQ_SHAPE("mca_gates_fwd");
-    hipLaunchKernelGGL(mca_gates_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, sums, gp, stats, o, gates, N, H, W, C);
+    const size_t lds = (size_t)N * (H + W + C) * sizeof(float);
+    if (lds <= 48 * 1024) hipLaunchKernelGGL(mca_gates_fwd_kernel<true>, dim3(1), dim3(1024), lds, (hipStream_t)s, sums, gp, stats, o, gates, N, H, W, C);
+    else hipLaunchKernelGGL(mca_gates_fwd_kernel<false>, dim3(1), dim3(1024), 0, (hipStream_t)s, sums, gp, stats, o, gates, N, H, W, C);
     EGM_CHECK_LAUNCH("mca_gates_fwd");
     return EGM_OK;
 }
@@ -652,8 +675,20 @@ extern "C" int egm_mca_gates_bwd(const float* dG, const float* stats, const floa
     EGM_REQUIRE(gate_params(gp, w_h, k_h, ks_h, w_w, k_w, ks_w, w_c, k_c, ks_c), "mca_gates_bwd: bad gate parameters");
     EGM_REQUIRE(dG && stats && o && gates && dz_scratch && coef && dwts && dks, "mca_gates_bwd: null pointer");
     EGM_REQ_SHAPE("mca_gates_bwd");
-    hipLaunchKernelGGL(mca_gates_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, dG, stats, o, gates, gp, dz_scratch, coef, dwts, dks, N, H,
-                       W, C);
+    const size_t lds = (size_t)4 * N * (H + W + C) * sizeof(float);
+    if (lds <= 140 * 1024) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mca_gates_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+            if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "mca_gates_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(mca_gates_bwd_kernel<true>, dim3(1), dim3(1024), lds, (hipStream_t)s, dG, stats, o, gates, gp, dz_scratch, coef, dwts, dks, N,
+                           H, W, C);
+    } else {
+        hipLaunchKernelGGL(mca_gates_bwd_kernel<false>, dim3(1), dim3(1024), 0, (hipStream_t)s, dG, stats, o, gates, gp, dz_scratch, coef, dwts, dks, N,
+                           H, W, C);
+    }
     EGM_CHECK_LAUNCH("mca_gates_bwd");
     return EGM_OK;
 }
