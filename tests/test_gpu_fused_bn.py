@@ -250,7 +250,10 @@ def test_model_fused_equals_materialised(dtype, which):
     # the round-3 fusions (pool in the BatchNorm passes, dz on the fly, BatchNorm inside the MCA statistics pass) only exist on the
     # materialised path and accumulate the BatchNorm partial sums in another pixel order: switched off for the bit-for-bit comparison
     # of the operand-prologue path (they have their own on/off tests in test_gpu_pool_fused.py)
-    r3 = [(ops.fuse_pool, ops.fuse_pool()), (ops.fuse_dz, ops.fuse_dz()), (ops.fuse_mca_bn, ops.fuse_mca_bn())]
+    from egm_unet_amd._lib import lib as _lib
+    c7 = _lib().cdll.egm_conv_c7_mode                 # the 16-channel kernels take only prologue-free convs: their statistics sum in another order
+    r3 = [(ops.fuse_pool, ops.fuse_pool()), (ops.fuse_dz, ops.fuse_dz()), (ops.fuse_mca_bn, ops.fuse_mca_bn()), (ops.fuse_cls, ops.fuse_cls()),
+          (lambda v: c7(int(v)), c7(-1))]
     for fuse in (True, False):
         toggle(fuse)
         if which == "prologue":
