@@ -61,15 +61,15 @@ def test_conv7x7_c16_matches_generic_kernel_and_torch(shape, with_bias):
     del wref
 
 
-@pytest.mark.parametrize("shape", [(8, 128, 128, 32, 64, 32), (2, 256, 256, 32, 64, 32), (4, 64, 64, 128, 256, 128), (2, 100, 132, 64, 128, 64)])
+@pytest.mark.parametrize("shape", [(8, 128, 128, 32, 64, 32), (2, 256, 256, 32, 64, 32), (8, 128, 128, 128, 256, 128), (8, 100, 132, 64, 128, 64), (6, 129, 131, 32, 64, 32)])
 def test_conv_fwd_split_equals_one_output(shape):
     """egm_conv_fwd_split (the data gradient behind a channel concatenation written as two dense tensors) == the channel slices of
     egm_conv_fwd's single output, bit for bit."""
     from egm_unet_amd._lib import dtype_code, lib, ptr, stream
     N, H, W, Cin, Cout, cs = shape
     L, dt = lib(), dtype_code(torch.bfloat16)
-    if not L.cdll.egm_conv_split_ok(dt, N, H, W, Cin, Cout, 3, 3, 1, cs):
-        pytest.skip("shape does not take the tile kernel")
+    assert L.cdll.egm_conv_split_ok(dt, N, H, W, Cin, Cout, 3, 3, 1, cs), "shape chosen to take the 8-wave tile kernel"
+    assert not L.cdll.egm_conv_split_ok(dt, 4, 64, 64, 128, 256, 3, 3, 1, 128)        # too few tiles for that kernel: callers fall back to one output
     g = torch.Generator().manual_seed(31)
     x = torch.randn(N, H, W, Cin, generator=g).to(DEV).to(torch.bfloat16)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(DEV)
