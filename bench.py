@@ -55,7 +55,7 @@ class KernelTimer:
     stream, which is the stream handed to the library)."""
 
     def __init__(self, lib):
-        self.lib, self.records, self._orig = lib, [], lib.call
+        self.lib, self.records, self._orig, self.grouped = lib, [], lib.call, []
 
     REPS = 4          # conv launches are re-issued back to back so the event pair brackets kernel time, not launch gaps
 
@@ -82,7 +82,9 @@ class KernelTimer:
                 self._orig(name, *args)
             e1.record()
             cname, cargs = self._canon(name, args)
+            from egm_unet_amd import ops as _o
             self.records.append((cname, cargs, _Span(e0, e1, reps), None))
+            self.grouped.append(_o.conv_group.depth > 0)
         self.lib.call = timed
         return self
 
@@ -148,9 +150,27 @@ class KernelTimer:
         getattr(self.lib.cdll, entry)(dtype, 0, N, H, W, Cin, Cout, KH, KW, dil, ctypes.cast(buf, ctypes.c_void_p), 96)
         return buf.value.decode()
 
+    FAMILIES = (("conv fwd/dgrad", ("egm_conv_fwd", "egm_conv_fwd_split", "egm_group_end")),
+                ("weight gradients", ("egm_conv_wgrad", "egm_wgrad_reduce", "egm_sa_conv7_bwd_w", "egm_dwconv3_bwd_w")),
+                ("pointwise conv+BatchNorm (moment form)", ("egm_pw_",)),
+                ("BatchNorm", ("egm_bn_", "egm_channel_sums", "egm_reduce_tiles")),
+                ("MCALayer", ("egm_mca_",)))
+
+    def families(self):
+        """ms and C-ABI calls per kernel family of the instrumented step (HIP-event pair per call; conv calls as trains of REPS)."""
+        fam = {}
+        for name, _args, e0, e1 in self.records:
+            key = next((f for f, pre in self.FAMILIES if name.startswith(pre)), "other")
+            a = fam.setdefault(key, [0, 0.0])
+            a[0] += 1; a[1] += e0.elapsed_time(e1)
+        return {k: {"calls": v[0], "ms": round(v[1], 3)} for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])}
+
     def summary(self):
+        """-> {kernel: [launches, ms, flop, bytes, roofline ms, ungrouped launches, ungrouped bytes]}.  'Ungrouped' = issued outside an
+        ops.conv_group block: only those run under THIS kernel name in the replayed graph (grouped members run as one *_multi launch),
+        so they are the launches a rocprofv3 trace / PMC pass of the graph replays attributes to it."""
         agg = {}
-        for name, args, e0, e1 in self.records:
+        for (name, args, e0, e1), grouped in zip(self.records, self.grouped):
             key = name
             flops = 0.0
             if name == "egm_conv_fwd":
@@ -163,13 +183,15 @@ class KernelTimer:
                 KH, KW, dil = args[14:17]
                 flops = 2.0 * N * H * W * Cin * Cout * KH * KW
                 key = self._kernel_name("egm_conv_wgrad_kernel_name", args[0], N, H, W, Cin, Cout, KH, KW, dil)
-            a = agg.setdefault(key, [0, 0.0, 0.0, 0.0, 0.0])
+            a = agg.setdefault(key, [0, 0.0, 0.0, 0.0, 0.0, 0, 0.0])
             a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += flops
             if flops:
                 byts = 2.0 * (N * H * W * (Cin + Cout) + KH * KW * Cin * Cout)        # bf16 in + out + weights, once each
                 a[3] += byts
                 # per-launch roofline time: the layer is bound by whichever of MFMA peak and HBM peak takes longer
                 a[4] += 1e3 * max(flops / (MFMA_BF16_PEAK_TFLOPS * 1e12), byts / (HBM_PEAK_GBS * 1e9))
+                if not grouped:
+                    a[5] += 1; a[6] += byts
         return agg
 
 
@@ -207,6 +229,15 @@ def cpu_baseline(seconds_budget=25.0):
         pass
     return {"value": round(2.0 / best, 4), "unit": "images/s", "cores": threads, "cpu_model": cpu_model, "kind": "port",
             "sample": f"{len(times)} train steps (fwd+loss+bwd+SGD) of EGM-UNet(3,2,32) at bs 2x3x512x512 fp32 on the CPU oracle; best of steps after the first"}
+
+
+def _rccl_version():
+    """RCCL's version as torch reports it (torch.cuda.nccl IS RCCL on ROCm); NCCL_DEBUG=VERSION makes RCCL print the same at init."""
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(i) for i in v) if isinstance(v, tuple) else str(v)
+    except Exception as e:                                      # noqa: BLE001 -- a report field must not cost the measurement
+        return f"unavailable ({type(e).__name__})"
 
 
 def _seeded_clipseg(dev, dtype, seed=0):
@@ -415,6 +446,7 @@ def main():
     ap.add_argument("--workload", default="egm_unet_train", choices=["egm_unet_train", "clipseg_infer", "clipseg_train", "ablation_1024"],
                     help="egm_unet_train = the headline metric (BASELINE.json configs[1]); clipseg_infer = configs[3] (ViT-B/16 image+text "
                          "encode + decoder on 352x352), reported as a secondary line")
+    ap.add_argument("--instrument", action="store_true", help="N > 1: also run the instrumented eager step (roofline / families objects) on every rank")
     ap.add_argument("--eager", action="store_true", help="issue every kernel from Python instead of replaying the captured hipGraph")
     ap.add_argument("--dp-single-graph", action="store_true",
                     help="N > 1: one captured graph (forward + backward) followed by the exchange and the SGD launch, instead of the three-graph "
@@ -428,14 +460,13 @@ def main():
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves as a CHILD process (one rank per GPU over
         # torch.distributed.run), before this process has touched the GPU, pass their output through (rank 0 prints the JSON
         # line on the inherited stdout) and exit with the launcher's return code.  Never exec: the parent stays a plain waiter.
-        import socket
         import subprocess
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env.setdefault("NCCL_DEBUG", "VERSION")                # RCCL prints its version once at init (stderr)
+        # --standalone: the launcher binds its rendezvous store to a free port itself (picking one here and closing the socket first
+        # can collide on a busy host); --local-addr because the container hostname may not resolve
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node",
+               str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.run(cmd, env=env, cwd=ROOT).returncode)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launched by torch.distributed.run with another --nproc-per-node?)")
@@ -523,63 +554,92 @@ def main():
         elapsed = float(tt.item())
     final_loss = float(loss.detach())
 
-    roofline = roofline_wgrad = None
+    roofline = roofline_wgrad = families = None
     cpu = None
-    # instrumented eager step outside the timed region.  EVERY rank runs it (its gradient exchange must match on all ranks);
-    # rank 0 reports.  After a captured graph the reducer's autograd hooks are off: switch them back on for this eager step.
-    if reducer is not None:
-        reducer.hooks_enabled = True
-    from egm_unet_amd import ops as _ops
-    grouped = _ops.group_convs()
-    _ops.group_convs(False)                 # every conv launched (and timed) on its own: inside a launch group the calls only record
-    try:
-        with KernelTimer(lib()) as kt:
-            eager_step()
-    finally:
-        _ops.group_convs(grouped)
-    if rank == 0:
+    # Instrumented eager step outside the timed region: every C-ABI call bracketed by HIP events on the launch stream.  At N > 1 it is
+    # off unless --instrument (EVERY rank would have to run it, its hook-driven gradient exchange included, after the measurement);
+    # EGM_BENCH_NO_INSTRUMENT=1 switches it off at N = 1 too -- the rocprofv3 --pmc passes use that, so that their per-kernel
+    # averages cover the graph replays only (tools/pmc_traffic.py).
+    instrument = (world == 1 or args.instrument) and not os.environ.get("EGM_BENCH_NO_INSTRUMENT")
+    kt = None
+    if instrument:
+        # after a captured graph the reducer's autograd hooks are off: switch them back on for this eager step
+        if reducer is not None:
+            reducer.hooks_enabled = True
+        from egm_unet_amd import ops as _ops
+        grouped = _ops.group_convs()
+        _ops.group_convs(False)                 # every conv launched (and timed) on its own: inside a launch group the calls only record
+        try:
+            with KernelTimer(lib()) as kt:
+                eager_step()
+        finally:
+            _ops.group_convs(grouped)
+    if rank == 0 and kt is not None:
         agg = kt.summary()
         total_ms = sum(v[1] for v in agg.values())
         dom_key, dom = max(((k, v) for k, v in agg.items() if v[2] > 0), key=lambda kv: kv[1][1])
-        achieved = dom[2] / (dom[1] * 1e-3) / 1e12
-        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command; FETCH_SIZE
-        # doubled per the gfx950 note of the guide): a CHECKED-IN measurement keyed by kernel instantiation (tools/pmc_traffic.py), so the
-        # figure beside a kernel is that kernel's own traffic, like-for-like with its algorithmic bytes
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (9, 8, 7, 6, 5, 4, 3)) if os.path.exists(q)), "")
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command with
+        # EGM_BENCH_NO_INSTRUMENT=1, i.e. graph replays only; FETCH_SIZE doubled per the gfx950 note of the guide): a CHECKED-IN
+        # measurement keyed by kernel instantiation (tools/pmc_traffic.py)
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (9, 8, 7, 6, 5, 4)) if os.path.exists(q)), "")
         tjson = json.load(open(tpath)) if (tpath and args.dtype == "bf16") else {}
-        peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
+        mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
 
         def roofline_of(key, row):
-            n_, ms_, flop_, byts_, roof_ms_ = row
-            ach = flop_ / (ms_ * 1e-3) / 1e12
+            n_, ms_, flop_, byts_, roof_ms_, n_ung, byts_ung = row
+            # the bound is the kernel's own: over ITS launches, which of MFMA time at peak and HBM time at peak is longer
+            t_mfma, t_hbm = flop_ / (mfma_peak * 1e12), byts_ / (HBM_PEAK_GBS * 1e9)
+            hbm = t_hbm > t_mfma
+            if hbm:
+                ach, peak, unit = byts_ / (ms_ * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+            else:
+                ach, peak, unit = flop_ / (ms_ * 1e-3) / 1e12, mfma_peak, "TFLOP/s"
             tr = tjson.get(key, {}).get("hbm_bytes_per_launch_corrected")
-            return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            alg_ung = (byts_ung / n_ung) if n_ung else None
+            return {"bound": "hbm" if hbm else "mfma", "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
                     "traffic": tr,
-                    "traffic_over_algorithmic": round(tr / (byts_ / n_), 3) if tr else None,
-                    "traffic_source": (os.path.relpath(tpath, ROOT) + ": rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this command, per kernel "
-                                       "instantiation, recorded earlier and checked in (FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); not "
-                                       "collected by this run") if tr else None,
-                    "kernel": key, "algorithmic_bytes_per_launch": round(byts_ / n_), "launches_per_step": n_,
-                    "avg_launch_ms": round(ms_ / n_, 4), "algorithmic_gflop_per_launch": round(flop_ / n_ / 1e9, 3),
+                    # like for like: the PMC passes see this kernel name only for the launches that are not merged into a launch group
+                    "traffic_over_algorithmic": round(tr / alg_ung, 3) if (tr and alg_ung) else None,
+                    "traffic_source": (os.path.relpath(tpath, ROOT) + ": rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over graph replays only "
+                                       "(EGM_BENCH_NO_INSTRUMENT=1), per kernel instantiation, recorded earlier and checked in (FETCH doubled per the "
+                                       "gfx950 note of MI355X_MICROARCH.md); not collected by this run") if tr else None,
+                    "kernel": key, "algorithmic_bytes_per_launch": round(byts_ / n_),
+                    "algorithmic_bytes_per_launch_in_graph": round(alg_ung) if alg_ung else None, "launches_per_step_in_graph": n_ung,
+                    "launches_per_step": n_, "avg_launch_ms": round(ms_ / n_, 4), "algorithmic_gflop_per_launch": round(flop_ / n_ / 1e9, 3),
+                    "tflops": round(flop_ / (ms_ * 1e-3) / 1e12, 2), "frac_of_mfma_peak": round(flop_ / (ms_ * 1e-3) / 1e12 / mfma_peak, 4),
                     "share_of_step_kernel_time": round(ms_ / total_ms, 3),
-                    # sum over the launches of min(MFMA, HBM)-roofline time / measured time: the high-resolution layers of this
-                    # U-Net are HBM-bound (AI 144-192 FLOP/B < ridge ~310), so "frac" vs the MFMA peak understates them
+                    # sum over the launches of max(MFMA, HBM)-roofline time / measured time (each launch against its own bound)
                     "frac_of_per_layer_roofline": round(roof_ms_ / ms_, 4) if args.dtype == "bf16" else None}
 
         roofline = roofline_of(dom_key, dom)
+        roofline["note"] = ("dominant = the conv kernel instantiation with the largest share of the step; the step is ~700 launches and no kernel "
+                            "exceeds a few percent, see families")
         # the layers the north_star target is quoted on, each against its own roofline
         roofline["encoder_3x3"] = kt.encoder_table() if args.dtype == "bf16" and args.batch == 8 and args.size == 512 else None
         # second object: the heaviest weight-gradient kernel
         wg = [(k, v) for k, v in agg.items() if v[2] > 0 and "wgrad" in k]
         roofline_wgrad = roofline_of(*max(wg, key=lambda kv: kv[1][1])) if wg else None
+        families = kt.families()
         top = sorted(agg.items(), key=lambda kv: -kv[1][1])[:12]
         print(f"[bench] host enqueue {1e3 * t_enqueue / args.steps:.2f} ms/step vs wall {1e3 * elapsed / args.steps:.2f} ms/step", file=sys.stderr)
         print("[bench] kernel time by C-ABI entry (instrumented step, ms): " +
               ", ".join(f"{k}={v[1]:.2f}({v[0]})" for k, v in top) + f"; total {total_ms:.2f}", file=sys.stderr)
         if os.environ.get("EGM_CONV_TABLE"):
             print("\n".join(kt.conv_table()), file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
+        if world == 1:
             cpu = cpu_baseline()
+        else:
+            # timed at N = 1 only (the other ranks would idle at the barrier for its 25 s): carry the newest checked-in N = 1 figure
+            for r in (9, 8, 7, 6, 5, 4, 3):
+                q = os.path.join(ROOT, "profiles", f"r0{r}_bench_line.json")
+                if os.path.exists(q):
+                    try:
+                        cpu = dict(json.load(open(q))["cpu_baseline"], source=f"n1 ({os.path.relpath(q, ROOT)})")
+                    except (KeyError, TypeError, ValueError):
+                        cpu = None
+                    if cpu:
+                        break
 
     if rank == 0:
         imgs = args.batch * world * args.steps
@@ -592,9 +652,10 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "launch": (f"eager (capture failed: {capture_error})" if capture_error else "eager") if args.eager else
                        ("hipGraph replay" if world == 1 or not getattr(step, "split", False) else
                         "3 hipGraph replays per step (fwd + decoder bwd | encoder bwd | SGD), RCCL all-reduce of bucket 0 / 1 between them on a side stream"),
-                       "allreduces_per_step": coll_per_step, "dist_backend": (os.environ.get("EGM_DIST_BACKEND", "nccl") + (" (RCCL)" if os.environ.get("EGM_DIST_BACKEND", "nccl") == "nccl" else "")) if world > 1 else None,
+                       "allreduces_per_step": coll_per_step, "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                       "rccl_version": _rccl_version() if world > 1 else None, "dist_backend": (os.environ.get("EGM_DIST_BACKEND", "nccl") + (" (RCCL)" if os.environ.get("EGM_DIST_BACKEND", "nccl") == "nccl" else "")) if world > 1 else None,
                        "final_loss": round(final_loss, 4)},
-            "roofline": roofline, "roofline_wgrad": roofline_wgrad, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_wgrad": roofline_wgrad, "families": families, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:

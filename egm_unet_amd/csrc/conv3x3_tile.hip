@@ -35,9 +35,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 __device__ uint4 egm_zero_page[4];          // zero-initialised: the source of every DMA lane that must deliver zeros
 
-#ifndef EGM_TILE_ORDER
-#define EGM_TILE_ORDER 0          // 0 = kernel-column-major fragment order (product), 1 = tap-major software pipeline (measured slower)
-#endif
 #ifndef EGM_TILE_DMA_EVERY
 #define EGM_TILE_DMA_EVERY 1      // one LDS-DMA instruction after every n-th fragment group of the MFMA phase
 #endif
@@ -210,33 +207,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
     // meanwhile).
     auto compute = [&](int bufi, bool with_dma, const Src& q) __attribute__((always_inline)) {
         const unsigned char* sb = smem + bufi * STAGE;
-#if EGM_TILE_ORDER == 1
-        constexpr int PD = (R >= 4) ? 1 : 2;
-        bf16x8_t fa[PD + 1][NT], fb[PD + 1][R];
-        auto load_group = [&](int g, int slot) __attribute__((always_inline)) {
-            const int s_ = g / 3, r_ = g % 3;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                fa[slot][nt] = *reinterpret_cast<const bf16x8_t*>(sb + wbo + ((r_ * 3 + s_) * NC + nt * 32) * 32);
-#pragma unroll
-            for (int m = 0; m < R; ++m)
-                fb[slot][m] = *reinterpret_cast<const bf16x8_t*>(sb + pb[s_] + (m + r_) * (PW * 32));
-        };
-#pragma unroll
-        for (int g = 0; g < PD; ++g) load_group(g, g % (PD + 1));
-#pragma unroll
-        for (int g = 0; g < 9; ++g) {
-            if (g + PD < 9) load_group(g + PD, (g + PD) % (PD + 1));
-            if (g < KT) {
-                if (with_dma) dma(q, g);
-            }
-#pragma unroll
-            for (int m = 0; m < R; ++m)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g % (PD + 1)][nt], fb[g % (PD + 1)][m], acc[m][nt], 0, 0, 0);
-        }
-#else
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             bf16x8_t fa[3][NT];                                       // one kernel column of weights, held across the patch rows
@@ -262,7 +232,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
                 }
             }
         }
-#endif
     };
     static_assert(9 >= KT && (3 * (R + 2) + EGM_TILE_DMA_EVERY - 1) / EGM_TILE_DMA_EVERY >= KT, "not enough fragment groups to carry the stage's DMA instructions");
 
@@ -276,6 +245,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
+                    if (p.bias != nullptr) {                          // rare (convs in front of a BatchNorm carry no bias); added in fp32, ONE rounding
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int co = co0 + wc * NT * 32 + nt * 32 + gq * 8 + h * 4 + j;
+                            acc[m][nt][gq * 4 + j] += co < p.bias_n ? p.bias[co] : 0.f;
+                        }
+                    }
                     uint2 v;
                     v.x = pack_bf16x2(acc[m][nt][gq * 4 + 0], acc[m][nt][gq * 4 + 1]);
                     v.y = pack_bf16x2(acc[m][nt][gq * 4 + 2], acc[m][nt][gq * 4 + 3]);
@@ -298,17 +274,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
                     const int pl = it2 * (64 / NV) + slot;
                     const bool ok = t.ox0 + pl < p.W;
                     uint4 rw = raw[it2];
-                    if (p.bias != nullptr) {                          // rare (convs in front of a BatchNorm carry no bias): rounds twice
-                        float b[8], bias8[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) { const int co = co0 + wc * NT * 32 + cv * 8 + j; bias8[j] = co < p.bias_n ? p.bias[co] : 0.f; }
-                        b[0] = __uint_as_float(rw.x << 16); b[1] = __uint_as_float(rw.x & 0xffff0000u);
-                        b[2] = __uint_as_float(rw.y << 16); b[3] = __uint_as_float(rw.y & 0xffff0000u);
-                        b[4] = __uint_as_float(rw.z << 16); b[5] = __uint_as_float(rw.z & 0xffff0000u);
-                        b[6] = __uint_as_float(rw.w << 16); b[7] = __uint_as_float(rw.w & 0xffff0000u);
-                        rw.x = pack_bf16x2(b[0] + bias8[0], b[1] + bias8[1]); rw.y = pack_bf16x2(b[2] + bias8[2], b[3] + bias8[3]);
-                        rw.z = pack_bf16x2(b[4] + bias8[4], b[5] + bias8[5]); rw.w = pack_bf16x2(b[6] + bias8[6], b[7] + bias8[7]);
-                    }
                     if (!ok) rw = make_uint4(0, 0, 0, 0);             // pixels right of the image: no store, nothing in the statistics
                     if (ok) *reinterpret_cast<uint4*>(yrow + (long long)pl * ldo) = rw;
                     float v[8];

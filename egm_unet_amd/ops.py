@@ -45,18 +45,25 @@ _zero_pools = {}
 
 def _zero_grad_vec(n, device):
     """An all-zero fp32 gradient of n elements for a parameter whose gradient is identically zero (a conv bias in front of a train-mode
-    BatchNorm): a slice of one zero buffer per device, allocated once OUTSIDE any capture, instead of a fill kernel per parameter and
-    step (14 launches per EGM-UNet step).  The slices are read (SGD, bucket gather), scaled or re-zeroed by their users, never
-    accumulated into: such a bias has this one gradient contribution."""
+    BatchNorm): a slice of a zero buffer per device, allocated OUTSIDE any capture, instead of a fill kernel per parameter and step
+    (14 launches per EGM-UNet step).  Every caller gets storage of its own: when a buffer is used up the next one is allocated (the
+    slices handed out keep the old one alive), never a slice that somebody else already holds -- a user-side in-place write to such a
+    gradient (p.grad.add_(), foreach optimizers with weight decay + maximize, gradient noise) then touches that one bias only.
+    A captured graph never refills its slices, so writes to them persist across replays: use them read-only under graph replay."""
     pool = _zero_pools.get(device)
     if pool is None or pool[0].numel() < pool[1] + n:
         if torch.cuda.is_current_stream_capturing():
-            return torch.zeros(n, dtype=torch.float32, device=device)      # first need arises inside a capture: plain fill this time
+            return torch.zeros(n, dtype=torch.float32, device=device)      # the need arises inside a capture: plain fill this time
         pool = _zero_pools[device] = [torch.zeros(max(1 << 16, 4 * n), dtype=torch.float32, device=device), 0]
-    # every caller gets its own slice while the pool lasts (wraps around: all slices hold zeros anyway)
     off = pool[1]
-    pool[1] = off + n if off + 2 * n <= pool[0].numel() else 0
+    pool[1] = off + n
     return pool[0][off:off + n]
+
+
+def _bn_conv_bias_grad(Cout, dy, training, device):
+    """Gradient of a conv bias in front of a BatchNorm: identically zero when the BatchNorm normalises with batch statistics (the mean
+    subtraction removes the bias), sum(dy) over the pixels when it is frozen (eval mode with grad enabled)."""
+    return _zero_grad_vec(Cout, device) if training else _channel_sum(dy)[0, :Cout]
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -279,6 +286,7 @@ def prepack_model(model, dtype):
 # contribution in this backward (autograd would otherwise sum unfilled buffers): _conv_uses counts the conv forwards a weight has
 # taken part in since its gradients were last produced, and a weight used more than once takes the immediate path.
 _pending_wgrad = []
+_wgrad_run = [None]                       # graph-task id of the backward run whose end-of-run flush is queued
 _conv_uses = {}                           # id(weight) -> [weakref, weight generation, forwards awaiting their backward, peak of that]
 
 
@@ -311,6 +319,8 @@ def _flush_wgrads(ready_only=False):
     """Finish the deferred weight gradients with ONE multi-conv reduction.  Runs as an autograd-engine callback when backward ends;
     ready_only=True (a gradient bucket is about to be gathered mid-backward, parallel.GradAllReducer) finishes the convs whose
     gradient tensor autograd has already adopted and leaves the others pending."""
+    if not ready_only:
+        _wgrad_run[0] = None
     if not _pending_wgrad:
         return
     todo, later = [], []
@@ -447,13 +457,17 @@ class conv_group:
     of one kernel instantiation as ONE launch (csrc/group.h).  Only for convolutions that are independent of each other and whose
     outputs are first used after the block.  EGM_GROUP_CONVS=0 turns it into a no-op."""
 
+    depth = 0                                 # open conv_group blocks, whether or not merging is switched on (bench.py's bookkeeping)
+
     def __enter__(self):
         self.on = _GROUP_CONVS
+        conv_group.depth += 1
         if self.on:
             lib().call("egm_group_begin")
         return self
 
     def __exit__(self, et, ev, tb):
+        conv_group.depth -= 1
         if self.on:
             if et is None:
                 lib().call("egm_group_end", stream())
@@ -509,8 +523,11 @@ def _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, dy_pre, dy_out, weight, dil, gro
            KH, KW, dil, groups, 0, st)
     if defer:
         nslab = L.query("egm_conv_wgrad_slabs_pre", dt, 1 if (xm != PRE_NONE or dm != PRE_NONE) else 0, N, H, W, CinP, CoutP, KH, KW, dil)
-        if not _pending_wgrad:
+        run = torch._C._current_graph_task_id()
+        if run != _wgrad_run[0]:              # per engine run (an aborted backward never ran its callback: its entries are dead)
+            _pending_wgrad.clear()
             Variable._execution_engine.queue_callback(_flush_wgrads)
+            _wgrad_run[0] = run
         _pending_wgrad.append((ws, weight, nslab, KH * KW, CoutP, CinP, Cout, Cin, groups, weakref.ref(gw), gw.data_ptr()))
     return gw
 
@@ -533,6 +550,7 @@ def fuse_dz(enabled=None):
 
 
 def _check_deferred_dz():
+    _dz_run[0] = None
     if _DEFERRED_DZ:
         kinds = [v[1][0] for v in _DEFERRED_DZ.values()]
         _DEFERRED_DZ.clear()
@@ -540,9 +558,19 @@ def _check_deferred_dz():
                            "its BatchNorm had another consumer); call ops.fuse_dz(False)")
 
 
+_dz_run = [None]                          # autograd graph-task id of the backward run whose end-of-run check is queued
+
+
 def _defer_dz(standin, payload):
-    if not _DEFERRED_DZ:
+    # The check is per ENGINE RUN, not per "registry was empty": the engine drops its callbacks when a backward raises (OOM, launch
+    # error, KeyboardInterrupt), so entries of an aborted run would otherwise stay for the life of the process, pin their payload
+    # tensors, and keep the check from ever being queued again.  A new graph-task id means a new run: stale entries are dropped
+    # (their stand-ins belong to a backward that no longer exists) and this run gets its own check.
+    run = torch._C._current_graph_task_id()
+    if run != _dz_run[0]:
+        _DEFERRED_DZ.clear()
         Variable._execution_engine.queue_callback(_check_deferred_dz)
+        _dz_run[0] = run
     _DEFERRED_DZ[standin.data_ptr()] = (standin, payload)          # the stand-in stays alive: its address cannot be recycled meanwhile
 
 
@@ -768,7 +796,7 @@ class _ConvBN(Function):
             if need_gx:
                 gx = _conv_dgrad(dy, wd, N, H, W, CoutP, CinP, KH, KW, dil, ctx.x_split)
             if has_bias and ctx.needs_input_grad[4]:
-                gb = _zero_grad_vec(Cout, dev)
+                gb = _bn_conv_bias_grad(Cout, dy, training, dev)
             ggamma = sums[1, :Cout] if ctx.needs_input_grad[5] else None
             gbeta = sums[0, :Cout] if ctx.needs_input_grad[6] else None
             return gx, None, None, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None, None
@@ -791,7 +819,7 @@ class _ConvBN(Function):
         if need_gx:
             gx = _conv_dgrad(dy, wd, N, H, W, CoutP, CinP, KH, KW, dil, ctx.x_split)
         if has_bias and ctx.needs_input_grad[4]:
-            gb = _zero_grad_vec(Cout, dev)              # a conv bias feeding a BatchNorm has an identically zero gradient
+            gb = _bn_conv_bias_grad(Cout, dy, training, dev)
         ggamma = sums[1, :Cout] if ctx.needs_input_grad[5] else None
         gbeta = sums[0, :Cout] if ctx.needs_input_grad[6] else None
         return gx, None, None, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None, None
@@ -898,7 +926,7 @@ class _ConvBNPool(Function):
             gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=dev)
             L.call("egm_conv_fwd", dt, ptr(dy), CoutP, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
         if has_bias and ctx.needs_input_grad[2]:
-            gb = _zero_grad_vec(Cout, dev)              # a conv bias feeding a BatchNorm has an identically zero gradient
+            gb = _bn_conv_bias_grad(Cout, dy, training, dev)
         ggamma = sums[1, :Cout] if ctx.needs_input_grad[3] else None
         gbeta = sums[0, :Cout] if ctx.needs_input_grad[4] else None
         return gx, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None, None
@@ -1107,7 +1135,7 @@ class _MultiConvBN(Function):
             base = 1 + 5 * k
             gx, gw, gb = gxs[k], gws[k], None
             if has_bias and ctx.needs_input_grad[base + 2]:
-                gb = _zero_grad_vec(Cout, x.device)
+                gb = _bn_conv_bias_grad(Cout, dy, training, x.device)
             ggamma = sums[1, :Cout] if ctx.needs_input_grad[base + 3] else None
             gbeta = sums[0, :Cout] if ctx.needs_input_grad[base + 4] else None
             grads += [gx, gw, gb, ggamma, gbeta]
@@ -1212,7 +1240,7 @@ class _ConvBNEw(Function):
         if ctx.needs_input_grad[2]:
             gw = _conv_wgrad(x, ldx, None, ACT_NONE, dy, CoutP, None, None, weight, 1, 1, Cin, Cout)
         if has_bias and ctx.needs_input_grad[3]:
-            gb = _zero_grad_vec(Cout, dev)              # a conv bias feeding a BatchNorm has an identically zero gradient
+            gb = _bn_conv_bias_grad(Cout, dy, training, dev)
         ggamma = sums[1, :Cout] if ctx.needs_input_grad[4] else None
         gbeta = sums[0, :Cout] if ctx.needs_input_grad[5] else None
         return gx, dp if ctx.needs_input_grad[1] else None, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None, None

@@ -34,6 +34,11 @@ class GradAllReducer:
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         if self.world > 1 and not dist.is_initialized():
             raise RuntimeError("GradAllReducer(world_size=%d) needs an initialised torch.distributed process group" % self.world)
+        if dist.is_initialized() and self.world != dist.get_world_size():
+            # the collective below spans the whole process group: a reducer that believes in another world size would SUM over N ranks
+            # while its caller scales by 1/world_size (and hang if not every rank builds one)
+            raise RuntimeError("GradAllReducer(world_size=%d) inside a process group of %d ranks: pass world_size=None or the group's size"
+                               % (self.world, dist.get_world_size()))
         # The collective is issued whenever a process group exists, ALSO at world size 1: a one-rank all-reduce is a valid RCCL
         # call and exercises the same stream / event / Work interplay with the graph replays as the N-rank step (the only way
         # a one-GPU box can run it).  Without a process group (plain single-process training) there is nothing to call.

@@ -237,6 +237,25 @@ def test_bench_starts_its_own_ranks():
     assert line["config"]["allreduces_per_step"] == 2, line["config"]
 
 
+def test_bench_starts_its_own_ranks_single_graph_variant():
+    """The same with --dp-single-graph (one captured graph, then the exchange and the SGD launch): the N > 1 line is self-sufficient --
+    world size and RCCL version in `config`, no instrumented eager step (roofline / families null without --instrument), and a
+    cpu_baseline carried from the checked-in N = 1 line with its source named."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(EGM_BENCH_SINGLE_DEVICE="1", EGM_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "128",
+                        "--dp-single-graph"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["config"]["global_batch"] == 16 and line["value"] > 0
+    assert line["config"]["launch"] == "hipGraph replay" and line["config"]["allreduces_per_step"] == 2, line["config"]
+    assert line["config"]["rccl_version"], line["config"]
+    assert line["roofline"] is None and line["families"] is None
+    assert line["cpu_baseline"] is None or line["cpu_baseline"]["source"].startswith("n1 ("), line["cpu_baseline"]
+
+
 def test_weight_with_tensor_hook_is_not_deferred():
     """A tensor hook on a conv weight makes autograd replace the gradient buffer backward() returned: the deferred slab reduction
     must not be used for it (the hooked gradient would be computed from an unfilled buffer)."""

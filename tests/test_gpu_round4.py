@@ -1,0 +1,71 @@
+"""Round-4 GPU tests: robustness of the deferred-gradient registry (ops._defer_dz) and of the gradient helpers the advisor flagged."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _model_and_batch(dtype=torch.float32):
+    from egm_unet_amd import GRFBUNet
+    from oracle import egm_ref as R
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 3, 64, 64, generator=g).to(DEV)
+    gl = torch.randn(2, 2, 64, 64, generator=g).to(DEV)
+    m = GRFBUNet(3, 2, base_c=8)
+    m.load_state_dict(R.make_egm_unet_state(3, 2, 8, seed=17), strict=True)
+    return m.to(DEV).train().set_compute_dtype(dtype), x, gl
+
+
+def test_aborted_backward_does_not_poison_the_deferred_dz_registry():
+    """A backward that raises between a deferring producer (the classifier's data gradient, left to up4's BatchNorm backward) and its
+    consumer leaves an entry in ops._DEFERRED_DZ and the engine never runs the end-of-run check.  The next backward must drop the
+    stale entry, queue its own check, and give the gradients of an undisturbed model."""
+    from egm_unet_amd import ops
+    assert ops.fuse_dz()
+    ref, x, gl = _model_and_batch()
+    ref(x)["out"].backward(gl)
+    want = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
+
+    m, _, _ = _model_and_batch()
+
+    def boom(_g):
+        raise RuntimeError("boom")
+    # AccumulateGrad (and its hooks) of the classifier weight runs right after the classifier's backward, before up4's BatchNorm backward
+    h = m.out_conv[0].weight.register_hook(boom)
+    with pytest.raises(RuntimeError, match="boom"):
+        m(x)["out"].backward(gl)
+    h.remove()
+    torch.cuda.synchronize()
+    assert ops._DEFERRED_DZ, "the aborted run was expected to leave its deferred entry behind (otherwise this test checks nothing)"
+    m.zero_grad(set_to_none=True)
+    m(x)["out"].backward(gl)
+    torch.cuda.synchronize()
+    assert not ops._DEFERRED_DZ and ops._dz_run[0] is None
+    got = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert got.keys() == want.keys()
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+
+def test_conv_bias_gradient_in_front_of_a_frozen_batchnorm_is_the_channel_sum():
+    """A conv bias feeding a train-mode BatchNorm has an identically zero gradient; in front of an eval-mode (frozen) BatchNorm the true
+    gradient is sum(dy) (the fused nodes used to return zeros there too)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from egm_unet_amd import ops
+    from egm_unet_amd._lib import ACT_RELU
+    g = torch.Generator().manual_seed(5)
+    conv, bn = nn.Conv2d(8, 16, 3, padding=1, bias=True), nn.BatchNorm2d(16)
+    with torch.no_grad():
+        bn.running_mean.copy_(torch.randn(16, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(16, generator=g) + 0.5)
+    conv.to(DEV); bn.to(DEV).eval()
+    x = torch.randn(2, 12, 12, 8, generator=g).to(DEV)
+    go = torch.randn(2, 12, 12, 16, generator=g).to(DEV)
+    ops.conv_bn_act(x, conv, bn, ACT_RELU).backward(go)
+    gb = conv.bias.grad.clone()
+    conv.zero_grad(); bn.zero_grad()
+    y = F.relu(bn(conv(x.permute(0, 3, 1, 2))))
+    y.backward(go.permute(0, 3, 1, 2))
+    assert float((gb - conv.bias.grad).norm() / conv.bias.grad.norm()) < 1e-4
