@@ -342,6 +342,66 @@ def _blob_dataset(n, size, seed):
     return x, t
 
 
+TRAIN_RUN = (64, 4, 8, 25, 0.02, 48)          # size, batch, batches per epoch, epochs, lr0, steps compared one by one
+
+
+def _train_run_data():
+    from oracle import egm_ref as R
+    size, bs, nb = TRAIN_RUN[:3]
+    xs, ts = _blob_dataset(bs * nb, size, 31)
+    xv, tv = _blob_dataset(64, size, 32)
+    return xs, ts, xv, tv, R.make_egm_unet_state(3, 2, 8, seed=9), torch.tensor([1.0, 2.0])
+
+
+def _oracle_eval(work):
+    from oracle import egm_ref as R, loss_ref as L
+    _, _, xv, tv, _, _ = _train_run_data()
+    with torch.no_grad():
+        pred = R.egm_unet_forward(work, xv, False)["out"].argmax(1)
+    mat = L.confusion_matrix(tv.flatten(), pred.flatten(), 2)
+    return mat, float(L.confusion_metrics(mat)[2].mean()) * 100
+
+
+_oracle_runs_cache = []
+
+
+def _oracle_training_runs():
+    """The CPU oracle trained for 200 steps with the reference's recipe, twice (8 threads and 4 threads: identical arithmetic, another
+    reduction order) -> ((losses, val mIoU), (losses, val mIoU)).  Run once per test session (fp32 and bf16 training tests share it)."""
+    if _oracle_runs_cache:
+        return _oracle_runs_cache[0]
+    from oracle import egm_ref as R, loss_ref as L
+    size, bs, nb, epochs, lr0, _ = TRAIN_RUN
+    xs, ts, _, _, st, lw = _train_run_data()
+
+    def oracle_run(threads):
+        torch.set_num_threads(threads)
+        params = {k: v.clone() for k, v in st.items() if v.is_floating_point() and "running_" not in k}
+        work, bufs, losses = {k: v.clone() for k, v in st.items()}, {}, []
+        for step in range(epochs * nb):
+            b = step % nb
+            for k in params:
+                work[k] = params[k].detach().clone().requires_grad_(True)
+            loss = L.criterion(R.egm_unet_forward(work, xs[b * bs:(b + 1) * bs], True), ts[b * bs:(b + 1) * bs], lw, num_classes=2,
+                               ignore_index=255)
+            loss.backward()
+            with torch.no_grad():
+                L.sgd_step(params, {k: work[k].grad for k in params}, bufs, lr=lr0 * L.lr_factor(step, nb, epochs))
+            losses.append(float(loss.detach()))
+        for k in params:
+            work[k] = params[k].detach()
+        return losses, _oracle_eval(work)[1]
+
+    nthreads = torch.get_num_threads()
+    try:
+        a = oracle_run(min(8, nthreads))
+        b = oracle_run(max(1, min(8, nthreads) // 2))
+    finally:
+        torch.set_num_threads(nthreads)
+    _oracle_runs_cache.append((a, b))
+    return a, b
+
+
 def test_training_run_val_miou_matches_oracle():
     """SURVEY 8d mIoU check (ii): 200 training steps of the HIP build and of the CPU oracle from the same seeded init on the same
     synthetic batches with the reference's recipe (SGD 0.9 / 1e-4, warm-up + poly LR stepped per iteration, 5-term criterion,
@@ -364,43 +424,10 @@ def test_training_run_val_miou_matches_oracle():
     from egm_unet_amd.optim import SGD
     from egm_unet_amd.train_utils import create_lr_scheduler, criterion
     from egm_unet_amd.train_utils.distributed_utils import ConfusionMatrix
-    from oracle import egm_ref as R, loss_ref as L
-    size, bs, nb, epochs, lr0, ncmp = 64, 4, 8, 25, 0.02, 48
-    xs, ts = _blob_dataset(bs * nb, size, 31)
-    xv, tv = _blob_dataset(64, size, 32)
-    st = R.make_egm_unet_state(3, 2, 8, seed=9)
-    lw = torch.tensor([1.0, 2.0])
-
-    def oracle_eval(work):
-        with torch.no_grad():
-            pred = R.egm_unet_forward(work, xv, False)["out"].argmax(1)
-        mat = L.confusion_matrix(tv.flatten(), pred.flatten(), 2)
-        return mat, float(L.confusion_metrics(mat)[2].mean()) * 100
-
-    def oracle_run(threads):
-        torch.set_num_threads(threads)
-        params = {k: v.clone() for k, v in st.items() if v.is_floating_point() and "running_" not in k}
-        work, bufs, losses = {k: v.clone() for k, v in st.items()}, {}, []
-        for step in range(epochs * nb):
-            b = step % nb
-            for k in params:
-                work[k] = params[k].detach().clone().requires_grad_(True)
-            loss = L.criterion(R.egm_unet_forward(work, xs[b * bs:(b + 1) * bs], True), ts[b * bs:(b + 1) * bs], lw, num_classes=2,
-                               ignore_index=255)
-            loss.backward()
-            with torch.no_grad():
-                L.sgd_step(params, {k: work[k].grad for k in params}, bufs, lr=lr0 * L.lr_factor(step, nb, epochs))
-            losses.append(float(loss.detach()))
-        for k in params:
-            work[k] = params[k].detach()
-        return losses, oracle_eval(work)[1]
-
-    nthreads = torch.get_num_threads()
-    try:
-        ref_losses, miou_a = oracle_run(min(8, nthreads))
-        ref_losses_b, miou_b = oracle_run(max(1, min(8, nthreads) // 2))
-    finally:
-        torch.set_num_threads(nthreads)
+    size, bs, nb, epochs, lr0, ncmp = TRAIN_RUN
+    xs, ts, xv, tv, st, lw = _train_run_data()
+    oracle_eval = _oracle_eval
+    (ref_losses, miou_a), (ref_losses_b, miou_b) = _oracle_training_runs()
     # ---- HIP run (fp32 path)
     m = GRFBUNet(3, 2, base_c=8)
     m.load_state_dict(st, strict=True)
