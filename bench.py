@@ -84,7 +84,7 @@ class KernelTimer:
             cname, cargs = self._canon(name, args)
             from egm_unet_amd import ops as _o
             self.records.append((cname, cargs, _Span(e0, e1, reps), None))
-            self.grouped.append(_o.conv_group.depth > 0)
+            self.grouped.append(_o.conv_group.serial if _o.conv_group.depth > 0 else 0)      # which launch group the call sits in (0 = none)
         self.lib.call = timed
         return self
 
@@ -170,7 +170,21 @@ class KernelTimer:
         ops.conv_group block: only those run under THIS kernel name in the replayed graph (grouped members run as one *_multi launch),
         so they are the launches a rocprofv3 trace / PMC pass of the graph replays attributes to it."""
         agg = {}
-        for (name, args, e0, e1), grouped in zip(self.records, self.grouped):
+        keyed = []
+        for name, args, e0, e1 in self.records:
+            k = name
+            if name == "egm_conv_fwd":
+                k = self._kernel_name("egm_conv_kernel_name", args[0], *args[9:17])
+            elif name == "egm_conv_wgrad":
+                k = self._kernel_name("egm_conv_wgrad_kernel_name", args[0], *args[7:12], *args[14:17])
+            keyed.append(k)
+        # a launch group merges the members that run the SAME kernel instantiation; a member alone of its kind launches under its own name
+        members = {}
+        for k, gid in zip(keyed, self.grouped):
+            if gid:
+                members[(gid, k)] = members.get((gid, k), 0) + 1
+        for (name, args, e0, e1), gid, kk in zip(self.records, self.grouped, keyed):
+            grouped = bool(gid) and members[(gid, kk)] > 1
             key = name
             flops = 0.0
             if name == "egm_conv_fwd":

@@ -458,10 +458,13 @@ class conv_group:
     outputs are first used after the block.  EGM_GROUP_CONVS=0 turns it into a no-op."""
 
     depth = 0                                 # open conv_group blocks, whether or not merging is switched on (bench.py's bookkeeping)
+    serial = 0                                # number of the outermost block that is open / was opened last
 
     def __enter__(self):
         self.on = _GROUP_CONVS
         conv_group.depth += 1
+        if conv_group.depth == 1:
+            conv_group.serial += 1
         if self.on:
             lib().call("egm_group_begin")
         return self

@@ -116,7 +116,7 @@ def test_bench_two_rank_code_path_rehearsal():
     env = dict(os.environ, EGM_BENCH_SINGLE_DEVICE="1", EGM_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "128",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--instrument"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
