@@ -222,7 +222,6 @@ class EdgeEnhancedGRFB(nn.Module):
         """pool=True: -> (result, maxpool2(result)) with the pool fused into the target gate (ops.gate3_pool) where that applies."""
         edge, x_e2, x_cat, x_sc = ops.fork_highpass3(x, 3)       # highpass3(x) + three aliases: backward sums all four gradients in one pass
         xe = self.edge_enhancer(None, x_e2, edge=edge)
-        xe_d, xe_e, xe_c = ops.fork(xe, 3)
         # the three branch tails write straight into their slots of the concat destination (no copy, one tensor write less each)
         N, H, W, C = x.shape
         if cat is None:
@@ -231,6 +230,13 @@ class EdgeEnhancedGRFB(nn.Module):
             buf, (_, sd, se, sc) = cat
         else:
             buf, sd, se, sc = None, None, None, None
+        bd, be, bc = self.branch_dir, self.branch_edge, self.branch_ctx
+        pw_heads = not ops.fuse_bn() and ops.pw_applicable(xe, [bd[0].conv, be[0].conv], "heads")
+        if pw_heads:
+            xe_d, xe_c = ops.fork(xe, 2)
+            xe_e = None
+        else:
+            xe_d, xe_e, xe_c = ops.fork(xe, 3)
         if ops.fuse_bn():
             d = self._seq(self.branch_dir, xe_d, sd)                  # operand-prologue path: one branch after the other
             e = self._seq(self.branch_edge, xe_e, se)
@@ -238,15 +244,24 @@ class EdgeEnhancedGRFB(nn.Module):
         else:
             # The three branches are independent and work on 8-32 channel tensors whose BatchNorm passes are launch-latency bound:
             # they advance in lockstep, and layers of equal depth share their BatchNorm launches (ops.multi_conv_bn_act).
-            bd, be, bc = self.branch_dir, self.branch_edge, self.branch_ctx
-
             def item(m, t, o=None):
                 return (t, m.conv, m.bn, ACT_RELU if m.relu is not None else ACT_NONE, m._dil, m._groups, o)
-            d, e, c = ops.multi_conv_bn_act([item(bd[0], xe_d), item(be[0], xe_e), item(bc[0], xe_c)])     # heads: 1x1, 1x1, 3x3
+
+            def head(m, o=None):
+                return (m.conv, m.bn, ACT_RELU if m.relu is not None else ACT_NONE, None, None, 1.0, o)
+            if pw_heads:
+                # the two 1x1 heads read the same tensor: ONE moment pass, ONE streaming pass with the stacked weights (csrc/pw_bn.hip)
+                d, e = ops.pw_conv_bn([(xe_d, [head(bd[0]), head(be[0])])])
+                c = bc[0](xe_c)
+            else:
+                d, e, c = ops.multi_conv_bn_act([item(bd[0], xe_d), item(be[0], xe_e), item(bc[0], xe_c)])     # heads: 1x1, 1x1, 3x3
             e = be[1](e)                                                                                  # EdgeAwareFeatureEnhancer(i)
             e, c = ops.multi_conv_bn_act([item(be[2], e), item(bc[1], c)])                                # grouped 3x3
             d, e, c = ops.multi_conv_bn_act([item(bd[1], d), item(be[3], e), item(bc[2], c)])             # dilated 3x3 (12 / 24 / 36)
-            d, e, c = ops.multi_conv_bn_act([item(bd[2], d, sd), item(be[4], e, se), item(bc[3], c, sc)])  # 1x1 tails -> concat slots
+            if all(ops.pw_applicable(t, [m.conv], "tails") for m, t in ((bd[2], d), (be[4], e), (bc[3], c))):
+                d, e, c = ops.pw_conv_bn([(d, [head(bd[2], sd)]), (e, [head(be[4], se)]), (c, [head(bc[3], sc)])])  # 1x1 tails -> concat slots
+            else:
+                d, e, c = ops.multi_conv_bn_act([item(bd[2], d, sd), item(be[4], e, se), item(bc[3], c, sc)])
         cat = ops.cat_channels([x_cat, d, e, c], buf)
         out_f = self.fusion_conv(cat)
         # relu(out*scale + BN(conv1x1(x))): the shortcut's BatchNorm apply and the residual ReLU are one pass (csrc/bn_fused.hip)

@@ -1253,6 +1253,8 @@ def conv_bn_ew(x, conv, bn, act, p, mode, alpha=1.0, out=None):
     """F(p, act(BN(conv(x)))) with F = EW_GATE: p*(1+z) or EW_SAR: relu(alpha*p + z); 1x1 convs (the two users in EdgeEnhancedGRFB)."""
     if conv.weight.shape[2] != 1 or conv.weight.shape[3] != 1 or conv.groups != 1:
         raise RuntimeError("conv_bn_ew: 1x1 ungrouped convolutions only")
+    if pw_applicable(x, [conv]):
+        return pw_conv_bn([(x, [(conv, bn, act, mode, p, alpha, out)])])[0]
     if not _FUSE_BN_EW:
         z = conv_bn_act(x, conv, bn, act)
         if mode == EW_GATE:
@@ -1265,6 +1267,198 @@ def conv_bn_ew(x, conv, bn, act, p, mode, alpha=1.0, out=None):
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _ConvBNEw.apply(materialize(x), materialize(p), conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                            momentum, act, training, mode, alpha, None if out is None else [out])
+
+
+# ----------------------------------------------------------------------------------------------------------
+# 1x1 conv -> BatchNorm -> activation (-> element-wise consumer) from the input's moments (csrc/pw_bn.hip)
+# ----------------------------------------------------------------------------------------------------------
+# Built, parity-tested (tests/test_gpu_pw.py) and measured SLOWER than the materialised chain on every site of the headline config
+# (+0.55 ms with the conv_bn_ew chains, +0.07 ms with the branch tails): opt-in.
+_FUSE_PW = os.environ.get("EGM_PW_BN", "0") != "0"
+_PW_HEAD = struct.Struct("<23Qq14i3f4x")          # egm_pw_head (include/egm_hip.h)
+
+
+def fuse_pw(enabled=None):
+    """Get / set whether 1x1 conv -> BatchNorm(+act, + GATE / SAR) chains run in the moment form (no conv output in memory)."""
+    global _FUSE_PW
+    if enabled is not None:
+        _FUSE_PW = bool(enabled)
+    return _FUSE_PW
+
+
+def _pw_head(x=None, w=None, wd=None, bias=None, gamma=None, beta=None, rm=None, rv=None, coef=None, p=None, out=None, g=None, q=None, dp=None,
+             sums=None, cf4=None, dw=None, dbias=None, mom=None, cov=None, mu=None, bwd=None, dx=None, npix=0, ldx=0, lddx=0, Cin=0, Cin_real=0,
+             Cout=0, CoutP=0, act=0, mode=0, ldp=0, ldo=0, ldg=0, ldq=0, lddp=0, train=0, alpha=1.0, eps=0.0, momentum=0.0):
+    dp_ = lambda t: 0 if t is None else t.data_ptr()
+    return _PW_HEAD.pack(dp_(x), dp_(w), dp_(wd), dp_(bias), dp_(gamma), dp_(beta), dp_(rm), dp_(rv), dp_(coef), dp_(p), dp_(out), dp_(g), dp_(q),
+                         dp_(dp), dp_(sums), dp_(cf4), dp_(dw), dp_(dbias), dp_(mom), dp_(cov), dp_(mu), dp_(bwd), dp_(dx), npix, ldx, lddx, Cin,
+                         Cin_real, Cout, CoutP, act, mode, ldp, ldo, ldg, ldq, lddp, train, alpha, eps, momentum)
+
+
+def _pw_ok(dtype, CinP, couts):
+    """couts: padded output channel counts of the heads sharing one input"""
+    return bool(lib().cdll.egm_pw_supported(dtype_code(dtype), CinP, sum(couts), len(couts)))
+
+
+class _PwConvBN(Function):
+    """K <= 4 inputs, each feeding one or two 1x1 conv -> BatchNorm -> act (-> GATE / SAR) heads, as ONE autograd node in the moment form
+    (csrc/pw_bn.hip): forward = moments + covariance + coefficients + ONE streaming pass per launch; backward = reduce + coefficients
+    (with the weight gradients in closed form) + ONE streaming pass that also sums the data gradients of the heads sharing an input.
+
+    meta: list (one entry per input) of lists (one entry per head) of
+          (rm, rv, eps, momentum, act, mode, alpha, training, out_slot)            mode: 0 none, 1 GATE, 2 SAR
+    flat: per input: x, then per head: weight, bias, gamma, beta, p"""
+
+    @staticmethod
+    def forward(ctx, meta, *flat):
+        L, st = lib(), stream()
+        descs, outs, saved, info, keep = [], [], [], [], []
+        pos = 0
+        dt = None
+        for heads in meta:
+            x, ldx = _nhwc(flat[pos])
+            xpos = pos
+            pos += 1
+            N, H, W, CinP = x.shape
+            npix, dev = _npix(x), x.device
+            dt = dtype_code(x.dtype)
+            training_any = any(h[7] for h in heads)
+            mom = cov = mu = None
+            if training_any:
+                mom = _f32(L.query("egm_pw_moments_floats", npix, CinP), dev)
+                cov = torch.empty((CinP, CinP), dtype=torch.float64, device=dev)
+                mu = torch.empty(CinP, dtype=torch.float64, device=dev)
+            hinfo = []
+            for (rm, rv, eps, momentum, act, mode, alpha, training, out_slot) in heads:
+                weight, bias, gamma, beta, p = flat[pos:pos + 5]
+                wpos = pos
+                pos += 5
+                Cout, Cin = weight.shape[0], weight.shape[1]
+                if pad8(Cin) != CinP:
+                    raise RuntimeError(f"pw_conv_bn: input has {CinP} channels, weight expects {Cin}")
+                CoutP = pad8(Cout)
+                wf, wd = _packed_weights(weight, 1, x.dtype)
+                coef = _f32((4, CoutP), dev)
+                out, ldo = _slot_or_new(out_slot, (N, H, W, CoutP), x.dtype, dev)
+                pt, ldp = (None, 0)
+                if mode:
+                    pt, ldp = _nhwc(p)
+                    if tuple(pt.shape) != (N, H, W, CoutP):
+                        raise RuntimeError(f"pw_conv_bn: element-wise operand {tuple(pt.shape)} does not match the conv output {(N, H, W, CoutP)}")
+                descs.append(_pw_head(x=x, w=wf, wd=wd, bias=bias.detach() if bias is not None else None, gamma=gamma.detach(), beta=beta.detach(),
+                                      rm=rm, rv=rv, coef=coef, p=pt, out=out, mom=mom, cov=cov, mu=mu, npix=npix, ldx=ldx, Cin=CinP, Cin_real=Cin,
+                                      Cout=Cout, CoutP=CoutP, act=act, mode=mode, ldp=ldp, ldo=ldo, train=1 if training else 0, alpha=float(alpha),
+                                      eps=eps, momentum=momentum))
+                outs.append(out)
+                # GATE needs p for its backward, SAR the output (ReLU mask)
+                qsave = pt if mode == 1 else (out if mode == 2 else None)
+                hinfo.append((wpos, len(saved), Cout, Cin, CoutP, act, mode, float(alpha), training, bias is not None))
+                saved += [weight, wf, wd, coef, qsave]
+            info.append((xpos, len(saved), hinfo, training_any))
+            saved += [x, cov, mu]
+            keep.append(mom)                         # alive until the launches below are enqueued (the allocator would hand it to the next input)
+        blob = b"".join(descs)
+        if any(i[3] for i in info):
+            tr = b"".join(d for d, i in zip(descs, [ii for ii in info for _ in ii[2]]) if i[3])
+            L.call("egm_pw_moments", dt, tr, len(tr) // _PW_HEAD.size, st)
+        L.call("egm_pw_fwd_coefs", dt, blob, len(descs), st)
+        L.call("egm_pw_fwd", dt, blob, len(descs), st)
+        ctx.save_for_backward(*[t for t in saved if t is not None])
+        ctx.saved_mask = [t is not None for t in saved]
+        ctx.info = info
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        L, st = lib(), stream()
+        it = iter(ctx.saved_tensors)
+        saved = [next(it) if m else None for m in ctx.saved_mask]
+        ngrad = max(max(h[0] for h in i[2]) for i in ctx.info) + 5
+        grads = [None] * ngrad
+        descs, keep = [], []
+        k = 0
+        dt = None
+        for xpos, xs, hinfo, _ in ctx.info:
+            x, cov, mu = saved[xs:xs + 3]
+            x, ldx = _nhwc(x)
+            N, H, W, CinP = x.shape
+            npix, dev = _npix(x), x.device
+            dt = dtype_code(x.dtype)
+            tot = sum(h[4] for h in hinfo)
+            bwd = _f32(L.query("egm_pw_bwd_floats", dt, npix, CinP, tot), dev)
+            dx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=dev) if ctx.needs_input_grad[1 + xpos] else None
+            grads[xpos] = dx
+            for (wpos, sp, Cout, Cin, CoutP, act, mode, alpha, training, has_bias) in hinfo:
+                weight, wf, wd, coef, qsave = saved[sp:sp + 5]
+                g = gouts[k]
+                k += 1
+                if g is None:
+                    g = torch.zeros((N, H, W, CoutP), dtype=x.dtype, device=dev)
+                g, ldg = _nhwc(g)
+                q, ldq = (None, 0) if qsave is None else _nhwc(qsave)
+                sums, cf4 = _f32((2, CoutP), dev), _f32((4, CoutP), dev)
+                need_w = ctx.needs_input_grad[1 + wpos]
+                dw = torch.empty_like(weight) if need_w else None
+                dp = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev) if (mode and ctx.needs_input_grad[1 + wpos + 4]) else None
+                dbias = None
+                if has_bias and ctx.needs_input_grad[1 + wpos + 1]:
+                    dbias = _zero_grad_vec(Cout, dev) if training else _f32(CoutP, dev)
+                descs.append(_pw_head(x=x, w=wf, wd=wd, coef=coef, g=g, q=q, dp=dp, sums=sums, cf4=cf4, dw=dw, dbias=None if training else dbias,
+                                      cov=cov, mu=mu, bwd=bwd, dx=dx, npix=npix, ldx=ldx, lddx=CinP, Cin=CinP, Cin_real=Cin, Cout=Cout, CoutP=CoutP,
+                                      act=act, mode=mode, ldg=ldg, ldq=ldq, lddp=CoutP, train=1 if training else 0, alpha=alpha))
+                keep += [g, q, sums, cf4, bwd]
+                grads[wpos] = dw
+                grads[wpos + 1] = dbias if (dbias is None or training) else dbias[:Cout]
+                grads[wpos + 2] = sums[1, :Cout] if ctx.needs_input_grad[1 + wpos + 2] else None
+                grads[wpos + 3] = sums[0, :Cout] if ctx.needs_input_grad[1 + wpos + 3] else None
+                grads[wpos + 4] = dp
+        blob = b"".join(descs)
+        L.call("egm_pw_bwd_reduce", dt, blob, len(descs), st)
+        L.call("egm_pw_bwd_coefs", dt, blob, len(descs), st)
+        L.call("egm_pw_bwd_apply", dt, blob, len(descs), st)
+        return (None,) + tuple(grads)
+
+
+def pw_conv_bn(problems):
+    """problems: list (<= 4) of (x, heads), heads = list (<= 2) of (conv, bn, act, mode, p, alpha, out) with mode None / EW_GATE / EW_SAR:
+    out_h = F(p, act(BN(conv1x1_h(x)))) for every head, computed in the moment form.  -> flat list of outputs (problem-major).
+    Callers check pw_applicable() first."""
+    meta, flat = [], []
+    for x, heads in problems:
+        flat.append(materialize(x))
+        hm = []
+        for conv, bn, act, mode, p, alpha, out in heads:
+            if bn.training and bn.num_batches_tracked is not None and not getattr(bn, "_egm_counter_managed", False):
+                bn.num_batches_tracked.add_(1)
+            training = bn.training or bn.running_mean is None
+            momentum = 0.1 if bn.momentum is None else bn.momentum
+            hm.append((bn.running_mean, bn.running_var, bn.eps, momentum, act, 0 if mode is None else mode + 1, alpha, training,
+                       None if out is None else [out]))
+            flat += [conv.weight, conv.bias, bn.weight, bn.bias, None if mode is None else materialize(p)]
+        meta.append(hm)
+    return list(_PwConvBN.apply(meta, *flat))
+
+
+_PW_SITES = set(t for t in os.environ.get("EGM_PW_SITES", "ew,heads,tails").split(",") if t)
+
+
+def pw_sites(sites=None):
+    """Get / set the places of EdgeEnhancedGRFB that use the moment form: "ew" (the conv_bn_ew chains: both EdgeAwareFeatureEnhancers and
+    the shortcut), "heads" (the two 1x1 branch heads sharing the enhanced input), "tails" (the three 1x1 branch tails)."""
+    global _PW_SITES
+    if sites is not None:
+        _PW_SITES = set(sites)
+    return set(_PW_SITES)
+
+
+def pw_applicable(x, convs, site="ew"):
+    """True when the 1x1 convs `convs` (nn.Conv2d holders) reading the NHWC tensor / Lazy x can take the moment form."""
+    if not _FUSE_PW or _FUSE_BN or site not in _PW_SITES:
+        return False
+    for c in convs:
+        if tuple(c.weight.shape[2:]) != (1, 1) or c.groups != 1 or pad8(c.weight.shape[1]) != x.shape[3]:
+            return False
+    return _pw_ok(x.dtype, x.shape[3], [pad8(c.weight.shape[0]) for c in convs])
 
 
 def _slot_or_new(out_slot, shape, dtype, device):

@@ -255,6 +255,45 @@ int egm_bn_ew_bwd_apply(int dtype, int mode, const void* g, int ldg, const void*
                         const float* cf_4xC, int act, float alpha, void* dy, int lddy, void* dp, int lddp, long long npix, int C,
                         egm_stream_t s);
 
+/* ---- 1x1 conv -> BatchNorm -> activation (-> element-wise consumer) from the INPUT's moments (csrc/pw_bn.hip) -------------------
+ * BasicConv(k = 1) / EdgeAwareFeatureEnhancer / the GRFB shortcut (src/EGM-UNet.py:872-886, 958-975, 1256-1278, 1296-1317).  The batch
+ * statistics of y = W x follow from S = sum x and G = sum x x^T, so the conv output never reaches memory:
+ *   egm_pw_moments   x -> per-wave partial Gram blocks and channel sums           (once per input; heads on the same x share it)
+ *   egm_pw_fwd_coefs partials -> covariance / mean (double) -> coef rows [4][CoutP] scale | shift | mean | rstd of y' = W x per head
+ *                    (conv bias folded in), running statistics updated as nn.BatchNorm2d does; train = 0: from the running statistics
+ *   egm_pw_fwd       out = F(p, act(scale * (W x) + shift)),  F: mode 0 identity, 1 GATE p*(1+z), 2 SAR relu(alpha*p + z)
+ *   egm_pw_bwd_reduce  from x, g = dL/dout, q (GATE: p, SAR: out): partials of s0 = sum dzp, s1 = sum dzp*xhat, M = sum dzp x^T
+ *   egm_pw_bwd_coefs   -> sums [2][CoutP] (dbeta | dgamma), cf4 [4][CoutP] (scale | shift | cb | cc), dw [Cout][Cin_real] =
+ *                      sc*M + cb*S^T + cc*(W G) (the weight gradient in closed form), dbias (zero under batch statistics)
+ *   egm_pw_bwd_apply   dy = sc*dzp + cb + cc*y' per element; dx = sum over the heads on x of W^T dy; dp of the element-wise consumer
+ * One egm_pw_head per conv; heads with the same x pointer form one problem (<= 2 heads, stacked CoutP <= 128, Cin <= 128) and
+ * share mom_partials / cov / mu / bwd_partials / dx, read from the first of them; <= 4 problems per call (one launch per kernel).
+ * w = egm_conv_pack's wf [CoutP][Cin], wd its wd [Cin][CoutP] (1x1, groups 1), both in `dtype`.  All pointers device pointers. */
+typedef struct egm_pw_head {
+    const void* x;  const void* w;  const void* wd;
+    const float* bias;  const float* gamma;  const float* beta;  float* running_mean;  float* running_var;
+    float* coef;                                   /* [4][CoutP] */
+    const void* p;  void* out;                     /* forward: element-wise partner (mode != 0), output */
+    const void* g;  const void* q;  void* dp;      /* backward: dL/dout, GATE: p / SAR: out, gradient of p (may be NULL) */
+    float* sums;  float* cf4;  float* dw;  float* dbias;
+    float* mom_partials;  double* cov;  double* mu; /* egm_pw_moments_floats floats; [Cin][Cin]; [Cin] */
+    float* bwd_partials;  void* dx;                /* egm_pw_bwd_floats floats; gradient of x (may be NULL) */
+    long long npix;
+    int ldx, lddx, Cin, Cin_real, Cout, CoutP, act, mode, ldp, ldo, ldg, ldq, lddp, train;
+    float alpha, eps, momentum;
+} egm_pw_head;
+int egm_pw_supported(int dtype, int Cin, int CoutTot, int heads_on_input);
+int egm_pw_moments_parts(long long npix);
+long long egm_pw_moments_floats(long long npix, int Cin);
+int egm_pw_bwd_parts(int dtype, long long npix, int Cin, int CoutTot);
+long long egm_pw_bwd_floats(int dtype, long long npix, int Cin, int CoutTot);
+int egm_pw_moments(int dtype, const egm_pw_head* heads, int n, egm_stream_t s);
+int egm_pw_fwd_coefs(int dtype, const egm_pw_head* heads, int n, egm_stream_t s);
+int egm_pw_fwd(int dtype, const egm_pw_head* heads, int n, egm_stream_t s);
+int egm_pw_bwd_reduce(int dtype, const egm_pw_head* heads, int n, egm_stream_t s);
+int egm_pw_bwd_coefs(int dtype, const egm_pw_head* heads, int n, egm_stream_t s);
+int egm_pw_bwd_apply(int dtype, const egm_pw_head* heads, int n, egm_stream_t s);
+
 /* ---- pooling / resampling --------------------------------------------------------------------- */
 /* nn.MaxPool2d(2,2) (src/EGM-UNet.py:908); H, W are the INPUT sizes (even). */
 int egm_maxpool2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, egm_stream_t s);
