@@ -140,7 +140,14 @@ class CLIP(nn.Module):
         """text int [n, L<=248] (clip.tokenize) -> [n, embed_dim] fp32   (clip/model.py:487-501)"""
         require_gpu()
         dev = self.token_embedding.weight.device
-        tokens = text.to(dev).to(torch.int32).contiguous()
+        # token ids and the EOT positions (EOT is the largest id) are index bookkeeping: prepared on the host when the tokens come from
+        # clip.tokenize (a CPU tensor), so no cast / reduce kernel runs on the device for them
+        if text.is_cuda:
+            tokens = text.to(torch.int32).contiguous()
+            eot = tokens.argmax(dim=-1).to(torch.int32)
+        else:
+            t32 = text.to(torch.int32).contiguous()
+            tokens, eot = t32.to(dev, non_blocking=True), t32.argmax(dim=-1).to(torch.int32).to(dev, non_blocking=True)
         n, L = tokens.shape
         D = self.token_embedding.weight.shape[1]
         dt = self.compute_dtype
@@ -151,7 +158,6 @@ class CLIP(nn.Module):
         for blk in self.transformer.resblocks:
             x = blk.run(x, "causal")
         x = O.layernorm(x, self.ln_final)
-        eot = tokens.argmax(dim=-1).to(torch.int32)                   # index bookkeeping (EOT is the largest id)
         sel = torch.empty((n, D), dtype=dt, device=dev)
         lib().call("egm_gather_rows", dtype_code(dt), ptr(x), ptr(eot), ptr(sel), n, L, D, stream())
         return O.matmul_kn(sel, self.text_projection).float()

@@ -184,6 +184,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wreg_kernel(WregParams p) {
         for (int m = 0; m < R; ++m)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
+                if (p.bias != nullptr) {                              // rare; in fp32, before the ONE rounding to bf16
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int co = gq * 8 + h * 4 + j;
+                        acc[m][gq * 4 + j] += co < p.bias_n ? p.bias[co] : 0.f;
+                    }
+                }
                 uint2 v;
                 v.x = pack2(acc[m][gq * 4 + 0], acc[m][gq * 4 + 1]);
                 v.y = pack2(acc[m][gq * 4 + 2], acc[m][gq * 4 + 3]);
@@ -210,17 +217,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wreg_kernel(WregParams p) {
                 const int pl = i2 * 16 + slot;
                 const bool ok = oy < p.H && ox0 + pl < p.W;
                 uint4 rw = raw[m][i2];
-                if (p.bias != nullptr) {                              // rare: rounds twice, like the other bf16 conv kernels
-                    float bv[8], b8[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { const int co = cv * 8 + j; b8[j] = co < p.bias_n ? p.bias[co] : 0.f; }
-                    bv[0] = __uint_as_float(rw.x << 16); bv[1] = __uint_as_float(rw.x & 0xffff0000u);
-                    bv[2] = __uint_as_float(rw.y << 16); bv[3] = __uint_as_float(rw.y & 0xffff0000u);
-                    bv[4] = __uint_as_float(rw.z << 16); bv[5] = __uint_as_float(rw.z & 0xffff0000u);
-                    bv[6] = __uint_as_float(rw.w << 16); bv[7] = __uint_as_float(rw.w & 0xffff0000u);
-                    rw.x = pack2(bv[0] + b8[0], bv[1] + b8[1]); rw.y = pack2(bv[2] + b8[2], bv[3] + b8[3]);
-                    rw.z = pack2(bv[4] + b8[4], bv[5] + b8[5]); rw.w = pack2(bv[6] + b8[6], bv[7] + b8[7]);
-                }
                 if (!ok) rw = make_uint4(0, 0, 0, 0);
                 unsigned char* dst = ok ? reinterpret_cast<unsigned char*>(yrow + (long long)pl * p.ldy) : dump;
                 *reinterpret_cast<uint4*>(dst) = rw;

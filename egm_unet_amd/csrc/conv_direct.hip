@@ -88,11 +88,9 @@ __device__ __forceinline__ void conv_direct_body(const DirectParams& p, const in
     }
     __syncthreads();
 
-    float ssum[8], ssq[8], bias8[8];
+    float ssum[8], ssq[8];
     zero8(ssum); zero8(ssq);
     const int cvo = lane % NV, slot = lane / NV;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const int co = co0 + cvo * 8 + j; bias8[j] = (p.bias != nullptr && co < p.bias_n) ? p.bias[co] : 0.f; }
     const long long npix = (long long)p.N * p.H * p.W;
     const bool row_blocks = (p.W & 31) == 0;                                 // a 32-pixel block never straddles an image row
     const unsigned char* arow = wts + (size_t)r31 * p.wrow + h * 16;
@@ -199,6 +197,13 @@ __device__ __forceinline__ void conv_direct_body(const DirectParams& p, const in
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
+                if (p.bias != nullptr) {                      // in fp32, before the ONE rounding to bf16
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int co = co0 + nt * 32 + gq * 8 + h * 4 + j;
+                        acc[nt][gq * 4 + j] += co < p.bias_n ? p.bias[co] : 0.f;
+                    }
+                }
                 uint2 pk;
                 pk.x = (uint32_t)f32_to_bf16(acc[nt][gq * 4 + 0]) | ((uint32_t)f32_to_bf16(acc[nt][gq * 4 + 1]) << 16);
                 pk.y = (uint32_t)f32_to_bf16(acc[nt][gq * 4 + 2]) | ((uint32_t)f32_to_bf16(acc[nt][gq * 4 + 3]) << 16);
@@ -213,10 +218,6 @@ __device__ __forceinline__ void conv_direct_body(const DirectParams& p, const in
             float v[8];
             load8(reinterpret_cast<const bf16_t*>(ot + pl * OROW + cvo * 16), v);
             if (po < npix && co < p.Cout) {
-                if (p.bias != nullptr) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<bf16_t>(v[j] + bias8[j]));
-                }
                 store8(yg + po * p.ldy + co, v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }

@@ -480,12 +480,6 @@ __device__ __forceinline__ void conv_igemm_pipe_body(const ConvParams& p, const 
     f32x16_t acc[R][NT];
     float ssum[8], ssq[8];
     zero8(ssum); zero8(ssq);
-    float bias8[8];
-    {
-        const int cv = lane % NV;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const int co = co0 + cv * 8 + j; bias8[j] = (p.bias != nullptr && co < p.bias_n) ? p.bias[co] : 0.f; }
-    }
 
 #ifdef EGM_CONV_TIMING
     long long tph[6] = {0, 0, 0, 0, 0, 0}; int nstages = 0;
@@ -570,6 +564,13 @@ __device__ __forceinline__ void conv_igemm_pipe_body(const ConvParams& p, const 
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
+                        if (p.bias != nullptr) {              // in fp32, before the ONE rounding to the storage type (as torch and the generic kernel)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int co = co0 + nt * 32 + gq * 8 + h * 4 + j;
+                                acc[m][nt][gq * 4 + j] += co < p.bias_n ? p.bias[co] : 0.f;
+                            }
+                        }
                         uint2 pk;
                         pk.x = (uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 0]) | ((uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 1]) << 16);
                         pk.y = (uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 2]) | ((uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 3]) << 16);
@@ -585,10 +586,6 @@ __device__ __forceinline__ void conv_igemm_pipe_body(const ConvParams& p, const 
                     float v[8];
                     load8(reinterpret_cast<const bf16_t*>(ot + pl * OROW + cv * 16), v);
                     if (oy < p.H && ox < p.W && co < p.Cout) {
-                        if (p.bias != nullptr) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<bf16_t>(v[j] + bias8[j]));
-                        }
                         store8(yg + ((long long)(cur.n * p.H + oy) * p.W + ox) * p.ldy + co, v);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }

@@ -1040,7 +1040,10 @@ int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW
     // ... unless they carry operand prologues: the element-wise work belongs on producer waves, beside the MFMAs
     const bool ws_family = dtype == EGM_BF16 && ws_on && (pl->ntaps >= 5 || pre);
     pl->ws = (ws_family && !smooth) ? 1 : 0;
-    const int per_cu = ws_family ? 1 : ((pl->ntaps <= 3 && dtype == EGM_BF16) ? per_cu_small : 1);
+    int per_cu = ws_family ? 1 : ((pl->ntaps <= 3 && dtype == EGM_BF16) ? per_cu_small : 1);
+    // the wave-specialised kernel on the narrow layers (one 32 x 32 block, two 38 KB image pairs): EGM_WGRAD_WS_PER_CU workgroups per CU
+    static const int ws_per_cu = getenv("EGM_WGRAD_WS_PER_CU") ? atoi(getenv("EGM_WGRAD_WS_PER_CU")) : 1;
+    if (ws_family && ws_per_cu > 1 && A * B == 1 && pl->ntaps == 9) per_cu = ws_per_cu;
     int nsplit = 256 * per_cu / blocks_per_split;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > pl->npt) nsplit = pl->npt;

@@ -1013,6 +1013,167 @@ __global__ __launch_bounds__(256) void pw_bwd_apply_kernel(const PwLaunch L) {
     }
 }
 
+// ================================================================= 1x1 conv backward: data gradient + weight-gradient slab in ONE pass
+// dx = dy W and dW = dy^T x of a 1x1 convolution both read dy; as two kernels (the data-gradient conv and the weight-gradient slab
+// kernel) dy is pulled from memory twice and each launch pays its own start-up on tensors that take 10-30 us at the roofline.  Here a
+// wave stages its 32-pixel tile of x and dy once (coalesced 16-byte loads, next tile prefetched), multiplies dx = wd . dy from row reads
+// of the dy image and accumulates dW += dy^T x from transposing reads of both images; no element-wise work at all.  grid.y = 64-channel
+// blocks of Cin: a workgroup owns the dx channels and the dW columns of its block and reads only those x channels.  One slab
+// [CoutP][CinP] per workgroup column (waves summed through LDS in wave order), laid out like conv_wgrad.hip's slabs, so the deferred
+// multi-conv reduction (egm_wgrad_reduce_multi) finishes them.  Limits: padded Cin, Cout <= 128.
+struct C1Prob { const void* x; const void* dy; const void* wd; void* dx; float* slab; long long npix; int ldx, lddy, lddx, Cin, Cout, ntiles, nparts, blk0; };
+struct C1Launch { int n, nw; C1Prob p[PW_MAXP]; };
+struct C1Geom { int Cout32, WDRB, wd_bytes, wave_off, x_bytes, dy_bytes, tile_rb, tile_bytes, wave_bytes; };
+template <typename T>
+__host__ __device__ inline C1Geom c1_geom(int Cout) {
+    constexpr int ESZ = Pw<T>::ESZ;
+    C1Geom g;
+    g.Cout32 = r32(Cout);
+    g.WDRB = g.Cout32 * ESZ + 16;
+    g.wd_bytes = 64 * g.WDRB;
+    g.wave_off = g.wd_bytes;
+    g.x_bytes = 2 * Pw<T>::BLK;
+    g.dy_bytes = g.Cout32 / 32 * Pw<T>::BLK;
+    g.tile_rb = 64 * ESZ + 16;
+    g.tile_bytes = 32 * g.tile_rb;
+    g.wave_bytes = g.x_bytes + g.dy_bytes + g.tile_bytes;
+    return g;
+}
+
+template <typename T, int K, int NI>
+__global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const C1Launch L) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using P = Pw<T>;
+    constexpr int VEC = P::VEC, ESZ = P::ESZ;
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < PW_MAXP; ++i) if (i < L.n && (int)blockIdx.x >= L.p[i].blk0) k = i;
+    const C1Prob& q = L.p[k];
+    const int cb = blockIdx.y, c_lo = cb * 64;
+    if (c_lo >= q.Cin) return;
+    const int c_n = q.Cin - c_lo < 64 ? q.Cin - c_lo : 64;         // x / dx channels of this block
+    const C1Geom g = c1_geom<T>(q.Cout);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r31 = lane & 31, h = lane >> 5;
+    unsigned char* wdimg = smem;                                    // [64 cin rows of the block][Cout32], zero beyond Cin / Cout
+    unsigned char* ximg = smem + g.wave_off + wv * g.wave_bytes;
+    unsigned char* dyimg = ximg + g.x_bytes;
+    unsigned char* tile = dyimg + g.dy_bytes;
+    {
+        const int nvr = g.Cout32 / VEC;
+        const T* wd = reinterpret_cast<const T*>(q.wd);
+        for (int i = threadIdx.x; i < 64 * nvr; i += blockDim.x) {
+            const int row = i / nvr, v = i - row * nvr, c = v * VEC;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (c_lo + row < q.Cin && c < q.Cout) val = *reinterpret_cast<const uint4*>(wd + (long long)(c_lo + row) * q.Cout + c);
+            *reinterpret_cast<uint4*>(wdimg + row * g.WDRB + c * ESZ) = val;
+        }
+    }
+    image_zero<T>(ximg, 2, lane);
+    image_zero<T>(dyimg, g.Cout32 / 32, lane);
+    __syncthreads();
+    const T* __restrict__ xg = reinterpret_cast<const T*>(q.x);
+    const T* __restrict__ dyg = reinterpret_cast<const T*>(q.dy);
+    T* __restrict__ dxg = reinterpret_cast<T*>(q.dx);
+    const int nwaves = q.nparts, nkc = g.Cout32 / 16;
+    int t = ((int)blockIdx.x - q.blk0) * L.nw + wv;
+    StageMap<K> smx, smd;
+    stage_map<T, K>(smx, q.ldx, c_lo, 64, q.Cin, lane);
+    stage_map<T, K>(smd, q.lddy, 0, q.Cout, q.Cout, lane);
+    const int nvi = c_n / VEC, nvip = pow2_ge(nvi), slotsi = 64 / nvip, cvi = lane % nvip, sloti = lane / nvip;
+    const int ni = g.Cout32 / 32;                                   // cout blocks in use (<= NI)
+    const bool two_b = c_n > 32;
+    f32x16_t am[NI][2];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { am[a][0][i] = 0.f; am[a][1][i] = 0.f; }
+    uint4 rx[K], rd[K];
+    if (t < q.ntiles) {
+        tile_load<T, K>(rx, xg, q.ldx, (long long)t * 32, q.npix, smx);
+        tile_load<T, K>(rd, dyg, q.lddy, (long long)t * 32, q.npix, smd);
+    }
+    for (; t < q.ntiles; t += nwaves) {
+        wave_fence();
+        tile_store<T, K>(rx, ximg, smx);
+        tile_store<T, K>(rd, dyimg, smd);
+        const int tn = t + nwaves;
+        if (tn < q.ntiles) {
+            tile_load<T, K>(rx, xg, q.ldx, (long long)tn * 32, q.npix, smx);
+            tile_load<T, K>(rd, dyg, q.lddy, (long long)tn * 32, q.npix, smd);
+        }
+        wave_fence();
+        if (dxg != nullptr) {
+            // dx[cin][pixel] = sum_cout wd[cin][cout] dy[cout][pixel]
+            typename P::Frag db[K];
+#pragma unroll
+            for (int ks = 0; ks < K; ++ks) if (ks < nkc) db[ks] = P::row_frag(dyimg, r31, ks * 16 + 8 * h);
+#pragma unroll
+            for (int cit = 0; cit < 2; ++cit) {
+                if (cit == 1 && !two_b) break;
+                f32x16_t acc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                const unsigned char* wrow = wdimg + (cit * 32 + r31) * g.WDRB;
+                typename P::Frag a[K];
+#pragma unroll
+                for (int ks = 0; ks < K; ++ks) if (ks < nkc) a[ks] = P::lin_frag(wrow, ks * 16 + 8 * h);
+#pragma unroll
+                for (int ks = 0; ks < K; ++ks) if (ks < nkc) acc = P::mma(a[ks], db[ks], acc);
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    P::put4(tile + r31 * g.tile_rb + (cit * 32 + gq * 8 + 4 * h) * ESZ, acc[gq * 4 + 0], acc[gq * 4 + 1], acc[gq * 4 + 2], acc[gq * 4 + 3]);
+            }
+            wave_fence();
+            if (cvi < nvi) {
+                const int left = (int)(q.npix - (long long)t * 32 < 32 ? q.npix - (long long)t * 32 : 32);
+                T* ob = dxg + (long long)t * 32 * q.lddx + c_lo + cvi * VEC;
+#pragma unroll
+                for (int it = 0; it < K; ++it) {
+                    const int px = sloti + it * slotsi;
+                    if (px < left) *reinterpret_cast<uint4*>(ob + (long long)px * q.lddx) = *reinterpret_cast<const uint4*>(tile + px * g.tile_rb + cvi * VEC * ESZ);
+                }
+            }
+        }
+        // dW[cout][cin] += dy^T x over the 32 pixels (K = pixels, both operands transposing reads)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const typename P::Frag b0 = P::col_frag(ximg, ks * 16, lane);
+            typename P::Frag b1 = b0;
+            if (two_b) b1 = P::col_frag(ximg + P::BLK, ks * 16, lane);
+#pragma unroll
+            for (int a = 0; a < NI; ++a) {
+                if (a < ni) {
+                    const typename P::Frag fa = P::col_frag(dyimg + a * P::BLK, ks * 16, lane);
+                    am[a][0] = P::mma(fa, b0, am[a][0]);
+                    if (two_b) am[a][1] = P::mma(fa, b1, am[a][1]);
+                }
+            }
+        }
+    }
+    // ---- one slab per workgroup: the waves' accumulators are added through LDS in wave order (fixed order), then stored
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);                   // [NI * 32][64]
+    for (int r = 0; r < L.nw; ++r) {
+        if (wv == r) {
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int idx = (a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 64 + b * 32 + r31;
+                        red[idx] = (r == 0 ? 0.f : red[idx]) + am[a][b][i];
+                    }
+        }
+        __syncthreads();
+    }
+    float* out = q.slab + (long long)((int)blockIdx.x - q.blk0) * q.Cout * q.Cin;
+    for (int i = threadIdx.x; i < q.Cout * 64; i += blockDim.x) {
+        const int row = i >> 6, col = i & 63;
+        if (col < c_n) out[(long long)row * q.Cin + c_lo + col] = red[row * 64 + col];
+    }
+}
+
 // ================================================================= host side
 struct Plan { int nw, smem; };
 template <typename T> Plan plan_for(int Cin, int CoutTot, bool second_w, bool aux) {
@@ -1357,4 +1518,72 @@ extern "C" int egm_pw_bwd_apply(int dtype, const egm_pw_head* heads, int n, egm_
                     (e.dp == nullptr || (egm_aligned16(e.dp) && e.lddp >= e.CoutP && e.lddp % 8 == 0)), "pw_bwd_apply: bad head %d", i);
     }
     return dtype == EGM_BF16 ? pw_bwd_apply_t<bf16_t>(heads, n, G, s) : pw_bwd_apply_t<float>(heads, n, G, s);
+}
+
+// ---------------------------------------------------------------- fused 1x1 backward
+namespace {
+constexpr int C1_WAVES = 1024;
+int c1_wgs(long long npix) { return (waves_for((npix + 31) / 32, C1_WAVES) + 3) / 4; }
+template <typename T> Plan c1_plan(int Cout) {
+    const C1Geom g = c1_geom<T>(Cout);
+    Plan p;
+    const int red = r32(Cout) * 64 * 4;
+    for (p.nw = 4; p.nw >= 1; p.nw >>= 1) {
+        p.smem = g.wave_off + p.nw * g.wave_bytes;
+        if (p.smem < red) p.smem = red;
+        if (p.smem <= PW_LDS_BUDGET) return p;
+    }
+    p.nw = 0; p.smem = 0;
+    return p;
+}
+template <typename T>
+int conv1x1_bwd_t(const egm_conv1x1_bwd_desc* d, int n, egm_stream_t s) {
+    C1Launch L; L.n = n; L.nw = 4;
+    int smem = 0, kk = 1, ni = 1, gy = 1, blk = 0;
+    for (int i = 0; i < n; ++i) {
+        const Plan p = c1_plan<T>(d[i].Cout);
+        EGM_REQUIRE(p.nw > 0, "conv1x1_bwd: shape does not fit the LDS");
+        if (p.nw < L.nw) L.nw = p.nw;
+    }
+    for (int i = 0; i < n; ++i) {
+        C1Prob& q = L.p[i];
+        q.x = d[i].x; q.dy = d[i].dy; q.wd = d[i].wd; q.dx = d[i].dx; q.slab = d[i].slabs; q.npix = d[i].npix; q.ldx = d[i].ldx; q.lddy = d[i].lddy;
+        q.lddx = d[i].lddx; q.Cin = d[i].Cin; q.Cout = d[i].Cout; q.ntiles = (int)((d[i].npix + 31) / 32);
+        const int wgs = c1_wgs(d[i].npix);
+        q.nparts = wgs * L.nw; q.blk0 = blk; blk += wgs;
+        const C1Geom g = c1_geom<T>(q.Cout);
+        int sm = g.wave_off + L.nw * g.wave_bytes;
+        if (sm < r32(q.Cout) * 64 * 4) sm = r32(q.Cout) * 64 * 4;
+        smem = std::max(smem, sm);
+        kk = std::max(kk, std::max(cv_of<T>(64), std::max(cv_of<T>(q.Cout), np_of<T>(64))));
+        ni = std::max(ni, r32(q.Cout) / 32);
+        gy = std::max(gy, (q.Cin + 63) / 64);
+    }
+#define C1_LAUNCH(KV, NIV) do { if (int rc = set_smem(conv1x1_bwd_kernel<T, KV, NIV>, smem)) return rc; \
+        hipLaunchKernelGGL((conv1x1_bwd_kernel<T, KV, NIV>), dim3(blk, gy), dim3(64 * L.nw), smem, (hipStream_t)s, L); } while (0)
+    if (ni <= 2) { if (kk <= 4) C1_LAUNCH(4, 2); else if (kk <= 8) C1_LAUNCH(8, 2); else C1_LAUNCH(16, 2); }
+    else { if (kk <= 8) C1_LAUNCH(8, 4); else C1_LAUNCH(16, 4); }
+#undef C1_LAUNCH
+    EGM_CHECK_LAUNCH("conv1x1_bwd");
+    return EGM_OK;
+}
+}  // namespace
+
+extern "C" int egm_conv1x1_bwd_supported(int dtype, int Cin, int Cout) {
+    if (!(Cin > 0 && Cin % 8 == 0 && Cin <= PW_MAXC && Cout > 0 && Cout % 8 == 0 && Cout <= PW_MAXC)) return 0;
+    if (dtype == EGM_BF16) return c1_plan<bf16_t>(Cout).nw > 0 ? 1 : 0;
+    if (dtype == EGM_F32) return c1_plan<float>(Cout).nw > 0 ? 1 : 0;
+    return 0;
+}
+extern "C" int egm_conv1x1_bwd_slabs(long long npix) { return npix > 0 ? c1_wgs(npix) : -1; }
+extern "C" int egm_conv1x1_bwd(int dtype, const egm_conv1x1_bwd_desc* descs, int n, egm_stream_t s) {
+    EGM_REQUIRE(descs && n > 0 && n <= PW_MAXP, "conv1x1_bwd: 1..%d convolutions per call", PW_MAXP);
+    for (int i = 0; i < n; ++i) {
+        const egm_conv1x1_bwd_desc& e = descs[i];
+        EGM_REQUIRE(egm_conv1x1_bwd_supported(dtype, e.Cin, e.Cout), "conv1x1_bwd: unsupported channels %d -> %d (entry %d)", e.Cin, e.Cout, i);
+        EGM_REQUIRE(e.x && e.dy && e.wd && e.slabs && egm_aligned16(e.x) && egm_aligned16(e.dy) && egm_aligned16(e.wd) && e.npix > 0 && e.ldx >= e.Cin &&
+                    e.ldx % 8 == 0 && e.lddy >= e.Cout && e.lddy % 8 == 0 && (e.dx == nullptr || (egm_aligned16(e.dx) && e.lddx >= e.Cin && e.lddx % 8 == 0)),
+                    "conv1x1_bwd: bad entry %d", i);
+    }
+    return dtype == EGM_BF16 ? conv1x1_bwd_t<bf16_t>(descs, n, s) : conv1x1_bwd_t<float>(descs, n, s);
 }

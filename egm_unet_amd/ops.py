@@ -382,6 +382,15 @@ _FUSE_BN = os.environ.get("EGM_FUSE_BN", "0") != "0"
 _FUSE_BN_BWD = os.environ.get("EGM_FUSE_BN_BWD", "0") != "0"
 
 
+# A/B switch for the size-selective prologue policy (VERDICT r03 item 6 ii): only the DoubleConvs whose second conv has <= 32 output
+# channels (the 4-wave kernel's layers, where the LDS-DMA tile kernel is not offered anyway) fold the first BatchNorm+ReLU into it
+_FUSE_BN_NARROW = os.environ.get("EGM_FUSE_BN_NARROW", "0") != "0"
+
+
+def fuse_bn_narrow():
+    return _FUSE_BN_NARROW
+
+
 def fuse_bn(enabled=None):
     """Get / set whether BatchNorm(+activation) is folded into consuming convolutions (Lazy tensors).  Both settings compute the same
     arithmetic; the materialised form (False) exists for A/B timing and for the bit-exactness test."""
@@ -1503,7 +1512,7 @@ def conv_bn_act(x, conv, bn, act, dil=1, groups=1, out=None, lazy=False):
         bn.num_batches_tracked.add_(1)                  # bookkeeping counter (int64), as nn.BatchNorm2d does
     training = bn.training or bn.running_mean is None
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    if not _FUSE_BN:
+    if not _FUSE_BN and not (_FUSE_BN_NARROW and isinstance(x, Lazy) and conv.weight.shape[0] <= 32):
         x = materialize(x)
     xt, xc, xa = _unlazy(x)
     y, coef = _ConvBN.apply(xt, xc, xa, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, act,

@@ -31,7 +31,8 @@ class DoubleConv(nn.Sequential):
         convolution).  The first BatchNorm+ReLU is never a pass: the second conv applies it while staging its input.
         pool=True: -> (result, maxpool2(result)), the skip tensor and the next level's input from ONE BatchNorm apply pass (or from
         the separate pool kernel when the fused form does not apply: odd sizes, switch off)."""
-        x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU, lazy=True)
+        narrow = ops.fuse_bn_narrow() and not pool and self[3].out_channels <= 32
+        x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU, lazy="force" if narrow else True)
         if pool:
             if ops.pool_fusable(x):
                 return ops.conv_bn_act_pool(x, self[3], self[4], ACT_RELU, out=out)

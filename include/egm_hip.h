@@ -294,6 +294,20 @@ int egm_pw_bwd_reduce(int dtype, const egm_pw_head* heads, int n, egm_stream_t s
 int egm_pw_bwd_coefs(int dtype, const egm_pw_head* heads, int n, egm_stream_t s);
 int egm_pw_bwd_apply(int dtype, const egm_pw_head* heads, int n, egm_stream_t s);
 
+/* Backward of a 1x1 convolution (groups 1) in ONE pass over dy and x (csrc/pw_bn.hip): dx = dy . W (data gradient, may be NULL) and
+ * the weight-gradient slabs [egm_conv1x1_bwd_slabs(npix)][CoutP][CinP] fp32, laid out like egm_conv_wgrad's workspace (taps = 1) so that
+ * egm_wgrad_reduce_multi / egm_conv_wgrad's own reduction sum them.  wd = egm_conv_pack's wd [CinP][CoutP] in `dtype`; Cin, Cout are the
+ * PADDED channel counts (<= 128).  Replaces the egm_conv_fwd(dy, wd) + egm_conv_wgrad pair of BasicConv(k = 1) and friends
+ * (src/EGM-UNet.py:958-975, 1210-1218).  Up to 4 convolutions per call (one launch). */
+typedef struct egm_conv1x1_bwd_desc {
+    const void* x;  const void* dy;  const void* wd;  void* dx;  float* slabs;
+    long long npix;
+    int ldx, lddy, lddx, Cin, Cout, pad_;
+} egm_conv1x1_bwd_desc;
+int egm_conv1x1_bwd_supported(int dtype, int Cin, int Cout);
+int egm_conv1x1_bwd_slabs(long long npix);
+int egm_conv1x1_bwd(int dtype, const egm_conv1x1_bwd_desc* descs, int n, egm_stream_t s);
+
 /* ---- pooling / resampling --------------------------------------------------------------------- */
 /* nn.MaxPool2d(2,2) (src/EGM-UNet.py:908); H, W are the INPUT sizes (even). */
 int egm_maxpool2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, egm_stream_t s);
