@@ -510,7 +510,86 @@ def _conv_forward(x, ldx, x_coef, x_act, weight, bias, dil, groups, want_stats):
     return y, stats, wd
 
 
-def _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, dy_pre, dy_out, weight, dil, groups, Cin, Cout):
+def _wgrad_deferrable(weight):
+    """True when the slab reduction of this weight's gradient may be left to the ONE multi-conv launch at the end of backward: a leaf
+    parameter whose only gradient contribution this is (not when a tensor hook may replace the returned buffer, nor under create_graph:
+    both hand autograd something it copies).  Consumes the conv-use note of the weight: call once per backward of a conv."""
+    return (_DEFER_WGRAD and _sole_conv_use(weight) and weight.is_leaf and weight.grad is None
+            and not weight._backward_hooks and not torch.is_grad_enabled())
+
+
+def _queue_wgrad(ws, weight, nslab, taps, CoutP, CinP, Cout, Cin, groups, gw):
+    run = torch._C._current_graph_task_id()
+    if run != _wgrad_run[0]:              # per engine run (an aborted backward never ran its callback: its entries are dead)
+        _pending_wgrad.clear()
+        Variable._execution_engine.queue_callback(_flush_wgrads)
+        _wgrad_run[0] = run
+    _pending_wgrad.append((ws, weight, nslab, taps, CoutP, CinP, Cout, Cin, groups, weakref.ref(gw), gw.data_ptr()))
+
+
+# ---- 1x1 convolutions: data gradient + weight-gradient slabs in ONE pass over dy and x (csrc/pw_bn.hip, egm_conv1x1_bwd) -----------
+_FUSE_C1 = os.environ.get("EGM_CONV1X1_BWD", "1") != "0"
+_C1_DESC = struct.Struct("<5Qq6i")
+_C1_MAXC = int(os.environ.get("EGM_CONV1X1_BWD_MAXC", "64"))
+
+
+def fuse_c1(enabled=None):
+    """Get / set whether the backward of a 1x1 conv runs as one fused launch (dx + weight-gradient slabs) where that applies."""
+    global _FUSE_C1
+    if enabled is not None:
+        _FUSE_C1 = bool(enabled)
+    return _FUSE_C1
+
+
+def _c1_shape_ok(x, gy, weight, dil, groups):
+    # measured (profiles/r04_*): <= 64 channels on both sides 32-43 us against 60 us for the pair at 8 x 256^2 x 64; at 128 channels the
+    # fused kernel needs one workgroup per CU and two column blocks and LOSES (73 us against 43 us), so those keep the pair
+    return (_FUSE_C1 and weight.shape[2] == 1 and weight.shape[3] == 1 and groups == 1 and x.shape[3] <= _C1_MAXC and gy.shape[3] <= _C1_MAXC
+            and bool(lib().cdll.egm_conv1x1_bwd_supported(dtype_code(x.dtype), x.shape[3], gy.shape[3])))
+
+
+def _conv1x1_bwd(items):
+    """items: up to 4 tuples (x, ldx, dy, lddy, weight, wd, need_gx) of 1x1 convs whose weight gradients are deferrable -> [(gx, gw)].
+    ONE launch writes every dx and every slab set; the slabs join the deferred multi-conv reduction like _conv_wgrad's."""
+    L, st = lib(), stream()
+    descs, res, keep = [], [], []
+    dt = dtype_code(items[0][0].dtype)
+    for x, ldx, dy, lddy, weight, wd, need_gx in items:
+        N, H, W, CinP = x.shape
+        CoutP, npix = dy.shape[3], _npix(x)
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        nslab = L.query("egm_conv1x1_bwd_slabs", npix)
+        ws = torch.empty(nslab * CoutP * CinP + 4, dtype=torch.float32, device=x.device)
+        gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=x.device) if need_gx else None
+        gw = torch.empty_like(weight)
+        descs.append(_C1_DESC.pack(x.data_ptr(), dy.data_ptr(), wd.data_ptr(), 0 if gx is None else gx.data_ptr(), ws.data_ptr(), npix, ldx, lddy,
+                                   CinP, CinP, CoutP, 0))
+        _queue_wgrad(ws, weight, nslab, 1, CoutP, CinP, Cout, Cin, 1, gw)
+        res.append((gx, gw))
+        keep.append(ws)
+    L.call("egm_conv1x1_bwd", dt, b"".join(descs), len(descs), st)
+    return res
+
+
+def _conv_grads(x, ldx, x_coef, x_act, dy, weight, wd, dil, groups, Cin, Cout, need_gx, need_gw, x_split=0):
+    """(data gradient, weight gradient) of a conv from a materialised dy [N, H, W, CoutP] (contiguous): one fused launch for a 1x1 conv
+    whose weight gradient is deferrable, the weight-gradient slab kernel followed by the data-gradient conv otherwise."""
+    N, H, W, CinP = x.shape
+    CoutP = dy.shape[3]
+    defer = None
+    if need_gw and x_coef is None and not x_split and _c1_shape_ok(x, dy, weight, dil, groups):
+        defer = _wgrad_deferrable(weight)
+        if defer:
+            return _conv1x1_bwd([(x, ldx, dy, CoutP, weight, wd, need_gx)])[0]
+    gx = gw = None
+    if need_gw:
+        gw = _conv_wgrad(x, ldx, x_coef, x_act, dy, CoutP, None, None, weight, dil, groups, Cin, Cout, defer=defer)
+    if need_gx:
+        gx = _conv_dgrad(dy, wd, N, H, W, CoutP, CinP, weight.shape[2], weight.shape[3], dil, x_split)
+    return gx, gw
+
+
+def _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, dy_pre, dy_out, weight, dil, groups, Cin, Cout, defer=None):
     """Weight gradient of one conv (operands may be logical, see egm_conv_wgrad_pre); deferred slab reduction when that is safe.
     dy_pre: None or (act, cf4 [4, CoutP], y, ldy) = the BatchNorm backward computed while staging; dy_out: tensor that receives the
     logical dy as a by-product (or None)."""
@@ -521,10 +600,8 @@ def _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, dy_pre, dy_out, weight, dil, gro
     gw = torch.empty_like(weight)
     nbytes = L.query("egm_conv_wgrad_workspace", N, H, W, CinP, CoutP, KH, KW)
     ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=x.device)
-    # leaf parameter whose only gradient contribution this is: defer the slab reduction to one multi-conv launch
-    # (not when a tensor hook may replace the returned buffer, nor under create_graph: both hand autograd something it copies)
-    defer = (_DEFER_WGRAD and _sole_conv_use(weight) and weight.is_leaf and weight.grad is None
-             and not weight._backward_hooks and not torch.is_grad_enabled())
+    if defer is None:                     # (a caller that asked already -- _wgrad_deferrable consumes the use note -- passes the answer)
+        defer = _wgrad_deferrable(weight)
     xm = PRE_BN_ACT if x_coef is not None else PRE_NONE
     if dy_pre is None:
         dm, dact, dcf, daux, dld = PRE_NONE, 0, None, None, 0
@@ -535,12 +612,7 @@ def _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, dy_pre, dy_out, weight, dil, gro
            KH, KW, dil, groups, 0, st)
     if defer:
         nslab = L.query("egm_conv_wgrad_slabs_pre", dt, 1 if (xm != PRE_NONE or dm != PRE_NONE) else 0, N, H, W, CinP, CoutP, KH, KW, dil)
-        run = torch._C._current_graph_task_id()
-        if run != _wgrad_run[0]:              # per engine run (an aborted backward never ran its callback: its entries are dead)
-            _pending_wgrad.clear()
-            Variable._execution_engine.queue_callback(_flush_wgrads)
-            _wgrad_run[0] = run
-        _pending_wgrad.append((ws, weight, nslab, KH * KW, CoutP, CinP, Cout, Cin, groups, weakref.ref(gw), gw.data_ptr()))
+        _queue_wgrad(ws, weight, nslab, KH * KW, CoutP, CinP, Cout, Cin, groups, gw)
     return gw
 
 
@@ -626,6 +698,15 @@ class _Conv2d(Function):
         KH, KW = weight.shape[2], weight.shape[3]
         L, dt, st = lib(), dtype_code(x.dtype), stream()
         gx = gw = gb = None
+        if (ctx.needs_input_grad[3] and x_coef is None and not (ctx.needs_input_grad[0] and ctx.defer_dgrad and _FUSE_DZ)
+                and _c1_shape_ok(x, gy, weight, dil, groups)):
+            defer = _wgrad_deferrable(weight)
+            if defer:
+                gx, gw = _conv1x1_bwd([(x, ldx, gy, ldg, weight, wd, ctx.needs_input_grad[0])])[0]
+                if has_bias and ctx.needs_input_grad[4]:
+                    gb = _zero_grad_vec(Cout, x.device) if ctx.bias_grad_zero else _channel_sum(gy)[0, :Cout]
+                return gx, None, None, gw, gb, None, None, None, None, None
+            gw = _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, None, None, weight, dil, groups, Cin, Cout, defer=False)
         if ctx.needs_input_grad[0]:
             gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=x.device)
             if ctx.defer_dgrad and _FUSE_DZ:
@@ -633,7 +714,7 @@ class _Conv2d(Function):
                 _defer_dz(gx, ("cls", gy, ldg, weight.detach(), Cout, Cin))
             else:
                 L.call("egm_conv_fwd", dt, ptr(gy), ldg, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
-        if ctx.needs_input_grad[3]:
+        if ctx.needs_input_grad[3] and gw is None:
             gw = _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, None, None, weight, dil, groups, Cin, Cout)
         if has_bias and ctx.needs_input_grad[4]:
             gb = _zero_grad_vec(Cout, x.device) if ctx.bias_grad_zero else _channel_sum(gy)[0, :Cout]
@@ -803,10 +884,7 @@ class _ConvBN(Function):
             L.call("egm_bn_bwd_coefs", ptr(part), nb, npix, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), train, ptr(sums), ptr(cf4), CoutP, st)
             L.call(head[0] + "_bwd_apply", *head[1], ptr(y), ldy, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), act, train, ptr(sums),
                    ptr(dy), CoutP, *head[2], st)
-            if need_gw:
-                gw = _conv_wgrad(x, ldx, x_coef, x_act, dy, CoutP, None, None, weight, dil, groups, Cin, Cout)
-            if need_gx:
-                gx = _conv_dgrad(dy, wd, N, H, W, CoutP, CinP, KH, KW, dil, ctx.x_split)
+            gx, gw = _conv_grads(x, ldx, x_coef, x_act, dy, weight, wd, dil, groups, Cin, Cout, need_gx, need_gw, ctx.x_split)
             if has_bias and ctx.needs_input_grad[4]:
                 gb = _bn_conv_bias_grad(Cout, dy, training, dev)
             ggamma = sums[1, :Cout] if ctx.needs_input_grad[5] else None
@@ -826,8 +904,8 @@ class _ConvBN(Function):
                 dy = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev)
             L.call("egm_bn_act_bwd_apply", dt, ptr(gz), ldg, ptr(y), ldy, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), act,
                    1 if training else 0, ptr(sums), ptr(dy), CoutP, npix, CoutP, st)
-            if need_gw:
-                gw = _conv_wgrad(x, ldx, x_coef, x_act, dy, CoutP, None, None, weight, dil, groups, Cin, Cout)
+            gx, gw = _conv_grads(x, ldx, x_coef, x_act, dy, weight, wd, dil, groups, Cin, Cout, need_gx, need_gw, ctx.x_split)
+            need_gx = False
         if need_gx:
             gx = _conv_dgrad(dy, wd, N, H, W, CoutP, CinP, KH, KW, dil, ctx.x_split)
         if has_bias and ctx.needs_input_grad[4]:
@@ -1124,22 +1202,38 @@ class _MultiConvBN(Function):
         L.call("egm_bn_multi", dt, _BN_BWD_COEFS, d_coef, K, st)
         L.call("egm_bn_multi", dt, _BN_BWD_APPLY, d_app, K, st)
         grads = [None]
-        gxs = [None] * K
-        with conv_group():                                    # the K data gradients: one launch per kernel instantiation
+        gxs, gws = [None] * K, [None] * K
+        # the 1x1 members (deferrable weight gradients): data gradient + weight-gradient slabs of all of them in ONE fused launch
+        fused, defer_of = [], {}
+        for k in range(K):
+            x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP = per[k][:12]
+            dil, groups = ctx.meta[k][0], ctx.meta[k][1]
+            if ctx.needs_input_grad[1 + 5 * k + 1] and _c1_shape_ok(x, dy, weight, dil, groups):
+                defer_of[k] = _wgrad_deferrable(weight)
+                if defer_of[k]:
+                    fused.append(k)
+        if fused:
+            res = _conv1x1_bwd([(per[k][0], per[k][1], per[k][5], per[k][11], per[k][2], per[k][3], ctx.needs_input_grad[1 + 5 * k]) for k in fused])
+            for k, (gx_k, gw_k) in zip(fused, res):
+                gxs[k], gws[k] = gx_k, gw_k
+        with conv_group():                                    # the other data gradients: one launch per kernel instantiation
             for k in range(K):
+                if k in fused:
+                    continue
                 x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP = per[k][:12]
                 dil = ctx.meta[k][0]
                 KH, KW = weight.shape[2], weight.shape[3]
                 if ctx.needs_input_grad[1 + 5 * k]:
                     gxs[k] = torch.empty((N, H, W, CinP), dtype=x.dtype, device=x.device)
                     L.call("egm_conv_fwd", dt, ptr(dy), CoutP, ptr(wd), None, 0, ptr(gxs[k]), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
-        gws = [None] * K
-        with conv_group():                                    # ... and the K weight gradients (slab kernels)
+        with conv_group():                                    # ... and their weight gradients (slab kernels)
             for k in range(K):
+                if k in fused:
+                    continue
                 x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP = per[k][:12]
                 dil, groups, has_bias, Cin, Cout, act, training = ctx.meta[k]
                 if ctx.needs_input_grad[1 + 5 * k + 1]:
-                    gws[k] = _conv_wgrad(x, ldx, None, ACT_NONE, dy, CoutP, None, None, weight, dil, groups, Cin, Cout)
+                    gws[k] = _conv_wgrad(x, ldx, None, ACT_NONE, dy, CoutP, None, None, weight, dil, groups, Cin, Cout, defer=defer_of.get(k))
         for k in range(K):
             x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP = per[k][:12]
             dil, groups, has_bias, Cin, Cout, act, training = ctx.meta[k]
@@ -1245,12 +1339,8 @@ class _ConvBNEw(Function):
         dp = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev)
         L.call("egm_bn_ew_bwd_apply", dt, mode, ptr(g), ldg, ptr(q), ldq, ptr(y), CoutP, ptr(cf4), act, alpha, ptr(dy), CoutP, ptr(dp),
                CoutP, npix, CoutP, st)
-        gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=dev)
-            L.call("egm_conv_fwd", dt, ptr(dy), CoutP, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, 1, st)
-        if ctx.needs_input_grad[2]:
-            gw = _conv_wgrad(x, ldx, None, ACT_NONE, dy, CoutP, None, None, weight, 1, 1, Cin, Cout)
+        gb = None
+        gx, gw = _conv_grads(x, ldx, None, ACT_NONE, dy, weight, wd, 1, 1, Cin, Cout, ctx.needs_input_grad[0], ctx.needs_input_grad[2])
         if has_bias and ctx.needs_input_grad[3]:
             gb = _bn_conv_bias_grad(Cout, dy, training, dev)
         ggamma = sums[1, :Cout] if ctx.needs_input_grad[4] else None

@@ -206,3 +206,47 @@ def test_whole_model_with_the_moment_form_matches_the_reference_fixture():
                 rels.append((float((params[k[5:]].grad.cpu().double() - ref).norm() / ref.norm()), k))
     rels.sort(reverse=True)
     assert rels[0][0] < 2e-2 and rels[len(rels) // 2][0] < 2e-3, (rels[:4], rels[len(rels) // 2])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 9, 7, 64, 64), (2, 8, 8, 8, 8), (1, 10, 10, 16, 40), (2, 6, 10, 128, 128), (2, 16, 16, 128, 32),
+                                   (2, 16, 16, 32, 128), (1, 33, 31, 24, 3), (4, 32, 32, 64, 16)])
+def test_fused_1x1_backward_matches_the_two_kernel_backward_and_torch(shape, dtype):
+    """egm_conv1x1_bwd (dx and the weight-gradient slabs from one pass over dy and x) against the data-gradient conv + weight-gradient
+    slab kernel pair it replaces, and against torch: dx and dW to fp32 summation-order noise (bf16: equal after rounding up to rare last-bit flips)."""
+    from egm_unet_amd import ops
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = torch.randn(N, H, W, ops.pad8(Cin), generator=g).to(dtype)
+    x[..., Cin:] = 0
+    go = torch.randn(N, H, W, ops.pad8(Cout), generator=g).to(dtype)
+    go[..., Cout:] = 0
+    w0 = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b0 = torch.randn(Cout, generator=g)
+    default, maxc = ops.fuse_c1(), ops._C1_MAXC
+    res = []
+    try:
+        ops._C1_MAXC = 128                     # the kernel's own limit (the product offers it up to 64 channels, where it wins)
+        for on in (True, False):
+            ops.fuse_c1(on)
+            w, b = nn.Parameter(w0.clone().to(DEV)), nn.Parameter(b0.clone().to(DEV))
+            xi = x.to(DEV).requires_grad_(True)
+            ops.conv2d(xi, w, b).backward(go.to(DEV))
+            torch.cuda.synchronize()
+            res.append((xi.grad.clone(), w.grad.clone(), b.grad.clone()))
+    finally:
+        ops.fuse_c1(default); ops._C1_MAXC = maxc
+    if dtype == torch.float32:                 # the fp32 MFMA forms walk k in another order: summation-order noise
+        assert _rel(res[0][0], res[1][0]) < 1e-6
+    else:                                      # same bf16 products, fp32 accumulation in another order: equal after rounding up to rare last-bit flips
+        ndiff = int((res[0][0] != res[1][0]).sum())
+        assert ndiff <= 2e-3 * res[0][0].numel() and _rel(res[0][0], res[1][0]) < 1e-3, ndiff
+    assert torch.equal(res[0][2], res[1][2])
+    assert _rel(res[0][1], res[1][1]) < 2e-6
+    # torch, on the storage-rounded operands
+    xr = x[..., :Cin].double().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w0.to(dtype).double().requires_grad_(True)
+    F.conv2d(xr, wr, b0.double()).backward(go[..., :Cout].double().permute(0, 3, 1, 2))
+    f32 = dtype == torch.float32
+    assert _rel(res[0][0][..., :Cin].permute(0, 3, 1, 2), xr.grad) < (1e-5 if f32 else 6e-3)
+    assert _rel(res[0][1], wr.grad) < (1e-5 if f32 else 1e-5 + 2e-3 * 0)      # products of storage-rounded operands, fp32 accumulation
