@@ -59,20 +59,11 @@ class KernelTimer:
 
     REPS = 4          # conv launches are re-issued back to back so the event pair brackets kernel time, not launch gaps
 
-    @staticmethod
-    def _canon(name, args):
-        """The *_pre entry points (operand prologues) recorded under the plain names with the plain argument layout."""
-        if name == "egm_conv_fwd_pre":          # (dtype, x, ldx, [pre_mode, pre_act, pre_cf, pre_aux, pre_ld_aux], wf, bias, ...)
-            return "egm_conv_fwd", args[:3] + args[8:]
-        if name == "egm_conv_wgrad_pre":        # (dtype, x, ldx, [3 x-prologue], dy, lddy, [5 dy-prologue, dy_out, ld_dy_out], dw, ws, N, ...)
-            return "egm_conv_wgrad", args[:3] + args[6:8] + args[15:]
-        return name, args
-
     def __enter__(self):
         def timed(name, *args):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = 1
-            if name in ("egm_conv_fwd", "egm_conv_wgrad", "egm_conv_fwd_pre", "egm_conv_wgrad_pre"):
+            if name in ("egm_conv_fwd", "egm_conv_wgrad"):
                 # idempotent (same inputs, outputs overwritten with the same values): the first call does the work of the step,
                 # REPS more are timed as a train, which matches the per-launch durations rocprofv3 reports for the graph replay
                 self._orig(name, *args)
@@ -81,9 +72,8 @@ class KernelTimer:
             for _ in range(reps):
                 self._orig(name, *args)
             e1.record()
-            cname, cargs = self._canon(name, args)
             from egm_unet_amd import ops as _o
-            self.records.append((cname, cargs, _Span(e0, e1, reps), None))
+            self.records.append((name, args, _Span(e0, e1, reps), None))
             self.grouped.append(_o.conv_group.serial if _o.conv_group.depth > 0 else 0)      # which launch group the call sits in (0 = none)
         self.lib.call = timed
         return self
@@ -147,11 +137,12 @@ class KernelTimer:
         """The kernel a conv call takes, spelled as in a rocprofv3 kernel trace (egm_conv_kernel_name / egm_conv_wgrad_kernel_name), so
         that the per-launch averages below sit beside the matching rows of profiles/*_kernel_trace_summary.md."""
         buf = ctypes.create_string_buffer(96)
-        getattr(self.lib.cdll, entry)(dtype, 0, N, H, W, Cin, Cout, KH, KW, dil, ctypes.cast(buf, ctypes.c_void_p), 96)
+        getattr(self.lib.cdll, entry)(dtype, N, H, W, Cin, Cout, KH, KW, dil, ctypes.cast(buf, ctypes.c_void_p), 96)
         return buf.value.decode()
 
     FAMILIES = (("conv fwd/dgrad", ("egm_conv_fwd", "egm_conv_fwd_split", "egm_group_end")),
                 ("weight gradients", ("egm_conv_wgrad", "egm_wgrad_reduce", "egm_sa_conv7_bwd_w", "egm_dwconv3_bwd_w")),
+                ("1x1 backward, dx + dW in one pass", ("egm_conv1x1_bwd",)),
                 ("pointwise conv+BatchNorm (moment form)", ("egm_pw_",)),
                 ("BatchNorm", ("egm_bn_", "egm_channel_sums", "egm_reduce_tiles")),
                 ("MCALayer", ("egm_mca_",)))

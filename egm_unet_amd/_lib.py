@@ -17,7 +17,6 @@ LIB_PATH = os.path.join(_HERE, "lib", "libegm_hip%s.so" % ("_" + os.environ["EGM
 
 EGM_F32, EGM_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU = 0, 1, 2, 3
-PRE_NONE, PRE_BN_ACT, PRE_BN_BWD = 0, 1, 2            # enum egm_prologue
 
 _CTYPES = {
     "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "long long": ctypes.c_longlong,

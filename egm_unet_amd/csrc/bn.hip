@@ -3,7 +3,7 @@
 // All of these are HBM-bound streaming kernels: 16-byte (bf16) / 32-byte (fp32) vectors of 8 channels per lane,
 // channel-contiguous so a wave reads whole pixels; reductions are two-stage with plain stores (deterministic).
 #include "common.h"
-#include "prologue.h"
+#include "bn_elem.h"
 
 namespace {
 
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 }
 
 // BatchNorm backward, second stage: partial tiles [ntiles][2][C] of (sum dzp, sum dzp*xhat) -> sums [2][C] (= dbeta | dgamma) and the
-// coefficient rows cf [4][C] = scale | shift | cb | cc of EGM_PRE_BN_BWD (prologue.h), so that neither a reduce_tiles launch nor a
-// stand-alone apply pass is needed: the data-gradient and weight-gradient kernels of the conv in front compute dy while staging.
+// coefficient rows cf [4][C] = scale | shift | cb | cc with dy = scale*dzp + cb + cc*y (bn_elem.h): one launch instead of a reduce_tiles
+// launch plus per-element mean arithmetic in the apply passes that follow.
 __device__ __forceinline__ void bn_bwd_coefs_body(const float* __restrict__ st, int ntiles, float inv_count,
                                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                                   const float* __restrict__ mean, const float* __restrict__ rstd, int train,

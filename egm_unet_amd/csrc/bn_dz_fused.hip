@@ -8,9 +8,9 @@
 //           (A + B*x) summed over the three axes (the layer's last backward kernel, egm_mca_bwd_dx), x being this BatchNorm's own output.
 // Both passes of the BatchNorm backward (partial sums; dy = scale*dzp + cb + cc*y) evaluate that expression per 8-channel vector, with
 // the rounding to the storage type the separate kernel applied when it stored dz, so the producer kernel, its tensor write and two
-// tensor reads disappear.  Same partial-sum geometry as bn.hip (egm_channel_partials_blocks), same element formulas (prologue.h).
+// tensor reads disappear.  Same partial-sum geometry as bn.hip (egm_channel_partials_blocks), same element formulas (bn_elem.h).
 #include "common.h"
-#include "prologue.h"
+#include "bn_elem.h"
 
 namespace {
 

@@ -12,7 +12,7 @@
 // All three are HBM-bound streaming kernels with VALU slack; every rounding point of the unfused chain is kept (z and dz are rounded
 // to the storage type in registers before they are used), so fused and unfused results agree bit for bit.
 #include "common.h"
-#include "prologue.h"
+#include "bn_elem.h"
 
 namespace {
 

@@ -13,7 +13,6 @@
 // HBM-bound for the narrow layers (C <= 64), MFMA-bound for 256 -> 256; algorithmic work as for conv_igemm.hip.
 #include <type_traits>
 #include "common.h"
-#include "prologue.h"
 #include "group.h"
 #include <string.h>
 #include <stdlib.h>
@@ -27,16 +26,12 @@ struct DirectParams {
     const void* x; const void* w; const float* bias; void* y; float* stats;
     int ldx, ldy, N, H, W, Cin, Cout, KH, KW, dil, bias_n;
     int nblk, nct, G, wrow;      // 32-pixel blocks, cout tiles, pixel groups (workgroups per cout tile), LDS weight row bytes
-    PreArgs pre;                 // operand prologue (prologue.h)
 };
 
 __device__ __forceinline__ bf16x8_t as_frag(uint4 v) { return __builtin_bit_cast(bf16x8_t, v); }
 
-// PRE (EGM_PRE_NONE / EGM_PRE_BN_ACT, prologue.h): the loaded channel vectors are transformed in registers on their way into the
-// MFMA operand (BatchNorm apply + activation of the producing layer); the coefficient rows sit in LDS behind the out tiles; taps
-// that fall outside the image stay exactly zero.
 // K1: the 1x1 instantiation (no tap groups: its register count, and with it the occupancy the streaming layers live on, stays low)
-template <int NT, int PRE, bool K1>
+template <int NT, bool K1>
 __device__ __forceinline__ void conv_direct_body(const DirectParams& p, const int b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int OROW = NT * 64 + 16, NV = NT * 4;
@@ -52,16 +47,6 @@ __device__ __forceinline__ void conv_direct_body(const DirectParams& p, const in
     const int ntaps = p.KH * p.KW, nks = (p.Cin + 15) >> 4, cvecs = p.Cin >> 3;
     unsigned char* wts = smem;                                               // [ntaps][NT*32][wrow]
     unsigned char* ot = smem + (size_t)ntaps * NT * 32 * p.wrow + wv * 32 * OROW;   // wave-private out tile
-    static_assert(PRE == EGM_PRE_NONE || PRE == EGM_PRE_BN_ACT, "direct conv: prologue must be NONE or BN_ACT");
-    float* cfl = reinterpret_cast<float*>(smem + (size_t)ntaps * NT * 32 * p.wrow + 4 * 32 * OROW);   // [2][nks*16] coefficient rows
-    const int cs = nks * 16;
-    if (PRE != EGM_PRE_NONE) {
-        for (int i = tid; i < 2 * cs; i += 256) {
-            const int r = i / cs, c = i - r * cs;
-            cfl[i] = c < p.Cin ? p.pre.cf[r * p.pre.C + c] : 0.f;
-        }
-    }
-
     // ---- weights of this cout tile: staged once, zero rows past Cout, zero tail past Cin (the k-loop runs in steps of 16)
     {
         // eight loads in flight per lane: one at a time, the 18 round trips of a 64 -> 64 dilated conv's 73 KB slab were a flat
@@ -149,18 +134,6 @@ __device__ __forceinline__ void conv_direct_body(const DirectParams& p, const in
                             fb[u][k] = make_uint4(0, 0, 0, 0);
                             if (ok && k0 + k < nks && (k0 + k) * 16 + h * 8 < p.Cin) fb[u][k] = *reinterpret_cast<const uint4*>(src + (k0 + k) * 16);
                         }
-                        if (PRE != EGM_PRE_NONE) {
-                            EGM_ACT_SWITCH(p.pre.act,
-                                _Pragma("unroll")
-                                for (int k = 0; k < KS; ++k) {
-                                    if (k0 + k < nks) {
-                                        PreCoef8 kf;
-                                        pre_load_coef8<PRE>(kf, cfl + (k0 + k) * 16 + h * 8, cs);
-                                        const uint4 v = pre_apply8<PRE, ACT>(fb[u][k], fb[u][k], kf, p.pre.act);
-                                        fb[u][k] = ok ? v : make_uint4(0, 0, 0, 0);
-                                    }
-                                });
-                        }
                     }
 #pragma unroll
                     for (int u = 0; u < TG; ++u) {
@@ -180,15 +153,11 @@ __device__ __forceinline__ void conv_direct_body(const DirectParams& p, const in
                 }
             }
         };
-        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
         using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>; using I8 = std::integral_constant<int, 8>;
         using I9 = std::integral_constant<int, 9>;
         if constexpr (K1) run_taps(I1(), I8());
-        else if (PRE != EGM_PRE_NONE) {                     // the transform's temporaries leave room for fewer loads in flight
-            if (nks > 4) run_taps(I1(), I8());
-            else if (nks <= 2) run_taps(I3(), I2());
-            else run_taps(I2(), I4());
-        } else if (nks <= 2) run_taps(I9(), I2());          // 18 loads in flight
+        else if (nks <= 2) run_taps(I9(), I2());            // 18 loads in flight
         else if (nks <= 4) run_taps(I5(), I4());            // 20
         else run_taps(I2(), I8());                          // 16
 
@@ -248,9 +217,9 @@ __device__ __forceinline__ void conv_direct_body(const DirectParams& p, const in
     }
 }
 
-template <int NT, int PRE, bool K1>
+template <int NT, bool K1>
 __global__ __launch_bounds__(256) void conv_direct_kernel(DirectParams p) {
-    conv_direct_body<NT, PRE, K1>(p, blockIdx.x);
+    conv_direct_body<NT, K1>(p, blockIdx.x);
 }
 // merged launch of up to EGM_GROUP_MAX independent convolutions (group.h): member i owns blocks [blk0[i], blk0[i+1])
 struct DirectMulti { DirectParams p[EGM_GROUP_MAX]; int blk0[EGM_GROUP_MAX + 1]; int n; };
@@ -258,7 +227,7 @@ template <int NT, bool K1>
 __global__ __launch_bounds__(256) void conv_direct_multi_kernel(DirectMulti m) {
     int i = 0;
     while (i + 1 < m.n && (int)blockIdx.x >= m.blk0[i + 1]) ++i;
-    conv_direct_body<NT, EGM_PRE_NONE, K1>(m.p[i], (int)blockIdx.x - m.blk0[i]);
+    conv_direct_body<NT, K1>(m.p[i], (int)blockIdx.x - m.blk0[i]);
 }
 
 template <int NT, bool K1>
@@ -266,7 +235,7 @@ int launch_direct_group(const EgmGroupRec* recs, int n, hipStream_t st) {
     if (n == 1) {
         DirectParams first;
         memcpy(&first, recs[0].params, sizeof(DirectParams));
-        hipLaunchKernelGGL((conv_direct_kernel<NT, EGM_PRE_NONE, K1>), dim3(recs[0].grid), dim3(256), recs[0].smem, st, first);
+        hipLaunchKernelGGL((conv_direct_kernel<NT, K1>), dim3(recs[0].grid), dim3(256), recs[0].smem, st, first);
         EGM_CHECK_LAUNCH("conv_direct");
         return EGM_OK;
     }
@@ -290,38 +259,33 @@ int launch_direct_group(const EgmGroupRec* recs, int n, hipStream_t st) {
     EGM_CHECK_LAUNCH("conv_direct_multi");
     return EGM_OK;
 }
-template <int NT, int PRE, bool K1>
-int launch_direct_pre(const DirectParams& p, size_t smem, hipStream_t st) {
+template <int NT, bool K1>
+int launch_direct_k(const DirectParams& p, size_t smem, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct_kernel<NT, PRE, K1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct_kernel<NT, K1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024);
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_direct: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    if (PRE != EGM_PRE_NONE) smem += (size_t)2 * ((p.Cin + 15) / 16 * 16) * sizeof(float);
     EGM_REQUIRE(smem <= 160 * 1024, "conv_direct: LDS budget exceeded (%zu)", smem);
     const int grid = ((p.G + 7) / 8) * 8 * p.nct;
-    if constexpr (PRE == EGM_PRE_NONE) {
-        if (egm_group_recording()) {                                   // launched by egm_group_end(), merged with its siblings
-            static_assert(sizeof(DirectParams) <= sizeof(EgmGroupRec::params), "group record too small");
-            EgmGroupRec r;
-            r.launch = &launch_direct_group<NT, K1>;
-            memcpy(r.params, &p, sizeof(DirectParams));
-            r.G = p.G; r.grid = grid; r.smem = smem;
-            egm_group_push(r);
-            return EGM_OK;
-        }
+    if (egm_group_recording()) {                                       // launched by egm_group_end(), merged with its siblings
+        static_assert(sizeof(DirectParams) <= sizeof(EgmGroupRec::params), "group record too small");
+        EgmGroupRec r;
+        r.launch = &launch_direct_group<NT, K1>;
+        memcpy(r.params, &p, sizeof(DirectParams));
+        r.G = p.G; r.grid = grid; r.smem = smem;
+        egm_group_push(r);
+        return EGM_OK;
     }
-    hipLaunchKernelGGL((conv_direct_kernel<NT, PRE, K1>), dim3(grid), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((conv_direct_kernel<NT, K1>), dim3(grid), dim3(256), smem, st, p);
     EGM_CHECK_LAUNCH("conv_direct");
     return EGM_OK;
 }
 template <int NT>
 int launch_direct(const DirectParams& p, size_t smem, hipStream_t st) {
-    if (p.pre.mode == EGM_PRE_BN_ACT) return p.KH == 1 ? launch_direct_pre<NT, EGM_PRE_BN_ACT, true>(p, smem, st) : launch_direct_pre<NT, EGM_PRE_BN_ACT, false>(p, smem, st);
-    if (p.pre.mode != EGM_PRE_NONE) EGM_FAIL(EGM_ERR_UNSUPPORTED, "conv_direct: prologue mode %d not built", p.pre.mode);
-    return p.KH == 1 ? launch_direct_pre<NT, EGM_PRE_NONE, true>(p, smem, st) : launch_direct_pre<NT, EGM_PRE_NONE, false>(p, smem, st);
+    return p.KH == 1 ? launch_direct_k<NT, true>(p, smem, st) : launch_direct_k<NT, false>(p, smem, st);
 }
 
 }  // namespace
@@ -360,11 +324,10 @@ int egm_conv_direct_plan(int dtype, int N, int H, int W, int Cin, int Cout, int 
     return 1;
 }
 
-int egm_conv_direct_launch(const void* x, int ldx, const PreArgs& pre, const void* wf, const float* bias, int bias_n, void* y, int ldy,
+int egm_conv_direct_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy,
                            float* stats, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int NT, int nct, int G, size_t smem,
                            egm_stream_t s) {
     DirectParams p;
-    p.pre = pre;
     p.x = x; p.w = wf; p.bias = bias; p.y = y; p.stats = stats;
     p.ldx = ldx; p.ldy = ldy; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.dil = (KH == 1) ? 1 : dil;
     p.bias_n = bias ? bias_n : 0;

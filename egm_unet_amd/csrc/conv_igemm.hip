@@ -23,7 +23,6 @@
 // bf16: v_mfma_f32_32x32x16_bf16 (A = pixels x k, B = k x couts, fp32 accumulate)
 // f32 : v_mfma_f32_32x32x2_f32   (exact fp32 FMA chain; the parity path)
 #include "common.h"
-#include "prologue.h"
 #include "group.h"
 #include <string.h>
 #include <stdio.h>
@@ -35,7 +34,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
 // conv_direct.hip: 1x1 / dilated convolutions without an LDS activation tile
 int egm_conv_direct_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int* NT_out, int* nct_out, int* G_out,
                          size_t* smem_out);
-int egm_conv_direct_launch(const void* x, int ldx, const PreArgs& pre, const void* wf, const float* bias, int bias_n, void* y, int ldy,
+int egm_conv_direct_launch(const void* x, int ldx, const void* wf, const float* bias, int bias_n, void* y, int ldy,
                            float* stats, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int NT, int nct, int G, size_t smem,
                            egm_stream_t s);
 
@@ -108,7 +107,6 @@ struct ConvParams {
     int wrows_per_stage;          // kernel rows whose weights are staged together (halo mode)
     int patch_bytes;
     WLayout wl;                   // weight image layout (common.h)
-    PreArgs pre;                  // prologue of the input operand (prologue.h); mode EGM_PRE_NONE = x is used as stored
 };
 
 template <typename T, int NT>
@@ -169,18 +167,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                 const bool ok = (iy >= 0) && (iy < p.H) && (ix >= 0) && (ix < p.W) && (c < p.Cin);
                 const long long pixoff = (long long)(n * p.H + iy) * p.W + ix;
                 const T* src = xg + pixoff * p.ldx + c;
-                if (p.pre.mode == EGM_PRE_NONE) {
-                    M::stage16(patch + pix * PS + v * 16, src, ok);
-                } else {
-                    // logical operand computed while staging (positions outside the image / beyond Cin stay exactly zero)
-                    uint4 val = make_uint4(0, 0, 0, 0);
-                    if (ok) {
-                        uint4 aux = make_uint4(0, 0, 0, 0);
-                        if (p.pre.mode == EGM_PRE_BN_BWD) aux = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.pre.aux) + pixoff * p.pre.ld_aux + c);
-                        val = pre_apply_rt<kActRuntime>(T(), *reinterpret_cast<const uint4*>(src), aux, p.pre.cf + c, p.pre.C, p.pre.mode, p.pre.act);
-                    }
-                    M::stage_val(patch + pix * PS + v * 16, val);
-                }
+                M::stage16(patch + pix * PS + v * 16, src, ok);
             }
             for (int wr0 = 0; wr0 < wh; wr0 += rows_per_stage) {
                 const int nrows = min(rows_per_stage, wh - wr0);
@@ -292,13 +279,9 @@ template <int WH, int WW, int R> struct PipeGeom {
     static constexpr int PVEC = (PH * PW * 4 + 255) / 256;                 // patch 16-byte vectors per thread
 };
 
-//   * PRE (EGM_PRE_NONE / EGM_PRE_BN_ACT, prologue.h): the staged patch vectors are transformed between their global load and their
-//     LDS write -- BatchNorm apply + activation of the producing layer -- so the producer's apply pass and its tensor never exist;
-//     the per-channel coefficient rows sit in LDS behind the weights.  (The BatchNorm-backward form is not built here: a data
-//     gradient reads the dy its weight-gradient kernel materialises as a by-product, conv_wgrad.hip.)
 // The kernel body; `b` = the workgroup's index within THIS convolution (blockIdx.x, or blockIdx.x minus the member's first block in a
 // merged launch, group.h).
-template <int NT, int WH, int WW, int R, int PRE>
+template <int NT, int WH, int WW, int R>
 __device__ __forceinline__ void conv_igemm_pipe_body(const ConvParams& p, const int G, const int b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using Gm = PipeGeom<WH, WW, R>;
@@ -352,17 +335,6 @@ __device__ __forceinline__ void conv_igemm_pipe_body(const ConvParams& p, const 
     const int w_step = TAPS_PER_K * p.Cout * p.Cin;
     const bool w_rows_full = co0 + NT * 32 <= p.Cout;                      // uniform: every weight row of this cout tile exists
     uint4 pre_p[PVEC], pre_w[WVEC];
-    // ---- operand prologue: coefficient rows cached in LDS (zero beyond Cin, so the zero weight columns of a ragged last chunk
-    // meet finite values)
-    static_assert(PRE == EGM_PRE_NONE || PRE == EGM_PRE_BN_ACT, "pipelined conv: prologue must be NONE or BN_ACT");
-    float* cfl = reinterpret_cast<float*>(wts + WROWS * PS + 64 * 16);
-    const int cin32 = (p.Cin + KC - 1) / KC * KC;
-    if (PRE != EGM_PRE_NONE) {
-        for (int i = tid; i < 2 * cin32; i += 256) {
-            const int r = i / cin32, c = i - r * cin32;
-            cfl[i] = c < p.Cin ? p.pre.cf[r * p.pre.C + c] : 0.f;        // visible after the main loop's first barrier
-        }
-    }
 
     // ---- stage iterator: (pixel tile, tap group, chunk) with wholly-out-of-image dilated groups skipped
     struct Stage { int pt, g, c0, n, oy0, ox0, offy, offx, tap0; bool valid, interior; };
@@ -452,23 +424,9 @@ __device__ __forceinline__ void conv_igemm_pipe_body(const ConvParams& p, const 
         }
     };
     auto write_lds = [&](bool with_weights, const Stage& st) {
-        if (PRE == EGM_PRE_NONE) {
 #pragma unroll
-            for (int k = 0; k < PVEC; ++k)
-                *reinterpret_cast<uint4*>((!kPatchTail || k < PVEC - 1 || p_tail_ok) ? patch + lds_off0 + k * 64 * PS : dump) = pre_p[k];
-        } else {
-            // the thread's channel vector is the same for all of its slots: one coefficient set per stage
-            PreCoef8 kf;
-            pre_load_coef8<PRE>(kf, cfl + st.c0 + (tid & 3) * 8, cin32);
-            const bool masked = !st.interior;                     // edge tile: padding positions must stay exactly zero
-            EGM_ACT_SWITCH(p.pre.act,
-                _Pragma("unroll")
-                for (int k = 0; k < PVEC; ++k) {
-                    uint4 v = pre_apply8<PRE, ACT>(pre_p[k], pre_p[k], kf, p.pre.act);
-                    if (masked && !pv_ok[k]) v = make_uint4(0, 0, 0, 0);
-                    *reinterpret_cast<uint4*>((!kPatchTail || k < PVEC - 1 || p_tail_ok) ? patch + lds_off0 + k * 64 * PS : dump) = v;
-                });
-        }
+        for (int k = 0; k < PVEC; ++k)
+            *reinterpret_cast<uint4*>((!kPatchTail || k < PVEC - 1 || p_tail_ok) ? patch + lds_off0 + k * 64 * PS : dump) = pre_p[k];
         if (with_weights) {
 #pragma unroll
             for (int k = 0; k < WVEC; ++k) {
@@ -634,9 +592,9 @@ __device__ __forceinline__ void conv_igemm_pipe_body(const ConvParams& p, const 
     }
 }
 
-template <int NT, int WH, int WW, int R, int PRE>
+template <int NT, int WH, int WW, int R>
 __global__ __launch_bounds__(256, (R * NT >= 8) ? 1 : 2) void conv_igemm_pipe_kernel(ConvParams p, int G) {
-    conv_igemm_pipe_body<NT, WH, WW, R, PRE>(p, G, blockIdx.x);
+    conv_igemm_pipe_body<NT, WH, WW, R>(p, G, blockIdx.x);
 }
 // merged launch of up to EGM_GROUP_MAX independent convolutions of one instantiation (group.h): member i owns blocks [blk0[i], blk0[i+1])
 struct PipeMulti { ConvParams p[EGM_GROUP_MAX]; int G[EGM_GROUP_MAX]; int blk0[EGM_GROUP_MAX + 1]; int n; };
@@ -644,7 +602,7 @@ template <int NT, int WH, int WW, int R>
 __global__ __launch_bounds__(256, (R * NT >= 8) ? 1 : 2) void conv_igemm_pipe_multi_kernel(PipeMulti m) {
     int i = 0;
     while (i + 1 < m.n && (int)blockIdx.x >= m.blk0[i + 1]) ++i;
-    conv_igemm_pipe_body<NT, WH, WW, R, EGM_PRE_NONE>(m.p[i], m.G[i], (int)blockIdx.x - m.blk0[i]);
+    conv_igemm_pipe_body<NT, WH, WW, R>(m.p[i], m.G[i], (int)blockIdx.x - m.blk0[i]);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -733,11 +691,6 @@ bool pipe_eligible(int dtype, int KH, int KW, int dil) {
     return dtype == EGM_BF16 && KH == KW && ((KH == 3 && dil == 1) || KH == 1 || (KH == 3 && dil > 1) || (KH == 7 && dil == 1));
 }
 
-// LDS bytes of the prologue's coefficient rows in the pipelined kernel
-size_t pipe_pre_bytes(int mode, int Cin) {
-    if (mode == EGM_PRE_NONE) return 0;
-    return (size_t)2 * ((Cin + KC - 1) / KC * KC) * sizeof(float);
-}
 template <int WH, int WW, int R> size_t pipe_base_bytes(int NT) {
     using Gm = PipeGeom<WH, WW, R>;
     return (size_t)((Gm::PH * Gm::PW * 80 + 15) / 16 * 16) + (size_t)Gm::NTAPS * NT * 32 * 80 + 64 * 16;
@@ -748,7 +701,7 @@ int launch_pipe_group(const EgmGroupRec* recs, int n, hipStream_t st) {
     ConvParams first;
     memcpy(&first, recs[0].params, sizeof(ConvParams));
     if (n == 1) {
-        hipLaunchKernelGGL((conv_igemm_pipe_kernel<NT, WH, WW, R, EGM_PRE_NONE>), dim3(recs[0].grid), dim3(256), recs[0].smem, st, first, recs[0].G);
+        hipLaunchKernelGGL((conv_igemm_pipe_kernel<NT, WH, WW, R>), dim3(recs[0].grid), dim3(256), recs[0].smem, st, first, recs[0].G);
         EGM_CHECK_LAUNCH("conv_igemm_pipe");
         return EGM_OK;
     }
@@ -773,68 +726,55 @@ int launch_pipe_group(const EgmGroupRec* recs, int n, hipStream_t st) {
     EGM_CHECK_LAUNCH("conv_igemm_pipe_multi");
     return EGM_OK;
 }
-template <int NT, int WH, int WW, int R, int PRE>
-int launch_pipe_pre(ConvParams& p, int G, hipStream_t st) {
+template <int NT, int WH, int WW, int R>
+int launch_pipe(ConvParams& p, int G, hipStream_t st) {
     using Gm = PipeGeom<WH, WW, R>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_pipe_kernel<NT, WH, WW, R, PRE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_pipe_kernel<NT, WH, WW, R>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_igemm_pipe: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     p.patch_bytes = (Gm::PH * Gm::PW * 80 + 15) / 16 * 16;
-    const size_t smem = pipe_base_bytes<WH, WW, R>(NT) + pipe_pre_bytes(PRE, p.Cin);      // patch | weights | per-lane dump slots | coefficients
+    const size_t smem = pipe_base_bytes<WH, WW, R>(NT);                                    // patch | weights | per-lane dump slots
     static_assert((size_t)4 * 32 * (NT * 64 + 16) <= (size_t)Gm::PH * Gm::PW * 80, "epilogue out tiles must fit inside the patch region");
     static_assert((size_t)Gm::PH * Gm::PW * 80 + 16 + (size_t)Gm::NTAPS * NT * 32 * 80 + 1024 <= 160 * 1024, "LDS budget");
     EGM_REQUIRE(smem <= 160 * 1024, "conv_igemm_pipe: LDS budget exceeded (%zu)", smem);
     const int grid = ((G + 7) / 8) * 8 * p.nct;
-    if constexpr (PRE == EGM_PRE_NONE) {
-        if (egm_group_recording()) {                                   // launched by egm_group_end(), merged with its siblings
-            static_assert(sizeof(ConvParams) <= sizeof(EgmGroupRec::params), "group record too small");
-            EgmGroupRec r;
-            r.launch = &launch_pipe_group<NT, WH, WW, R>;
-            memcpy(r.params, &p, sizeof(ConvParams));
-            r.G = G; r.grid = grid; r.smem = smem;
-            egm_group_push(r);
-            return EGM_OK;
-        }
+    if (egm_group_recording()) {                                       // launched by egm_group_end(), merged with its siblings
+        static_assert(sizeof(ConvParams) <= sizeof(EgmGroupRec::params), "group record too small");
+        EgmGroupRec r;
+        r.launch = &launch_pipe_group<NT, WH, WW, R>;
+        memcpy(r.params, &p, sizeof(ConvParams));
+        r.G = G; r.grid = grid; r.smem = smem;
+        egm_group_push(r);
+        return EGM_OK;
     }
-    hipLaunchKernelGGL((conv_igemm_pipe_kernel<NT, WH, WW, R, PRE>), dim3(grid), dim3(256), smem, st, p, G);
+    hipLaunchKernelGGL((conv_igemm_pipe_kernel<NT, WH, WW, R>), dim3(grid), dim3(256), smem, st, p, G);
     EGM_CHECK_LAUNCH("conv_igemm_pipe");
     return EGM_OK;
-}
-// PRE_OK: the shape family takes prologues at all (7x7 windows never follow a BatchNorm in this network)
-template <int NT, int WH, int WW, int R, bool PRE_OK = true>
-int launch_pipe(ConvParams& p, int G, hipStream_t st) {
-    if (p.pre.mode == EGM_PRE_NONE) return launch_pipe_pre<NT, WH, WW, R, EGM_PRE_NONE>(p, G, st);
-    if constexpr (PRE_OK) {
-        if (p.pre.mode == EGM_PRE_BN_ACT) return launch_pipe_pre<NT, WH, WW, R, EGM_PRE_BN_ACT>(p, G, st);
-    }
-    EGM_FAIL(EGM_ERR_UNSUPPORTED, "conv_igemm_pipe: prologue mode %d not built for this window", p.pre.mode);
 }
 
 // One place decides kernel, tile shape and grouping, so the stats-tile count the caller allocates always matches the launch.
 struct ConvPlan { bool pipe, direct, tile, wreg, c7, c16d = false; int tile_cfg; int R, NT, tiles_y, tiles_x, npt, nct, G; size_t smem; };
-ConvPlan conv_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int pre_mode = EGM_PRE_NONE) {
+ConvPlan conv_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil) {
     ConvPlan c;
     if (KH == 1 && KW == 1) dil = 1;
-    // prologues the fast kernels are not built with (the BatchNorm-backward form; anything in front of a 7x7) take the generic kernel
-    const bool fast_ok = pre_mode == EGM_PRE_NONE || (pre_mode == EGM_PRE_BN_ACT && KH != 7);
     c.tile_cfg = 0;
     // taken at launch when no BatchNorm statistics are asked for (the kernel has no statistics epilogue); the rest of the plan stays
     // that of the generic kernel, so a caller's statistics-tile count does not depend on it
-    c.c7 = pre_mode == EGM_PRE_NONE && !egm_group_recording() && egm_conv_c7_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil) != 0;
+    c.c7 = !egm_group_recording() && egm_conv_c7_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil) != 0;
     // dilated 3x3 on 16 channels (conv7x7_c16.hip): launched at once, also inside a launch group (it has no merged form)
-    const int c16d = pre_mode == EGM_PRE_NONE ? egm_conv_c16d_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil) : 0;
+    const int c16d = egm_conv_c16d_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil);
     if (c16d > 0) { c.c16d = true; c.pipe = c.direct = c.tile = c.wreg = false; c.R = 0; c.NT = 1; c.nct = 1; c.tiles_y = c.tiles_x = c.npt = 0; c.smem = 0; c.G = c16d; return c; }
-    c.wreg = pre_mode == EGM_PRE_NONE && egm_conv_wreg_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.G) != 0;
+    c.wreg = egm_conv_wreg_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.G) != 0;
     if (c.wreg) { c.pipe = c.direct = c.tile = false; c.R = 2; c.NT = 1; c.nct = 1; c.tiles_y = c.tiles_x = c.npt = 0; c.smem = 0; return c; }
-    c.tile = pre_mode == EGM_PRE_NONE && egm_conv_tile_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.tile_cfg, &c.nct, &c.G) != 0;
+    c.tile = egm_conv_tile_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.tile_cfg, &c.nct, &c.G) != 0;
     if (c.tile) { c.pipe = c.direct = false; c.R = 2; c.NT = 2; c.tiles_y = c.tiles_x = c.npt = 0; c.smem = 0; return c; }
-    c.direct = fast_ok && Cin > 0 && egm_conv_direct_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.NT, &c.nct, &c.G, &c.smem) != 0;
+    c.direct = Cin > 0 && egm_conv_direct_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &c.NT, &c.nct, &c.G, &c.smem) != 0;
     if (c.direct) { c.pipe = false; c.R = 0; c.tiles_y = c.tiles_x = c.npt = 0; return c; }
-    c.pipe = fast_ok && pipe_eligible(dtype, KH, KW, dil);
+    c.pipe = pipe_eligible(dtype, KH, KW, dil);
     c.R = 2;
     if (c.pipe && KH == 3 && dil == 1 && Cout <= 32) {
         // tall tiles (16 x 32 pixels, 4 rows per wave) for the narrow layers when they still fill the chip: 0.75 instead of
@@ -862,18 +802,17 @@ ConvPlan conv_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, in
 
 // The name of the kernel egm_conv_fwd_pre takes for a shape, as rocprofv3 prints it (template arguments included): lets a harness
 // put its own per-launch timings beside the matching row of a kernel trace.  Returns the length written (buf may be NULL).
-extern "C" int egm_conv_kernel_name(int dtype, int pre_mode, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen) {
+extern "C" int egm_conv_kernel_name(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen) {
     if (KH == 1 && KW == 1) dil = 1;
-    const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, pre_mode);
+    const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil);
     char tmp[96];
-    const int pre = pre_mode == EGM_PRE_NONE ? 0 : 1;
     if (c.c16d) snprintf(tmp, sizeof(tmp), "conv3x3d_c16_kernel");
     else if (c.c7) snprintf(tmp, sizeof(tmp), "conv7x7_c16_kernel");
     else if (c.wreg) snprintf(tmp, sizeof(tmp), "%s", egm_conv_wreg_name(Cin));
     else if (c.tile) snprintf(tmp, sizeof(tmp), "%s", egm_conv_tile_name(c.tile_cfg));
-    else if (c.direct) snprintf(tmp, sizeof(tmp), "conv_direct_kernel<%d, %d, %s>", c.NT, pre, KH == 1 ? "true" : "false");
-    else if (c.pipe) snprintf(tmp, sizeof(tmp), "conv_igemm_pipe_kernel<%d, %d, %d, %d, %d>", c.NT, (KH == 3 && dil == 1) ? 3 : 1,
-                              (KH == 3 && dil == 1) ? 3 : (KH == 7 ? 7 : 1), c.R, pre);
+    else if (c.direct) snprintf(tmp, sizeof(tmp), "conv_direct_kernel<%d, %s>", c.NT, KH == 1 ? "true" : "false");
+    else if (c.pipe) snprintf(tmp, sizeof(tmp), "conv_igemm_pipe_kernel<%d, %d, %d, %d>", c.NT, (KH == 3 && dil == 1) ? 3 : 1,
+                              (KH == 3 && dil == 1) ? 3 : (KH == 7 ? 7 : 1), c.R);
     else snprintf(tmp, sizeof(tmp), "conv_igemm_kernel<%s, %d>", dtype == EGM_BF16 ? "bf16_t" : "float", c.NT);
     const int n = (int)strlen(tmp);
     if (buf != nullptr && buflen > 0) { strncpy(buf, tmp, (size_t)buflen - 1); buf[buflen - 1] = 0; }
@@ -881,9 +820,6 @@ extern "C" int egm_conv_kernel_name(int dtype, int pre_mode, int N, int H, int W
 }
 extern "C" int egm_conv_stats_tiles(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil) {
     return conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil).G;
-}
-extern "C" int egm_conv_stats_tiles_pre(int dtype, int pre_mode, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil) {
-    return conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, pre_mode).G;
 }
 
 extern "C" int egm_conv_pack(int dtype, const void* w, void* wf, void* wd, int Cout, int Cin, int KH, int KW, int groups,
@@ -910,16 +846,10 @@ extern "C" int egm_conv_pack_multi(int dtype, const void* table_dev, int n, long
     return EGM_OK;
 }
 
-extern "C" int egm_conv_fwd(int dtype, const void* x, int ldx, const void* wf, const void* bias, int bias_n, void* y, int ldy,
-                            float* stats, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, egm_stream_t s) {
-    return egm_conv_fwd_pre(dtype, x, ldx, EGM_PRE_NONE, 0, nullptr, nullptr, 0, wf, bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, KH, KW,
-                            dil, s);
-}
-
 /* 1 when egm_conv_fwd_split takes this shape (the 8-wave 3x3 tile kernel does, with the split on an 8-channel boundary) */
 extern "C" int egm_conv_split_ok(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int csplit) {
     if (csplit <= 0 || csplit >= Cout || csplit % 8 || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cin % 8 || Cout % 8) return 0;
-    const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, EGM_PRE_NONE);
+    const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil);
     return (!c.c7 && !c.wreg && c.tile) ? 1 : 0;
 }
 extern "C" int egm_conv_fwd_split(int dtype, const void* x, int ldx, const void* wf, void* y, int ldy, void* y2, int ldy2, int csplit, int N,
@@ -927,18 +857,13 @@ extern "C" int egm_conv_fwd_split(int dtype, const void* x, int ldx, const void*
     EGM_REQUIRE(x && wf && y && y2 && egm_aligned16(x) && egm_aligned16(wf) && egm_aligned16(y) && egm_aligned16(y2), "conv_fwd_split: bad pointers");
     EGM_REQUIRE(egm_conv_split_ok(dtype, N, H, W, Cin, Cout, KH, KW, dil, csplit), "conv_fwd_split: shape not supported (egm_conv_split_ok)");
     EGM_REQUIRE(ldx >= Cin && ldx % 8 == 0 && ldy >= csplit && ldy % 8 == 0 && ldy2 >= Cout - csplit && ldy2 % 8 == 0, "conv_fwd_split: bad ld");
-    const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, EGM_PRE_NONE);
+    const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil);
     return egm_conv_tile_launch(x, ldx, wf, nullptr, 0, y, ldy, nullptr, N, H, W, Cin, Cout, c.tile_cfg, c.nct, c.G, s, y2, ldy2, csplit);
 }
 
-extern "C" int egm_conv_fwd_pre(int dtype, const void* x, int ldx, int pre_mode, int pre_act, const float* pre_cf, const void* pre_aux,
-                                int pre_ld_aux, const void* wf, const void* bias, int bias_n, void* y, int ldy, float* stats, int N, int H,
-                                int W, int Cin, int Cout, int KH, int KW, int dil, egm_stream_t s) {
+extern "C" int egm_conv_fwd(int dtype, const void* x, int ldx, const void* wf, const void* bias, int bias_n, void* y, int ldy, float* stats,
+                            int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, egm_stream_t s) {
     EGM_REQUIRE(x && wf && y, "conv_fwd: null pointer");
-    EGM_REQUIRE(pre_mode == EGM_PRE_NONE || pre_mode == EGM_PRE_BN_ACT || pre_mode == EGM_PRE_BN_BWD, "conv_fwd: bad prologue mode %d", pre_mode);
-    EGM_REQUIRE(pre_mode == EGM_PRE_NONE || pre_cf != nullptr, "conv_fwd: prologue without coefficient rows");
-    EGM_REQUIRE(pre_mode != EGM_PRE_BN_BWD || (pre_aux != nullptr && egm_aligned16(pre_aux) && pre_ld_aux >= Cin && pre_ld_aux % 8 == 0),
-                "conv_fwd: BN-backward prologue needs the BatchNorm input (aux) with ld >= Cin, multiple of 8");
     EGM_REQUIRE(!bias || (bias_n > 0 && bias_n <= Cout), "conv_fwd: bad bias_n %d", bias_n);
     EGM_REQUIRE(N > 0 && H > 0 && W > 0, "conv_fwd: bad shape N=%d H=%d W=%d", N, H, W);
     EGM_REQUIRE(Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, "conv_fwd: Cin=%d/Cout=%d must be multiples of 8", Cin, Cout);
@@ -952,14 +877,13 @@ extern "C" int egm_conv_fwd_pre(int dtype, const void* x, int ldx, int pre_mode,
     p.x = x; p.w = wf; p.bias = (const float*)bias; p.y = y; p.stats = stats;
     p.ldx = ldx; p.ldy = ldy; p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.dil = dil; p.bias_n = bias ? bias_n : 0;
     p.wl = egm_w_layout(dtype, KH, KW, Cin, Cout);
-    p.pre.mode = pre_mode; p.pre.act = pre_act; p.pre.cf = pre_cf; p.pre.aux = pre_aux; p.pre.ld_aux = pre_ld_aux; p.pre.C = Cin;
-    const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, pre_mode);
+    const ConvPlan c = conv_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil);
     if (c.c16d) return egm_conv_c16d_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, dil, s);
     if (c.c7 && stats == nullptr) return egm_conv_c7_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, N, H, W, s);
     if (c.wreg) return egm_conv_wreg_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, c.G, s);
     if (c.tile) return egm_conv_tile_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, c.tile_cfg, c.nct, c.G, s);
     if (c.direct)
-        return egm_conv_direct_launch(x, ldx, p.pre, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, KH, KW, dil, c.NT,
+        return egm_conv_direct_launch(x, ldx, wf, (const float*)bias, bias_n, y, ldy, stats, N, H, W, Cin, Cout, KH, KW, dil, c.NT,
                                       c.nct, c.G, c.smem, s);
     p.tiles_y = c.tiles_y; p.tiles_x = c.tiles_x; p.npt = c.npt; p.nct = c.nct;
     const int NT = c.NT;
@@ -969,7 +893,7 @@ extern "C" int egm_conv_fwd_pre(int dtype, const void* x, int ldx, int pre_mode,
             if (c.R == 4) return launch_pipe<1, 3, 3, 4>(p, c.G, st);                      // tall tiles: Cout <= 32 only (conv_plan)
             return NT == 2 ? launch_pipe<2, 3, 3, 2>(p, c.G, st) : launch_pipe<1, 3, 3, 2>(p, c.G, st);
         }
-        if (KH == 7) return NT == 2 ? launch_pipe<2, 1, 7, 2, false>(p, c.G, st) : launch_pipe<1, 1, 7, 2, false>(p, c.G, st);
+        if (KH == 7) return NT == 2 ? launch_pipe<2, 1, 7, 2>(p, c.G, st) : launch_pipe<1, 1, 7, 2>(p, c.G, st);
         return NT == 2 ? launch_pipe<2, 1, 1, 2>(p, c.G, st) : launch_pipe<1, 1, 1, 2>(p, c.G, st);
     }
     const int ps = (dtype == EGM_BF16) ? Mma<bf16_t>::kPixStride : Mma<float>::kPixStride;

@@ -21,7 +21,6 @@
 //   * the C waves sharing a dW block are summed through LDS; partial blocks go to a slab [split][tap][CoutP][CinP] with plain stores; a second kernel sums the slabs in
 //     fixed order (bitwise reproducible) and scatters into the fp32 OIHW gradient.
 #include "common.h"
-#include "prologue.h"
 #include "group.h"
 #include <string.h>
 #include <stdio.h>
@@ -84,10 +83,6 @@ struct WgradParams {
     int nci_tiles;               // ceil(Cin / (32*B))
     int ngroups;                 // tap groups
     int dma;                     // bf16: stage through LDS-DMA into two LDS images (no VGPR staging, one barrier per tile)
-    PreArgs prex, predy;         // operand prologues (prologue.h): x = act(bn(y_prev)) and dy = bn_backward(dz, y) computed while staging
-    int cf_off;                  // LDS byte offset of the prologue coefficient rows
-    void* dy_out; int ld_dy_out; // by-product: the logical dy, written once per element for the data-gradient kernel (may be null)
-    int out_grp;                 // the tap group whose workgroups write it (one that visits every pixel tile)
 };
 
 template <int NTAPS> struct Window;   // staged window of a tap group
@@ -97,15 +92,9 @@ template <> struct Window<5> { static constexpr int WH = 1, WW = 5; };
 template <> struct Window<3> { static constexpr int WH = 1, WW = 3; };   // one kernel row of a DILATED 3x3: taps p.dil apart
 template <> struct Window<1> { static constexpr int WH = 1, WW = 1; };
 
-// PRE: the kernel is built with operand prologues (prologue.h).  Both operands may then be LOGICAL tensors: x = act(scale*y_prev +
-// shift) of the BatchNorm in front of this conv, dy = the BatchNorm backward of the one behind it, computed from (dz, y) between the
-// global load and the LDS write of the staging pipeline.  The applied activation is never written to memory; dy is written ONCE, as
-// a by-product (dy_out: by the workgroups of input-channel block 0 and of the centre tap group, which between them stage every dy
-// element exactly once), for the data-gradient kernel that runs next -- the stand-alone BatchNorm-backward apply pass
-// (bn_act_bwd_apply_kernel: read dz, read y, write dy) and one of the two reads of dy disappear.
 // (bx, by, bz) = the workgroup's index within THIS convolution: blockIdx of a plain launch, or decoded from the flat block index of a
 // merged launch (group.h)
-template <typename T, int NTAPS, bool PRE>
+template <typename T, int NTAPS>
 __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using M = WMma<T>;
@@ -156,24 +145,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
     constexpr int XVEC = ((DROW ? 1 : 2) * PH * PWC * VPR + 255) / 256;   // sized for B = 2 (dilated-row variant: B = 1 only)
     constexpr bool PIPE = (sizeof(T) == 2);                           // bf16: register prefetch (issue early / write late)
     uint4 pre_dy[PIPE ? DYVEC : 1], pre_x[PIPE ? XVEC : 1];
-    uint4 pre_dya[(PIPE && PRE) ? DYVEC : 1];                         // BatchNorm input y next to dz (EGM_PRE_BN_BWD)
     const int ndy = p.A * TH * TW * VPR, nx = p.B * PH * PW * VPR;
-    // ---- prologue coefficient rows of this workgroup's channel blocks: dy rows [4][32 A], x rows [2][32 B] (zero past the tensor)
-    float* cf_dy = reinterpret_cast<float*>(smem + p.cf_off);
-    float* cf_x = cf_dy + 4 * 32 * p.A;
-    const int cs_dy = 32 * p.A, cs_x = 32 * p.B;
-    if (PRE) {
-        for (int i = tid; i < 4 * cs_dy; i += 256) {
-            const int r = i / cs_dy, c = co_base + (i - r * cs_dy);
-            cf_dy[i] = (p.predy.mode != EGM_PRE_NONE && c < p.Cout && (r < 2 || p.predy.mode == EGM_PRE_BN_BWD)) ? p.predy.cf[r * p.predy.C + c] : 0.f;
-        }
-        for (int i = tid; i < 2 * cs_x; i += 256) {
-            const int r = i / cs_x, c = ci_base + (i - r * cs_x);
-            cf_x[i] = (p.prex.mode != EGM_PRE_NONE && c < p.Cin) ? p.prex.cf[r * p.prex.C + c] : 0.f;
-        }
-        __syncthreads();
-    }
-
     auto tile_ok = [&](int pt, int& n, int& oy0, int& ox0) {
         n = pt / tpi; const int trem = pt - n * tpi;
         oy0 = (trem / p.tiles_x) * TH; ox0 = (trem % p.tiles_x) * TW;
@@ -200,39 +172,11 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
         if (dy_slot(i, n, oy0, ox0, po, c, cl)) val = *reinterpret_cast<const uint4*>(dyg + po * p.lddy + c);
         return val;
     };
-    auto load_dya = [&](int i, int n, int oy0, int ox0) __attribute__((always_inline)) {                  // the BatchNorm input y at dz's position
-        long long po; int c, cl;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (p.predy.mode == EGM_PRE_BN_BWD && dy_slot(i, n, oy0, ox0, po, c, cl))
-            val = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.predy.aux) + po * p.predy.ld_aux + c);
-        return val;
-    };
     auto load_x = [&](int i, int n, int oy0, int ox0) __attribute__((always_inline)) {
         long long po; int c, cl;
         uint4 val = make_uint4(0, 0, 0, 0);
         if (x_slot(i, n, oy0, ox0, po, c, cl)) val = *reinterpret_cast<const uint4*>(xg + po * p.ldx + c);
         return val;
-    };
-    // logical operands from the loaded vectors; slots outside the tensor (zero padding, ragged tiles) stay exactly zero
-    const bool dy_writer = PRE && p.dy_out != nullptr && cit == 0 && grp == p.out_grp;
-    auto xform_dy = [&](uint4 raw, uint4 aux, int i, int n, int oy0, int ox0) __attribute__((always_inline)) {
-        if (!PRE || p.predy.mode == EGM_PRE_NONE) return raw;
-        long long po; int c, cl;
-        if (!dy_slot(i, n, oy0, ox0, po, c, cl)) return make_uint4(0, 0, 0, 0);
-        uint4 v;
-        if (p.predy.act == EGM_ACT_RELU) v = pre_apply_rt<EGM_ACT_RELU>(T(), raw, aux, cf_dy + cl, cs_dy, p.predy.mode, 0);
-        else if (p.predy.act == EGM_ACT_NONE) v = pre_apply_rt<EGM_ACT_NONE>(T(), raw, aux, cf_dy + cl, cs_dy, p.predy.mode, 0);
-        else v = pre_apply_rt<kActRuntime>(T(), raw, aux, cf_dy + cl, cs_dy, p.predy.mode, p.predy.act);
-        if (dy_writer) *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.dy_out) + po * p.ld_dy_out + c) = v;
-        return v;
-    };
-    auto xform_x = [&](uint4 raw, int i, int n, int oy0, int ox0) __attribute__((always_inline)) {
-        if (!PRE || p.prex.mode == EGM_PRE_NONE) return raw;
-        long long po; int c, cl;
-        if (!x_slot(i, n, oy0, ox0, po, c, cl)) return make_uint4(0, 0, 0, 0);
-        if (p.prex.act == EGM_ACT_RELU) return pre_apply_rt<EGM_ACT_RELU>(T(), raw, raw, cf_x + cl, cs_x, EGM_PRE_BN_ACT, 0);
-        if (p.prex.act == EGM_ACT_NONE) return pre_apply_rt<EGM_ACT_NONE>(T(), raw, raw, cf_x + cl, cs_x, EGM_PRE_BN_ACT, 0);
-        return pre_apply_rt<kActRuntime>(T(), raw, raw, cf_x + cl, cs_x, EGM_PRE_BN_ACT, p.prex.act);
     };
     // vector i sits at block-major [32-ch block][pixel][v]: (i / VPR) * RB + (i % VPR) * 16 == 16 i
     auto dy_lds = [&](int i) { return dyl + i * 16; };
@@ -357,10 +301,6 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
     if (PIPE && pt < p.npt) {
 #pragma unroll
         for (int k = 0; k < DYVEC; ++k) pre_dy[k] = load_dy(tid + k * 256, n, oy0, ox0);
-        if (PRE) {
-#pragma unroll
-            for (int k = 0; k < DYVEC; ++k) pre_dya[k] = load_dya(tid + k * 256, n, oy0, ox0);
-        }
 #pragma unroll
         for (int k = 0; k < XVEC; ++k) pre_x[k] = load_x(tid + k * 256, n, oy0, ox0);
     }
@@ -371,14 +311,13 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
 #pragma unroll
             for (int k = 0; k < DYVEC; ++k)
                 if (tid + k * 256 < ndy)
-                    *reinterpret_cast<uint4*>(dy_lds(tid + k * 256)) = xform_dy(pre_dy[k], pre_dya[PRE ? k : 0], tid + k * 256, n, oy0, ox0);
+                    *reinterpret_cast<uint4*>(dy_lds(tid + k * 256)) = pre_dy[k];
 #pragma unroll
             for (int k = 0; k < XVEC; ++k)
-                if (tid + k * 256 < nx) *reinterpret_cast<uint4*>(x_lds(tid + k * 256)) = xform_x(pre_x[k], tid + k * 256, n, oy0, ox0);
+                if (tid + k * 256 < nx) *reinterpret_cast<uint4*>(x_lds(tid + k * 256)) = pre_x[k];
         } else {
-            for (int i = tid; i < ndy; i += 256)
-                *reinterpret_cast<uint4*>(dy_lds(i)) = xform_dy(load_dy(i, n, oy0, ox0), PRE ? load_dya(i, n, oy0, ox0) : make_uint4(0, 0, 0, 0), i, n, oy0, ox0);
-            for (int i = tid; i < nx; i += 256) *reinterpret_cast<uint4*>(x_lds(i)) = xform_x(load_x(i, n, oy0, ox0), i, n, oy0, ox0);
+            for (int i = tid; i < ndy; i += 256) *reinterpret_cast<uint4*>(dy_lds(i)) = load_dy(i, n, oy0, ox0);
+            for (int i = tid; i < nx; i += 256) *reinterpret_cast<uint4*>(x_lds(i)) = load_x(i, n, oy0, ox0);
         }
         EGM_WTICK(1);
         __syncthreads();
@@ -388,10 +327,6 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
         if (PIPE && pt2 < p.npt) {                                    // in flight during the MFMAs below
 #pragma unroll
             for (int k = 0; k < DYVEC; ++k) pre_dy[k] = load_dy(tid + k * 256, n2, oy2, ox2);
-            if (PRE) {
-#pragma unroll
-                for (int k = 0; k < DYVEC; ++k) pre_dya[k] = load_dya(tid + k * 256, n2, oy2, ox2);
-            }
 #pragma unroll
             for (int k = 0; k < XVEC; ++k) pre_x[k] = load_x(tid + k * 256, n2, oy2, ox2);
         }
@@ -446,9 +381,9 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
 #endif
 }
 
-template <typename T, int NTAPS, bool PRE>
-__global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2 && !PRE) ? 2 : 1) void conv_wgrad_kernel(WgradParams p) {
-    conv_wgrad_body<T, NTAPS, PRE>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+template <typename T, int NTAPS>
+__global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2) ? 2 : 1) void conv_wgrad_kernel(WgradParams p) {
+    conv_wgrad_body<T, NTAPS>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 // merged launch of up to EGM_GROUP_MAX independent weight gradients of one instantiation (group.h): member i owns the flat blocks
 // [blk0[i], blk0[i+1]) = its (nx, ny, nz) grid in x-fastest order
@@ -466,23 +401,21 @@ template <typename T, int NTAPS>
 __global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2) ? 2 : 1) void conv_wgrad_multi_kernel(WgradMulti m) {
     int bx, by, bz;
     const int i = wgrad_multi_member(m, bx, by, bz);
-    conv_wgrad_body<T, NTAPS, false>(m.p[i], bx, by, bz);
+    conv_wgrad_body<T, NTAPS>(m.p[i], bx, by, bz);
 }
 
 // -------------------------------------------------------------------------------------------------
 // Wave-specialised bf16 kernel (the throughput path): 8 waves per workgroup, one workgroup per CU.
 //   * waves 0-3 (one per SIMD) are CONSUMERS: A x B x C split as above, NTAPS accumulators each, nothing but transposing LDS reads
 //     and MFMAs in their loop -- no staging registers, no global memory instruction, no VALU work besides addressing;
-//   * waves 4-7 are PRODUCERS: they load the next tile's dy / x vectors into registers, apply the operand prologues (prologue.h:
-//     x = act(bn(y_prev)), dy = BatchNorm backward of (dz, y)), write the result into the OTHER LDS image pair, store dy once to
-//     memory for the data-gradient kernel (by-product) and immediately re-issue the loads of the tile after next into the freed
-//     registers, so a whole tile period hides the global latency.
-//   A consumer and a producer wave share each SIMD: the producers' VALU work (50-55 instructions per 16-byte vector for the
-//   BatchNorm backward) runs beside the consumers' MFMAs instead of in front of them -- in the one-wave-per-SIMD kernel above the
-//   same prologue work is serialised with the matrix work and doubles the kernel.  One barrier per tile.
+//   * waves 4-7 are PRODUCERS: they load the dy / x vectors of the tiles ahead into registers (two tiles in flight from memory), write
+//     them into the OTHER LDS image pair and immediately re-issue the loads of the tile three ahead into the freed registers, so
+//     whole tile periods hide the global latency.
+//   A consumer and a producer wave share each SIMD: staging runs beside the consumers' MFMAs instead of in front of them.  One
+//   barrier per tile.
 // ROT: the row-rotation consumer loop (9 taps, every wave walks all rows of the tile: p.C == 1); its own instantiation, because a kernel
 // that carries both consumer loops spills (660 bytes per lane)
-template <int NTAPS, bool PRE, bool ROT>
+template <int NTAPS, bool ROT>
 __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using M = WMma<bf16_t>;
@@ -515,21 +448,6 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
     const int img_bytes = (p.A * TH * TW + p.B * PH * PW) * RB;           // one dy + x image pair; two of them, then the coefficients
     const bf16_t* __restrict__ xg = reinterpret_cast<const bf16_t*>(p.x);
     const bf16_t* __restrict__ dyg = reinterpret_cast<const bf16_t*>(p.dy);
-    const bf16_t* __restrict__ yg = reinterpret_cast<const bf16_t*>(p.predy.aux);
-    bf16_t* __restrict__ og = reinterpret_cast<bf16_t*>(p.dy_out);
-    float* cf_dy = reinterpret_cast<float*>(smem + p.cf_off);
-    float* cf_x = cf_dy + 4 * 32 * p.A;
-    const int cs_dy = 32 * p.A, cs_x = 32 * p.B;
-    if (PRE) {
-        for (int i = tid; i < 4 * cs_dy; i += 512) {
-            const int r = i / cs_dy, c = co_base + (i - r * cs_dy);
-            cf_dy[i] = (p.predy.mode != EGM_PRE_NONE && c < p.Cout && (r < 2 || p.predy.mode == EGM_PRE_BN_BWD)) ? p.predy.cf[r * p.predy.C + c] : 0.f;
-        }
-        for (int i = tid; i < 2 * cs_x; i += 512) {
-            const int r = i / cs_x, c = ci_base + (i - r * cs_x);
-            cf_x[i] = (p.prex.mode != EGM_PRE_NONE && c < p.Cin) ? p.prex.cf[r * p.prex.C + c] : 0.f;
-        }
-    }
 
     const int tpi = p.tiles_y * p.tiles_x;
     auto tile_ok = [&](int pt, int& n, int& oy0, int& ox0) __attribute__((always_inline)) {
@@ -553,17 +471,15 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
         // ---- producer state: 16-byte vector i = ptid + 256 k of the dy image / the x image (block-major [32-ch block][pixel][4 vectors])
         constexpr int DYVEC = ((DROW ? 1 : 2) * TH * TW * VPR + 255) / 256;
         constexpr int XVEC = ((DROW ? 1 : 2) * PH * PWC * VPR + 255) / 256;
-        // one tile's staging registers.  Without prologues there are TWO sets, i.e. two tiles in flight from memory behind the one
-        // being written to LDS: a tile is 16-38 KB per CU and a round trip ~2 us, so ONE tile in flight caps the HBM-bound layers
-        // (<= 64 channels at 512^2 / 256^2) near 3 TB/s whatever the consumers do; the prologue forms keep one (register budget).
-        struct Regs { uint4 dy[DYVEC], ya[PRE ? DYVEC : 1], x[XVEC]; };
+        // one tile's staging registers.  There are TWO sets, i.e. two tiles in flight from memory behind the one being written to LDS:
+        // a tile is 16-38 KB per CU and a round trip ~2 us, so ONE tile in flight caps the HBM-bound layers (<= 64 channels at
+        // 512^2 / 256^2) near 3 TB/s whatever the consumers do.
+        struct Regs { uint4 dy[DYVEC], x[XVEC]; };
 #ifndef EGM_WGRAD_DEEP
 #define EGM_WGRAD_DEEP 1          // 0: one staging set everywhere (A/B builds)
 #endif
-        constexpr bool DEEP = !PRE && EGM_WGRAD_DEEP;
+        constexpr bool DEEP = EGM_WGRAD_DEEP;
         Regs ra, rb;
-        const bool dy_writer = PRE && og != nullptr && cit == 0 && grp == p.out_grp;
-        const bool dy_bwd = PRE && p.predy.mode == EGM_PRE_BN_BWD, x_act = PRE && p.prex.mode != EGM_PRE_NONE;
         const int v4 = ptid & 3;                                        // the thread's vector inside a 32-channel row (same for all its slots)
         // slot geometry -> (inside the tensor?, pixel offset from the tile's / patch's first pixel, channel offset inside the block set)
         // The slot arithmetic must stay INSIDE the tile loop: hoisted out of it, its ~27 per-slot invariants do not fit the register
@@ -595,12 +511,11 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
             return pk >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         };
         auto issue_tile = [&](Regs& rg, int n, int oy_, int ox_) __attribute__((always_inline)) {
-            uint4 (&rdy)[DYVEC] = rg.dy; uint4 (&rya)[PRE ? DYVEC : 1] = rg.ya; uint4 (&rx)[XVEC] = rg.x;
+            uint4 (&rdy)[DYVEC] = rg.dy; uint4 (&rx)[XVEC] = rg.x;
             tix = opaque(ptid);
             const long long o_dy = (long long)(n * p.H + oy_) * p.W + ox_;                // first pixel of the dy tile (inside the image)
             const long long o_x = (long long)(n * p.H + oy_ + offy) * p.W + ox_ + offx;   // first pixel of the x patch (may be outside)
             const bf16_t* dbase = dyg + o_dy * p.lddy + co_base;
-            const bf16_t* ybase = dy_bwd ? yg + o_dy * p.predy.ld_aux + co_base : nullptr;
             const bf16_t* xbase = xg + o_x * p.ldx + ci_base;
 #pragma unroll
             for (int k = 0; k < DYVEC; ++k) {
@@ -608,7 +523,6 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
                 const bool ok = dy_geom(k, oy_, ox_, rel, cl);
                 rdy[k] = make_uint4(0, 0, 0, 0);
                 if (ok) rdy[k] = *reinterpret_cast<const uint4*>(dbase + rel * p.lddy + cl);
-                if (PRE) { rya[k] = make_uint4(0, 0, 0, 0); if (ok && dy_bwd) rya[k] = *reinterpret_cast<const uint4*>(ybase + rel * p.predy.ld_aux + cl); }
             }
 #pragma unroll
             for (int k = 0; k < XVEC; ++k) {
@@ -618,83 +532,18 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
                 if (ok) rx[k] = *reinterpret_cast<const uint4*>(xbase + rel * p.ldx + cl);
             }
         };
-        // transform + LDS write of the tile held in registers (tile coordinates n, oy_, ox_) into image pair `buf`.
-        // The per-channel coefficients of a slot depend on (32-channel block, v4) only: dy slots 4b .. 4b+3 share block b, so one
-        // coefficient set is read per block (eight 16-byte LDS reads) and kept in registers for its four slots; ONE uniform branch on
-        // the activation surrounds each slot loop (a switch inside would triple the loop and miss the instruction cache).
-        auto load_cf = [&](PreCoef8& kf, const float* cf, int cs, int rows) __attribute__((always_inline)) {
-            const float4* c4 = reinterpret_cast<const float4*>(cf);              // cf is 32-byte aligned: cl is a multiple of 8
-            const int s4 = cs >> 2;
-            float* dst[4] = {kf.sc, kf.sh, kf.cb, kf.cc};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (r < rows) {
-                    const float4 lo = c4[r * s4], hi = c4[r * s4 + 1];
-                    dst[r][0] = lo.x; dst[r][1] = lo.y; dst[r][2] = lo.z; dst[r][3] = lo.w;
-                    dst[r][4] = hi.x; dst[r][5] = hi.y; dst[r][6] = hi.z; dst[r][7] = hi.w;
-                }
-            }
-        };
-        auto write_tile = [&](Regs& rg, int buf, int n, int oy_, int ox_) __attribute__((always_inline)) {
-            uint4 (&rdy)[DYVEC] = rg.dy; uint4 (&rya)[PRE ? DYVEC : 1] = rg.ya; uint4 (&rx)[XVEC] = rg.x;
+        // LDS write of the tile held in registers into image pair `buf`
+        auto write_tile = [&](Regs& rg, int buf) __attribute__((always_inline)) {
+            uint4 (&rdy)[DYVEC] = rg.dy; uint4 (&rx)[XVEC] = rg.x;
             tix = opaque(ptid);
             unsigned char* dyb = smem + buf * img_bytes;
             unsigned char* xb = dyb + p.A * (TH * TW) * RB;
-            bf16_t* obase = dy_writer ? og + ((long long)(n * p.H + oy_) * p.W + ox_) * p.ld_dy_out + co_base : nullptr;
-            if (PRE && dy_bwd) {
-                auto dy_pass = [&](auto act_tag) __attribute__((always_inline)) {
-                    constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-                    for (int b = 0; b < (DROW ? 1 : 2); ++b) {
-                        if (b < p.A) {
-                            PreCoef8 kf;
-                            load_cf(kf, cf_dy + b * 32 + (tix & 3) * 8, cs_dy, 4);
+            for (int k = 0; k < DYVEC; ++k)
+                if (tix + k * 256 < ndy) *reinterpret_cast<uint4*>(dyb + (tix + k * 256) * 16) = rdy[k];
 #pragma unroll
-                            for (int kk = 0; kk < 4; ++kk) {
-                                const int k = b * 4 + kk;
-                                int rel, cl;
-                                const bool ok = dy_geom(k, oy_, ox_, rel, cl);
-                                uint4 v = pre_apply8<EGM_PRE_BN_BWD, ACT>(rdy[k], rya[k], kf, 0);
-                                if (!ok) v = make_uint4(0, 0, 0, 0);
-                                else if (dy_writer) *reinterpret_cast<uint4*>(obase + rel * p.ld_dy_out + cl) = v;
-                                *reinterpret_cast<uint4*>(dyb + (tix + k * 256) * 16) = v;
-                            }
-                        }
-                    }
-                };
-                if (p.predy.act == EGM_ACT_RELU) dy_pass(std::integral_constant<int, EGM_ACT_RELU>());
-                else dy_pass(std::integral_constant<int, EGM_ACT_NONE>());
-            } else {
-#pragma unroll
-                for (int k = 0; k < DYVEC; ++k)
-                    if (tix + k * 256 < ndy) *reinterpret_cast<uint4*>(dyb + (tix + k * 256) * 16) = rdy[k];
-            }
-            if (PRE && x_act) {
-                auto x_pass = [&](auto act_tag) __attribute__((always_inline)) {
-                    constexpr int ACT = decltype(act_tag)::value;
-                    PreCoef8 kf;
-                    int cur_blk = -1;
-#pragma unroll
-                    for (int k = 0; k < XVEC; ++k) {
-                        const int i = tix + k * 256;
-                        if (i < nx) {
-                            int rel, cl;
-                            const bool ok = x_geom(k, oy_ + offy, ox_ + offx, rel, cl);
-                            const int blk = cl >> 5;
-                            if (blk != cur_blk) { load_cf(kf, cf_x + cl, cs_x, 2); cur_blk = blk; }   // changes at most once per thread (B <= 2)
-                            uint4 v = pre_apply8<EGM_PRE_BN_ACT, ACT>(rx[k], rx[k], kf, 0);
-                            if (!ok) v = make_uint4(0, 0, 0, 0);
-                            *reinterpret_cast<uint4*>(xb + i * 16) = v;
-                        }
-                    }
-                };
-                if (p.prex.act == EGM_ACT_RELU) x_pass(std::integral_constant<int, EGM_ACT_RELU>());
-                else x_pass(std::integral_constant<int, EGM_ACT_NONE>());
-            } else {
-#pragma unroll
-                for (int k = 0; k < XVEC; ++k)
-                    if (tix + k * 256 < nx) *reinterpret_cast<uint4*>(xb + (tix + k * 256) * 16) = rx[k];
-            }
+            for (int k = 0; k < XVEC; ++k)
+                if (tix + k * 256 < nx) *reinterpret_cast<uint4*>(xb + (tix + k * 256) * 16) = rx[k];
         };
         if constexpr (DEEP) {
             // Producers run one tile ahead in LDS and THREE ahead in registers: set `cur` holds tile pt1 (written to LDS this iteration,
@@ -702,9 +551,9 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
             int n2 = 0, oy2 = 0, ox2 = 0;
             int pt2 = pt1 < p.npt ? next_tile(pt1 + p.nsplit, n2, oy2, ox2) : p.npt;
             if (pt0 < p.npt) issue_tile(ra, n0, oy0, ox0);
-            __syncthreads();                                            // (coefficient rows: none here; the consumers' barrier count)
+            __syncthreads();                                            // (the consumers' barrier count)
             if (pt0 < p.npt) {
-                write_tile(ra, 0, n0, oy0, ox0);
+                write_tile(ra, 0);
                 if (pt1 < p.npt) issue_tile(ra, n1, oy1, ox1);
                 if (pt2 < p.npt) issue_tile(rb, n2, oy2, ox2);
             }
@@ -714,7 +563,7 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
                 int n3 = 0, oy3 = 0, ox3 = 0;
                 const int pt3 = pt2 < p.npt ? next_tile(pt2 + p.nsplit, n3, oy3, ox3) : p.npt;
                 if (pt1 < p.npt) {
-                    write_tile(cur, buf ^ 1, n1, oy1, ox1);             // registers -> the image pair the consumers are NOT reading
+                    write_tile(cur, buf ^ 1);                           // registers -> the image pair the consumers are NOT reading
                     if (pt3 < p.npt) issue_tile(cur, n3, oy3, ox3);     // the freed set takes the tile three ahead
                 }
                 __syncthreads();
@@ -730,9 +579,9 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
         } else {
         // Producers run one tile ahead in LDS and two ahead in registers.
         if (pt0 < p.npt) issue_tile(ra, n0, oy0, ox0);
-        __syncthreads();                                                // coefficient rows visible
+        __syncthreads();                                                // (the consumers' barrier count)
         if (pt0 < p.npt) {
-            write_tile(ra, 0, n0, oy0, ox0);
+            write_tile(ra, 0);
             if (pt1 < p.npt) issue_tile(ra, n1, oy1, ox1);
         }
         __syncthreads();
@@ -741,7 +590,7 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
             int n2 = 0, oy2 = 0, ox2 = 0;
             const int pt2 = pt1 < p.npt ? next_tile(pt1 + p.nsplit, n2, oy2, ox2) : p.npt;
             if (pt1 < p.npt) {
-                write_tile(ra, buf ^ 1, n1, oy1, ox1);                  // registers -> the image pair the consumers are NOT reading
+                write_tile(ra, buf ^ 1);                                // registers -> the image pair the consumers are NOT reading
                 if (pt2 < p.npt) issue_tile(ra, n2, oy2, ox2);          // the freed registers take the tile after next
             }
             __syncthreads();
@@ -873,15 +722,15 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
     }
 }
 
-template <int NTAPS, bool PRE, bool ROT>
+template <int NTAPS, bool ROT>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(WgradParams p) {
-    conv_wgrad_ws_body<NTAPS, PRE, ROT>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+    conv_wgrad_ws_body<NTAPS, ROT>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 template <int NTAPS, bool ROT>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_multi_kernel(WgradMulti m) {
     int bx, by, bz;
     const int i = wgrad_multi_member(m, bx, by, bz);
-    conv_wgrad_ws_body<NTAPS, false, ROT>(m.p[i], bx, by, bz);
+    conv_wgrad_ws_body<NTAPS, ROT>(m.p[i], bx, by, bz);
 }
 
 // sum slabs in fixed order and scatter to fp32 OIHW (real, possibly grouped, shape).
@@ -986,13 +835,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WredEntry
     }
 }
 
-struct WgradPlan { int A, B, C, ntaps, ngroups, nsplit, nco_tiles, nci_tiles, npt, tiles_y, tiles_x, dma, ws, cf_off, c7; size_t smem; long long slab_bytes; };
+struct WgradPlan { int A, B, C, ntaps, ngroups, nsplit, nco_tiles, nci_tiles, npt, tiles_y, tiles_x, dma, ws, c7; size_t smem; long long slab_bytes; };
 
-// smooth: a prologue with a sigmoid / SiLU activation (rare: the 4-wave kernel takes it; the slab count does not depend on it)
-int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, WgradPlan* pl, bool pre = false, bool smooth = false) {
+int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, WgradPlan* pl) {
     if (KH == 1 && KW == 1) dil = 1;
     pl->c7 = 0;
-    if (!pre) {
+    {
         // 16 -> 16 channels, 7x7 (conv7x7_c16.hip): its own kernel, its own slab count; nothing else of the plan is used
         const int ns = egm_conv_c7_wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil);
         if (ns > 0) {
@@ -1037,9 +885,8 @@ int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW
     static const int ws_on = getenv("EGM_WGRAD_WS") ? atoi(getenv("EGM_WGRAD_WS")) : 1;
     // (measured, profiles/r02_*: the 5-, 7- and 9-tap layers run 10-20 % faster wave-specialised; the 1- and 3-tap ones are
     //  stage-latency bound and keep the 4-wave kernel with two workgroups per CU)
-    // ... unless they carry operand prologues: the element-wise work belongs on producer waves, beside the MFMAs
-    const bool ws_family = dtype == EGM_BF16 && ws_on && (pl->ntaps >= 5 || pre);
-    pl->ws = (ws_family && !smooth) ? 1 : 0;
+    const bool ws_family = dtype == EGM_BF16 && ws_on && pl->ntaps >= 5;
+    pl->ws = ws_family ? 1 : 0;
     int per_cu = ws_family ? 1 : ((pl->ntaps <= 3 && dtype == EGM_BF16) ? per_cu_small : 1);
     // the wave-specialised kernel on the narrow layers (one 32 x 32 block, two 38 KB image pairs): EGM_WGRAD_WS_PER_CU workgroups per CU
     static const int ws_per_cu = getenv("EGM_WGRAD_WS_PER_CU") ? atoi(getenv("EGM_WGRAD_WS_PER_CU")) : 1;
@@ -1056,10 +903,8 @@ int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW
     static const int dma_off = getenv("EGM_WGRAD_NO_DMA") != nullptr;
     // (measured: 9 % faster on the 2 x 2-block layers, i.e. Cin, Cout > 32; slower on the narrow and the dilated ones, which keep
     //  the register-staged pipeline)
-    pl->dma = (dtype == EGM_BF16 && !pl->ws && !dma_off && !pre && A * B == 4 && pl->ntaps == 9 && 2 * pl->smem <= 156 * 1024) ? 1 : 0;
+    pl->dma = (dtype == EGM_BF16 && !pl->ws && !dma_off && A * B == 4 && pl->ntaps == 9 && 2 * pl->smem <= 156 * 1024) ? 1 : 0;
     if (pl->dma || pl->ws) pl->smem *= 2;
-    pl->cf_off = (int)pl->smem;
-    if (pre || pl->ws) pl->smem += (size_t)(4 * 32 * A + 2 * 32 * B) * sizeof(float);     // prologue coefficient rows behind the images
     const size_t red_bytes = pl->C > 1 ? (size_t)A * B * pl->ntaps * 16 * 64 * sizeof(float) : 0;   // cross-wave reduction buffer
     if (pl->smem < red_bytes) pl->smem = red_bytes;
     pl->slab_bytes = (long long)nsplit * KH * KW * Cout * Cin * (long long)sizeof(float);
@@ -1101,7 +946,7 @@ int launch_wgrad_group(const EgmGroupRec* recs, int n, hipStream_t st) {
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_wgrad_multi: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    return launch_wgrad_group_impl(recs, n, st, conv_wgrad_kernel<T, NTAPS, false>, conv_wgrad_multi_kernel<T, NTAPS>, 256, "conv_wgrad (group)");
+    return launch_wgrad_group_impl(recs, n, st, conv_wgrad_kernel<T, NTAPS>, conv_wgrad_multi_kernel<T, NTAPS>, 256, "conv_wgrad (group)");
 }
 template <int NTAPS, bool ROT>
 int launch_wgrad_ws_group(const EgmGroupRec* recs, int n, hipStream_t st) {
@@ -1112,9 +957,9 @@ int launch_wgrad_ws_group(const EgmGroupRec* recs, int n, hipStream_t st) {
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_wgrad_ws_multi: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    return launch_wgrad_group_impl(recs, n, st, conv_wgrad_ws_kernel<NTAPS, false, ROT>, conv_wgrad_ws_multi_kernel<NTAPS, ROT>, 512, "conv_wgrad_ws (group)");
+    return launch_wgrad_group_impl(recs, n, st, conv_wgrad_ws_kernel<NTAPS, ROT>, conv_wgrad_ws_multi_kernel<NTAPS, ROT>, 512, "conv_wgrad_ws (group)");
 }
-// records the launch when a group is open on this thread (only the prologue-free kernels have a merged form)
+// records the launch when a group is open on this thread
 inline bool wgrad_record(int (*fn)(const EgmGroupRec*, int, hipStream_t), const WgradParams& p, dim3 grid, size_t smem) {
     if (!egm_group_recording()) return false;
     static_assert(sizeof(WgradParams) + 3 * sizeof(int) <= sizeof(EgmGroupRec::params), "group record too small");
@@ -1127,56 +972,50 @@ inline bool wgrad_record(int (*fn)(const EgmGroupRec*, int, hipStream_t), const 
     egm_group_push(r);
     return true;
 }
-template <typename T, int NTAPS, bool PRE>
-int launch_wgrad_pre(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
+template <typename T, int NTAPS>
+int launch_wgrad_4w(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<T, NTAPS, PRE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<T, NTAPS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     dim3 grid(pl.nsplit, pl.nco_tiles * pl.nci_tiles, pl.ngroups);
-    if constexpr (!PRE) {
-        if (wgrad_record(&launch_wgrad_group<T, NTAPS>, p, grid, pl.smem)) return EGM_OK;
-    }
-    hipLaunchKernelGGL((conv_wgrad_kernel<T, NTAPS, PRE>), grid, dim3(256), pl.smem, st, p);
+    if (wgrad_record(&launch_wgrad_group<T, NTAPS>, p, grid, pl.smem)) return EGM_OK;
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, NTAPS>), grid, dim3(256), pl.smem, st, p);
     EGM_CHECK_LAUNCH("conv_wgrad");
     return EGM_OK;
 }
-template <int NTAPS, bool PRE, bool ROT>
+template <int NTAPS, bool ROT>
 int launch_wgrad_ws_rot(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ws_kernel<NTAPS, PRE, ROT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ws_kernel<NTAPS, ROT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_wgrad_ws: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     dim3 grid(pl.nsplit, pl.nco_tiles * pl.nci_tiles, pl.ngroups);
-    if constexpr (!PRE) {
-        if (wgrad_record(&launch_wgrad_ws_group<NTAPS, ROT>, p, grid, pl.smem)) return EGM_OK;
-    }
-    hipLaunchKernelGGL((conv_wgrad_ws_kernel<NTAPS, PRE, ROT>), grid, dim3(512), pl.smem, st, p);
+    if (wgrad_record(&launch_wgrad_ws_group<NTAPS, ROT>, p, grid, pl.smem)) return EGM_OK;
+    hipLaunchKernelGGL((conv_wgrad_ws_kernel<NTAPS, ROT>), grid, dim3(512), pl.smem, st, p);
     EGM_CHECK_LAUNCH("conv_wgrad_ws");
     return EGM_OK;
 }
-template <int NTAPS, bool PRE>
+template <int NTAPS>
 int launch_wgrad_ws(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     if constexpr (NTAPS == 9) {
         static const bool rot_on = getenv("EGM_WGRAD_ROT") ? atoi(getenv("EGM_WGRAD_ROT")) != 0 : true;
-        if (pl.C == 1 && rot_on) return launch_wgrad_ws_rot<NTAPS, PRE, true>(p, pl, st);
+        if (pl.C == 1 && rot_on) return launch_wgrad_ws_rot<NTAPS, true>(p, pl, st);
     }
-    return launch_wgrad_ws_rot<NTAPS, PRE, false>(p, pl, st);
+    return launch_wgrad_ws_rot<NTAPS, false>(p, pl, st);
 }
 template <typename T, int NTAPS>
 int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
-    const bool pre = p.prex.mode != EGM_PRE_NONE || p.predy.mode != EGM_PRE_NONE;
     if constexpr (sizeof(T) == 2) {
-        if (pl.ws) return pre ? launch_wgrad_ws<NTAPS, true>(p, pl, st) : launch_wgrad_ws<NTAPS, false>(p, pl, st);
+        if (pl.ws) return launch_wgrad_ws<NTAPS>(p, pl, st);
     }
-    if (pre) return launch_wgrad_pre<T, NTAPS, true>(p, pl, st);
-    return launch_wgrad_pre<T, NTAPS, false>(p, pl, st);
+    return launch_wgrad_4w<T, NTAPS>(p, pl, st);
 }
 
 template <typename T>
@@ -1207,29 +1046,26 @@ extern "C" long long egm_conv_wgrad_workspace(int N, int H, int W, int Cin, int 
     return a;
 }
 
-// Name of the kernel egm_conv_wgrad_pre launches for a shape, spelled like the rows of a rocprofv3 kernel trace (see egm_conv_kernel_name)
-extern "C" int egm_conv_wgrad_kernel_name(int dtype, int pre, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen) {
+// Name of the kernel egm_conv_wgrad launches for a shape, spelled like the rows of a rocprofv3 kernel trace (see egm_conv_kernel_name)
+extern "C" int egm_conv_wgrad_kernel_name(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen) {
     WgradPlan pl;
     if (KH == 1 && KW == 1) dil = 1;
-    if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl, pre != 0) != EGM_OK) return -1;
+    if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl) != EGM_OK) return -1;
     char tmp[96];
     static const bool rot_on = getenv("EGM_WGRAD_ROT") ? atoi(getenv("EGM_WGRAD_ROT")) != 0 : true;
     if (pl.c7) snprintf(tmp, sizeof(tmp), pl.c7 == 1 ? "conv7x7_c16_wgrad_kernel" : "conv3x3d_c16_wgrad_kernel");
     else if (dtype == EGM_BF16 && pl.ws)
-        snprintf(tmp, sizeof(tmp), "conv_wgrad_ws_kernel<%d, %s, %s>", pl.ntaps, pre ? "true" : "false", (pl.ntaps == 9 && pl.C == 1 && rot_on) ? "true" : "false");
+        snprintf(tmp, sizeof(tmp), "conv_wgrad_ws_kernel<%d, %s>", pl.ntaps, (pl.ntaps == 9 && pl.C == 1 && rot_on) ? "true" : "false");
     else
-        snprintf(tmp, sizeof(tmp), "conv_wgrad_kernel<%s, %d, %s>", dtype == EGM_BF16 ? "bf16_t" : "float", pl.ntaps, pre ? "true" : "false");
+        snprintf(tmp, sizeof(tmp), "conv_wgrad_kernel<%s, %d>", dtype == EGM_BF16 ? "bf16_t" : "float", pl.ntaps);
     const int n = (int)strlen(tmp);
     if (buf != nullptr && buflen > 0) { strncpy(buf, tmp, (size_t)buflen - 1); buf[buflen - 1] = 0; }
     return n;
 }
 extern "C" int egm_conv_wgrad_slabs(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil) {
-    return egm_conv_wgrad_slabs_pre(dtype, 0, N, H, W, Cin, Cout, KH, KW, dil);
-}
-extern "C" int egm_conv_wgrad_slabs_pre(int dtype, int pre, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil) {
     WgradPlan pl;
     if (KH == 1 && KW == 1) dil = 1;
-    if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl, pre != 0) != EGM_OK) return -1;
+    if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl) != EGM_OK) return -1;
     return pl.nsplit;
 }
 /* table: device array of {const float* slab; float* dw; int nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate;} (48 bytes) */
@@ -1244,22 +1080,7 @@ extern "C" int egm_wgrad_reduce_multi(const void* table_dev, int n, long long to
 extern "C" int egm_conv_wgrad(int dtype, const void* x, int ldx, const void* dy, int lddy, float* dw, void* workspace, int N,
                               int H, int W, int Cin, int Cout, int CinR, int CoutR, int KH, int KW, int dil, int groups,
                               int accumulate, egm_stream_t s) {
-    return egm_conv_wgrad_pre(dtype, x, ldx, EGM_PRE_NONE, 0, nullptr, dy, lddy, EGM_PRE_NONE, 0, nullptr, nullptr, 0, nullptr, 0, dw, workspace,
-                              N, H, W, Cin, Cout, CinR, CoutR, KH, KW, dil, groups, accumulate, s);
-}
-
-extern "C" int egm_conv_wgrad_pre(int dtype, const void* x, int ldx, int xpre_mode, int xpre_act, const float* xpre_cf, const void* dy,
-                                  int lddy, int dypre_mode, int dypre_act, const float* dypre_cf, const void* dypre_aux, int dypre_ld_aux,
-                                  void* dy_out, int ld_dy_out, float* dw, void* workspace, int N, int H, int W, int Cin, int Cout,
-                                  int CinR, int CoutR, int KH, int KW, int dil, int groups, int accumulate, egm_stream_t s) {
     EGM_REQUIRE(x && dy && workspace, "conv_wgrad: null pointer");
-    EGM_REQUIRE(xpre_mode == EGM_PRE_NONE || (xpre_mode == EGM_PRE_BN_ACT && xpre_cf), "conv_wgrad: x prologue must be NONE or BN_ACT with coefficients");
-    EGM_REQUIRE(dypre_mode == EGM_PRE_NONE || ((dypre_mode == EGM_PRE_BN_BWD || dypre_mode == EGM_PRE_BN_ACT) && dypre_cf),
-                "conv_wgrad: bad dy prologue");
-    EGM_REQUIRE(dypre_mode != EGM_PRE_BN_BWD || (dypre_aux && egm_aligned16(dypre_aux) && dypre_ld_aux >= Cout && dypre_ld_aux % 8 == 0),
-                "conv_wgrad: BN-backward prologue needs the BatchNorm input (aux) with ld >= Cout, multiple of 8");
-    EGM_REQUIRE(dy_out == nullptr || (dypre_mode != EGM_PRE_NONE && egm_aligned16(dy_out) && ld_dy_out >= Cout && ld_dy_out % 8 == 0),
-                "conv_wgrad: dy_out needs a dy prologue, 16-byte alignment and ld >= Cout, multiple of 8");
     EGM_REQUIRE(N > 0 && H > 0 && W > 0, "conv_wgrad: bad shape");
     EGM_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && Cin > 0 && Cout > 0, "conv_wgrad: padded channels must be multiples of 8");
     EGM_REQUIRE(CinR <= Cin && CoutR <= Cout && CinR > 0 && CoutR > 0 && groups > 0 && CinR % groups == 0 && CoutR % groups == 0,
@@ -1269,20 +1090,10 @@ extern "C" int egm_conv_wgrad_pre(int dtype, const void* x, int ldx, int xpre_mo
     EGM_REQUIRE(dil >= 1 && (KH & 1) && (KW & 1), "conv_wgrad: bad kernel");
     if (KH == 1 && KW == 1) dil = 1;
     WgradPlan pl;
-    const bool pre = xpre_mode != EGM_PRE_NONE || dypre_mode != EGM_PRE_NONE;
-    // the wave-specialised kernel builds: x = BN_ACT, dy = BN_BWD, activations ReLU / none; anything else takes the 4-wave kernel
-    const bool smooth = (xpre_mode != EGM_PRE_NONE && xpre_act != EGM_ACT_RELU && xpre_act != EGM_ACT_NONE) ||
-                        (dypre_mode != EGM_PRE_NONE && dypre_act != EGM_ACT_RELU && dypre_act != EGM_ACT_NONE) ||
-                        dypre_mode == EGM_PRE_BN_ACT;
-    if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl, pre, smooth) != EGM_OK)
+    if (wgrad_plan(dtype, N, H, W, Cin, Cout, KH, KW, dil, &pl) != EGM_OK)
         EGM_FAIL(EGM_ERR_UNSUPPORTED, "conv_wgrad: unsupported kernel %dx%d dil %d", KH, KW, dil);
     EGM_REQUIRE(pl.smem <= 160 * 1024, "conv_wgrad: LDS budget exceeded");
     WgradParams p;
-    p.prex.mode = xpre_mode; p.prex.act = xpre_act; p.prex.cf = xpre_cf; p.prex.aux = nullptr; p.prex.ld_aux = 0; p.prex.C = Cin;
-    p.predy.mode = dypre_mode; p.predy.act = dypre_act; p.predy.cf = dypre_cf; p.predy.aux = dypre_aux; p.predy.ld_aux = dypre_ld_aux;
-    p.predy.C = Cout; p.cf_off = pl.cf_off;
-    p.dy_out = dy_out; p.ld_dy_out = ld_dy_out;
-    p.out_grp = (pl.ntaps == 3 && dil > 1) ? 1 : (pl.ngroups == 9 ? 4 : 0);       // a tap group with zero row/column offset: it skips no tile
     p.x = x; p.dy = dy; p.slab = (float*)workspace; p.ldx = ldx; p.lddy = lddy; p.N = N; p.H = H; p.W = W;
     p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.dil = dil; p.tiles_y = pl.tiles_y; p.tiles_x = pl.tiles_x;
     p.npt = pl.npt; p.nsplit = pl.nsplit; p.A = pl.A; p.B = pl.B; p.C = pl.C; p.nci_tiles = pl.nci_tiles; p.ngroups = pl.ngroups;
@@ -1301,14 +1112,21 @@ extern "C" int egm_conv_wgrad_pre(int dtype, const void* x, int ldx, int xpre_mo
     if (rc == EGM_ERR_ARG && dtype != EGM_BF16 && dtype != EGM_F32) EGM_FAIL(EGM_ERR_ARG, "conv_wgrad: unknown dtype %d", dtype);
     if (rc != EGM_OK) return rc;
     if (dw == nullptr) return EGM_OK;                  // slabs only: the caller reduces later with egm_wgrad_reduce_multi
-    const long long total = (long long)KH * KW * Cout * Cin;
+    return egm_wgrad_reduce((const float*)workspace, dw, pl.nsplit, KH * KW, Cout, Cin, CoutR, CinR, groups, accumulate, s);
+}
+
+/* slabs [nslab][taps][CoutP][CinP] summed in slab order -> dw fp32 OIHW (real, possibly grouped, shape); one convolution, at once */
+extern "C" int egm_wgrad_reduce(const float* slabs, float* dw, int nslab, int taps, int CoutP, int CinP, int CoutR, int CinR, int groups,
+                                int accumulate, egm_stream_t s) {
+    EGM_REQUIRE(slabs && dw && nslab > 0 && taps > 0 && CoutP > 0 && CinP > 0 && CoutR > 0 && CoutR <= CoutP && CinR > 0 && CinR <= CinP && groups > 0,
+                "wgrad_reduce: bad args");
+    hipStream_t st = (hipStream_t)s;
+    const long long total = (long long)taps * CoutP * CinP;
     const int grid = (int)((total + 63) / 64);
-    if (pl.nsplit >= 256 && grid < 1024)               // many slabs of a small gradient: more slab lanes per element
-        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(grid), dim3(1024), 0, st, (const float*)workspace, dw, pl.nsplit,
-                           KH * KW, Cout, Cin, CoutR, CinR, groups, accumulate);
+    if (nslab >= 256 && grid < 1024)                   // many slabs of a small gradient: more slab lanes per element
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(grid), dim3(1024), 0, st, slabs, dw, nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate);
     else
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, (const float*)workspace, dw, pl.nsplit,
-                           KH * KW, Cout, Cin, CoutR, CinR, groups, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, st, slabs, dw, nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate);
     EGM_CHECK_LAUNCH("wgrad_reduce");
     return EGM_OK;
 }

@@ -15,7 +15,7 @@
 // element in window scan order (the forward stencil records the arg-max/arg-min window positions as one byte per
 // element for the backward gather).
 #include "common.h"
-#include "prologue.h"
+#include "bn_elem.h"
 #include <stdlib.h>
 
 namespace {

@@ -12,7 +12,7 @@
 // The element formulas and rounding points are those of the separate kernels (bn.hip, blocks.hip, pool_up.hip): results are bit-identical
 // except for the fp32 BatchNorm partial sums, which are accumulated in a different pixel order.
 #include "common.h"
-#include "prologue.h"
+#include "bn_elem.h"
 
 namespace {
 

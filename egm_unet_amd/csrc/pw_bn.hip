@@ -26,7 +26,7 @@
 // tile; the weights are staged once per workgroup, so the main loops contain no workgroup barrier.
 // Limits: padded Cin <= 128, stacked padded Cout of the heads sharing one x <= 128, <= 2 heads per x, <= 4 inputs per launch.
 #include "common.h"
-#include "prologue.h"
+#include "bn_elem.h"
 #include <algorithm>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;

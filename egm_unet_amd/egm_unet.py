@@ -90,10 +90,10 @@ class BasicConv(nn.Module):
         self.relu = nn.ReLU(inplace=True) if relu else None
         self._dil, self._groups = dilation, groups
 
-    def forward(self, x, out=None, lazy=False):
-        """x: NHWC tensor or ops.Lazy; lazy=True returns an ops.Lazy for a consuming convolution (no BatchNorm apply pass)."""
+    def forward(self, x, out=None):
+        """x: NHWC tensor; out: optional destination view (a concat slot)"""
         return ops.conv_bn_act(x, self.conv, self.bn, ACT_RELU if self.relu is not None else ACT_NONE, dil=self._dil,
-                               groups=self._groups, out=out, lazy=lazy)
+                               groups=self._groups, out=out)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -199,14 +199,10 @@ class EdgeEnhancedGRFB(nn.Module):
 
     @staticmethod
     def _seq(seq, x, out):
-        """nn.Sequential of blocks whose last BasicConv writes into the concat slot `out`.  A BasicConv followed by another
-        BasicConv hands its result on as an ops.Lazy: that BatchNorm(+ReLU) is applied by the next conv's operand prologue."""
+        """nn.Sequential of blocks whose last BasicConv writes into the concat slot `out`."""
         mods = list(seq)
-        for k, m in enumerate(mods[:-1]):
-            if isinstance(m, BasicConv):
-                x = m(x, lazy=isinstance(mods[k + 1], BasicConv))
-            else:
-                x = m(ops.materialize(x))
+        for m in mods[:-1]:
+            x = m(x)
         return mods[-1](x, out=out)
 
     def cat_buffer(self, N, H, W, dtype, device):
@@ -231,37 +227,32 @@ class EdgeEnhancedGRFB(nn.Module):
         else:
             buf, sd, se, sc = None, None, None, None
         bd, be, bc = self.branch_dir, self.branch_edge, self.branch_ctx
-        pw_heads = not ops.fuse_bn() and ops.pw_applicable(xe, [bd[0].conv, be[0].conv], "heads")
+        pw_heads = ops.pw_applicable(xe, [bd[0].conv, be[0].conv], "heads")
         if pw_heads:
             xe_d, xe_c = ops.fork(xe, 2)
             xe_e = None
         else:
             xe_d, xe_e, xe_c = ops.fork(xe, 3)
-        if ops.fuse_bn():
-            d = self._seq(self.branch_dir, xe_d, sd)                  # operand-prologue path: one branch after the other
-            e = self._seq(self.branch_edge, xe_e, se)
-            c = self._seq(self.branch_ctx, xe_c, sc)
-        else:
-            # The three branches are independent and work on 8-32 channel tensors whose BatchNorm passes are launch-latency bound:
-            # they advance in lockstep, and layers of equal depth share their BatchNorm launches (ops.multi_conv_bn_act).
-            def item(m, t, o=None):
-                return (t, m.conv, m.bn, ACT_RELU if m.relu is not None else ACT_NONE, m._dil, m._groups, o)
+        # The three branches are independent and work on 8-32 channel tensors whose BatchNorm passes are launch-latency bound:
+        # they advance in lockstep, and layers of equal depth share their BatchNorm launches (ops.multi_conv_bn_act).
+        def item(m, t, o=None):
+            return (t, m.conv, m.bn, ACT_RELU if m.relu is not None else ACT_NONE, m._dil, m._groups, o)
 
-            def head(m, o=None):
-                return (m.conv, m.bn, ACT_RELU if m.relu is not None else ACT_NONE, None, None, 1.0, o)
-            if pw_heads:
-                # the two 1x1 heads read the same tensor: ONE moment pass, ONE streaming pass with the stacked weights (csrc/pw_bn.hip)
-                d, e = ops.pw_conv_bn([(xe_d, [head(bd[0]), head(be[0])])])
-                c = bc[0](xe_c)
-            else:
-                d, e, c = ops.multi_conv_bn_act([item(bd[0], xe_d), item(be[0], xe_e), item(bc[0], xe_c)])     # heads: 1x1, 1x1, 3x3
-            e = be[1](e)                                                                                  # EdgeAwareFeatureEnhancer(i)
-            e, c = ops.multi_conv_bn_act([item(be[2], e), item(bc[1], c)])                                # grouped 3x3
-            d, e, c = ops.multi_conv_bn_act([item(bd[1], d), item(be[3], e), item(bc[2], c)])             # dilated 3x3 (12 / 24 / 36)
-            if all(ops.pw_applicable(t, [m.conv], "tails") for m, t in ((bd[2], d), (be[4], e), (bc[3], c))):
-                d, e, c = ops.pw_conv_bn([(d, [head(bd[2], sd)]), (e, [head(be[4], se)]), (c, [head(bc[3], sc)])])  # 1x1 tails -> concat slots
-            else:
-                d, e, c = ops.multi_conv_bn_act([item(bd[2], d, sd), item(be[4], e, se), item(bc[3], c, sc)])
+        def head(m, o=None):
+            return (m.conv, m.bn, ACT_RELU if m.relu is not None else ACT_NONE, None, None, 1.0, o)
+        if pw_heads:
+            # the two 1x1 heads read the same tensor: ONE moment pass, ONE streaming pass with the stacked weights (csrc/pw_bn.hip)
+            d, e = ops.pw_conv_bn([(xe_d, [head(bd[0]), head(be[0])])])
+            c = bc[0](xe_c)
+        else:
+            d, e, c = ops.multi_conv_bn_act([item(bd[0], xe_d), item(be[0], xe_e), item(bc[0], xe_c)])     # heads: 1x1, 1x1, 3x3
+        e = be[1](e)                                                                                  # EdgeAwareFeatureEnhancer(i)
+        e, c = ops.multi_conv_bn_act([item(be[2], e), item(bc[1], c)])                                # grouped 3x3
+        d, e, c = ops.multi_conv_bn_act([item(bd[1], d), item(be[3], e), item(bc[2], c)])             # dilated 3x3 (12 / 24 / 36)
+        if all(ops.pw_applicable(t, [m.conv], "tails") for m, t in ((bd[2], d), (be[4], e), (bc[3], c))):
+            d, e, c = ops.pw_conv_bn([(d, [head(bd[2], sd)]), (e, [head(be[4], se)]), (c, [head(bc[3], sc)])])  # 1x1 tails -> concat slots
+        else:
+            d, e, c = ops.multi_conv_bn_act([item(bd[2], d, sd), item(be[4], e, se), item(bc[3], c, sc)])
         cat = ops.cat_channels([x_cat, d, e, c], buf)
         out_f = self.fusion_conv(cat)
         # relu(out*scale + BN(conv1x1(x))): the shortcut's BatchNorm apply and the residual ReLU are one pass (csrc/bn_fused.hip)
@@ -475,7 +466,7 @@ class DoubleConv1(nn.Sequential):
             else:
                 x = self[3](ops.conv_bn_act(x, self[0], self[1], ACT_RELU))
         else:
-            x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU, lazy=True)        # consumed by a conv
+            x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU)
         # the second conv's BatchNorm+ReLU writes the GRFB's input straight into slot 0 of the GRFB's concat buffer
         grfb = self[6 + o]
         N, H, W = x.shape[0], x.shape[1], x.shape[2]
@@ -540,5 +531,5 @@ class GRFBUNet(_SegNetBase):
         y = self.up1(x5, x4s, bufs[3])
         y = self.up2(y, x3s, bufs[2])
         y = self.up3(y, x2s, bufs[1])
-        y = self.up4(y, x1s, bufs[0], lazy="force" if ops.fuse_cls() else True)   # the 1x1 classifier applies up4's last BatchNorm+ReLU itself
+        y = self.up4(y, x1s, bufs[0], lazy="force" if ops.fuse_cls() else False)   # the 1x1 classifier applies up4's last BatchNorm+ReLU itself
         return self._exit(self.out_conv(y, sole_consumer=True))

@@ -10,7 +10,7 @@ import weakref
 import torch
 from torch.autograd import Function, Variable
 
-from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, PRE_BN_ACT, PRE_BN_BWD, PRE_NONE, dtype_code, lib, ptr, stream  # noqa: F401
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, dtype_code, lib, ptr, stream  # noqa: F401
 
 
 def pad8(c: int) -> int:
@@ -375,35 +375,14 @@ def _channel_sum(t):
 
 
 _DEFER_WGRAD = os.environ.get("EGM_DEFER_WGRAD", "1") != "0"
-# environment switch for A/B runs and for the bit-exactness test of the fused path against the materialised one
-_FUSE_BN = os.environ.get("EGM_FUSE_BN", "0") != "0"
-# BatchNorm backward: 1 = dy computed inside the weight-gradient kernel's staging (by-product for the data gradient),
-# 0 = stand-alone egm_bn_act_bwd_apply pass
-_FUSE_BN_BWD = os.environ.get("EGM_FUSE_BN_BWD", "0") != "0"
-
-
-# A/B switch for the size-selective prologue policy (VERDICT r03 item 6 ii): only the DoubleConvs whose second conv has <= 32 output
-# channels (the 4-wave kernel's layers, where the LDS-DMA tile kernel is not offered anyway) fold the first BatchNorm+ReLU into it
-_FUSE_BN_NARROW = os.environ.get("EGM_FUSE_BN_NARROW", "0") != "0"
-
-
-def fuse_bn_narrow():
-    return _FUSE_BN_NARROW
-
-
-def fuse_bn(enabled=None):
-    """Get / set whether BatchNorm(+activation) is folded into consuming convolutions (Lazy tensors).  Both settings compute the same
-    arithmetic; the materialised form (False) exists for A/B timing and for the bit-exactness test."""
-    global _FUSE_BN
-    if enabled is not None:
-        _FUSE_BN = bool(enabled)
-    return _FUSE_BN
-
 
 class Lazy:
     """A logical activation z = act(scale*y + shift) that has NOT been written to memory: `y` is the raw conv output (the autograd
     stand-in: its gradient is, by convention, dL/dz), `coef` the fp32 [4, C] rows scale | shift | mean | rstd of the BatchNorm.
-    Convolutions consume it directly (operand prologue EGM_PRE_BN_ACT); everything else calls materialize()."""
+    Handed to a consumer whose first pass applies the BatchNorm itself and writes the tensor on the way (the MCALayer's statistics pass,
+    the classifier inside the apply pass, the fused skip-connection pool); everything else calls materialize().
+    (Rounds 2-3 also let convolutions consume it through operand prologues; measured slower three times -- DESIGN.md 6.2, 6.4, 6.5 --
+    and removed in round 4.)"""
     __slots__ = ("y", "coef", "act")
 
     def __init__(self, y, coef, act):
@@ -444,7 +423,7 @@ class _Materialize(Function):
 
 
 def _unlazy(x):
-    """-> (tensor, coef or None, act): the memory operand of a conv and its prologue"""
+    """-> (tensor, coef or None, act): a consumer's memory operand and the BatchNorm + activation it has to apply to it"""
     if isinstance(x, Lazy):
         return x.y, x.coef, x.act
     return x, None, ACT_NONE
@@ -488,8 +467,8 @@ class conv_group:
         return False
 
 
-def _conv_forward(x, ldx, x_coef, x_act, weight, bias, dil, groups, want_stats):
-    """The conv launch shared by _Conv2d and _ConvBN: y = conv(prologue(x), weight) (+bias), optional BN partial statistics."""
+def _conv_forward(x, ldx, weight, bias, dil, groups, want_stats):
+    """The conv launch shared by _Conv2d and _ConvBN: y = conv(x, weight) (+bias), optional BN partial statistics."""
     N, H, W, CinP = x.shape
     Cout, Cin_g, KH, KW = weight.shape
     Cin = Cin_g * groups
@@ -499,14 +478,13 @@ def _conv_forward(x, ldx, x_coef, x_act, weight, bias, dil, groups, want_stats):
     L, dt = lib(), dtype_code(x.dtype)
     wf, wd = _packed_weights(weight, groups, x.dtype)
     y = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=x.device)
-    pre = PRE_BN_ACT if x_coef is not None else PRE_NONE
     stats = None
     if want_stats:
-        ntiles = L.query("egm_conv_stats_tiles_pre", dt, pre, N, H, W, CinP, CoutP, KH, KW, dil)
+        ntiles = L.query("egm_conv_stats_tiles", dt, N, H, W, CinP, CoutP, KH, KW, dil)
         stats = _f32((ntiles, 2, CoutP), x.device)
     b = bias.detach() if bias is not None else None
-    L.call("egm_conv_fwd_pre", dt, ptr(x), ldx, pre, x_act, ptr(x_coef), None, 0, ptr(wf), ptr(b), Cout if b is not None else 0, ptr(y),
-           CoutP, ptr(stats), N, H, W, CinP, CoutP, KH, KW, dil, stream())
+    L.call("egm_conv_fwd", dt, ptr(x), ldx, ptr(wf), ptr(b), Cout if b is not None else 0, ptr(y), CoutP, ptr(stats), N, H, W, CinP, CoutP,
+           KH, KW, dil, stream())
     return y, stats, wd
 
 
@@ -549,12 +527,14 @@ def _c1_shape_ok(x, gy, weight, dil, groups):
 
 
 def _conv1x1_bwd(items):
-    """items: up to 4 tuples (x, ldx, dy, lddy, weight, wd, need_gx) of 1x1 convs whose weight gradients are deferrable -> [(gx, gw)].
-    ONE launch writes every dx and every slab set; the slabs join the deferred multi-conv reduction like _conv_wgrad's."""
+    """items: up to 4 tuples (x, ldx, dy, lddy, weight, wd, need_gx, defer) of 1x1 convs -> [(gx, gw)].  ONE launch writes every dx and
+    every slab set; the slabs of a deferrable weight join the deferred multi-conv reduction like _conv_wgrad's, the others are reduced
+    at once.  (The kernel choice must not depend on `defer`: a weight is not deferrable when its conv's backward runs a second time --
+    the split data-parallel step re-runs the bottleneck -- and both runs have to produce the same dx bit for bit.)"""
     L, st = lib(), stream()
-    descs, res, keep = [], [], []
+    descs, res, now = [], [], []
     dt = dtype_code(items[0][0].dtype)
-    for x, ldx, dy, lddy, weight, wd, need_gx in items:
+    for x, ldx, dy, lddy, weight, wd, need_gx, defer in items:
         N, H, W, CinP = x.shape
         CoutP, npix = dy.shape[3], _npix(x)
         Cout, Cin = weight.shape[0], weight.shape[1]
@@ -564,35 +544,34 @@ def _conv1x1_bwd(items):
         gw = torch.empty_like(weight)
         descs.append(_C1_DESC.pack(x.data_ptr(), dy.data_ptr(), wd.data_ptr(), 0 if gx is None else gx.data_ptr(), ws.data_ptr(), npix, ldx, lddy,
                                    CinP, CinP, CoutP, 0))
-        _queue_wgrad(ws, weight, nslab, 1, CoutP, CinP, Cout, Cin, 1, gw)
+        if defer:
+            _queue_wgrad(ws, weight, nslab, 1, CoutP, CinP, Cout, Cin, 1, gw)
+        else:
+            now.append((ws, gw, nslab, CoutP, CinP, Cout, Cin))
         res.append((gx, gw))
-        keep.append(ws)
     L.call("egm_conv1x1_bwd", dt, b"".join(descs), len(descs), st)
+    for ws, gw, nslab, CoutP, CinP, Cout, Cin in now:
+        L.call("egm_wgrad_reduce", ptr(ws), ptr(gw), nslab, 1, CoutP, CinP, Cout, Cin, 1, 0, st)
     return res
 
 
-def _conv_grads(x, ldx, x_coef, x_act, dy, weight, wd, dil, groups, Cin, Cout, need_gx, need_gw, x_split=0):
+def _conv_grads(x, ldx, dy, weight, wd, dil, groups, Cin, Cout, need_gx, need_gw, x_split=0):
     """(data gradient, weight gradient) of a conv from a materialised dy [N, H, W, CoutP] (contiguous): one fused launch for a 1x1 conv
     whose weight gradient is deferrable, the weight-gradient slab kernel followed by the data-gradient conv otherwise."""
     N, H, W, CinP = x.shape
     CoutP = dy.shape[3]
-    defer = None
-    if need_gw and x_coef is None and not x_split and _c1_shape_ok(x, dy, weight, dil, groups):
-        defer = _wgrad_deferrable(weight)
-        if defer:
-            return _conv1x1_bwd([(x, ldx, dy, CoutP, weight, wd, need_gx)])[0]
+    if need_gw and not x_split and _c1_shape_ok(x, dy, weight, dil, groups):
+        return _conv1x1_bwd([(x, ldx, dy, CoutP, weight, wd, need_gx, _wgrad_deferrable(weight))])[0]
     gx = gw = None
     if need_gw:
-        gw = _conv_wgrad(x, ldx, x_coef, x_act, dy, CoutP, None, None, weight, dil, groups, Cin, Cout, defer=defer)
+        gw = _conv_wgrad(x, ldx, dy, CoutP, weight, dil, groups, Cin, Cout)
     if need_gx:
         gx = _conv_dgrad(dy, wd, N, H, W, CoutP, CinP, weight.shape[2], weight.shape[3], dil, x_split)
     return gx, gw
 
 
-def _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, dy_pre, dy_out, weight, dil, groups, Cin, Cout, defer=None):
-    """Weight gradient of one conv (operands may be logical, see egm_conv_wgrad_pre); deferred slab reduction when that is safe.
-    dy_pre: None or (act, cf4 [4, CoutP], y, ldy) = the BatchNorm backward computed while staging; dy_out: tensor that receives the
-    logical dy as a by-product (or None)."""
+def _conv_wgrad(x, ldx, gy, ldg, weight, dil, groups, Cin, Cout, defer=None):
+    """Weight gradient of one conv; deferred slab reduction when that is safe."""
     N, H, W, CinP = x.shape
     CoutP = gy.shape[3]
     KH, KW = weight.shape[2], weight.shape[3]
@@ -602,16 +581,10 @@ def _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, dy_pre, dy_out, weight, dil, gro
     ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=x.device)
     if defer is None:                     # (a caller that asked already -- _wgrad_deferrable consumes the use note -- passes the answer)
         defer = _wgrad_deferrable(weight)
-    xm = PRE_BN_ACT if x_coef is not None else PRE_NONE
-    if dy_pre is None:
-        dm, dact, dcf, daux, dld = PRE_NONE, 0, None, None, 0
-    else:
-        dm, (dact, dcf, daux, dld) = PRE_BN_BWD, dy_pre
-    L.call("egm_conv_wgrad_pre", dt, ptr(x), ldx, xm, x_act, ptr(x_coef), ptr(gy), ldg, dm, dact, ptr(dcf), ptr(daux), dld,
-           ptr(dy_out), CoutP if dy_out is not None else 0, None if defer else ptr(gw), ptr(ws), N, H, W, CinP, CoutP, Cin, Cout,
-           KH, KW, dil, groups, 0, st)
+    L.call("egm_conv_wgrad", dt, ptr(x), ldx, ptr(gy), ldg, None if defer else ptr(gw), ptr(ws), N, H, W, CinP, CoutP, Cin, Cout, KH, KW, dil,
+           groups, 0, st)
     if defer:
-        nslab = L.query("egm_conv_wgrad_slabs_pre", dt, 1 if (xm != PRE_NONE or dm != PRE_NONE) else 0, N, H, W, CinP, CoutP, KH, KW, dil)
+        nslab = L.query("egm_conv_wgrad_slabs", dt, N, H, W, CinP, CoutP, KH, KW, dil)
         _queue_wgrad(ws, weight, nslab, KH * KW, CoutP, CinP, Cout, Cin, groups, gw)
     return gw
 
@@ -659,25 +632,24 @@ def _defer_dz(standin, payload):
 
 
 def _dz_fusable(C):
-    return _FUSE_DZ and not _FUSE_BN_BWD and C % 8 == 0 and C <= 1024 and 256 % (C // 8) == 0
+    return _FUSE_DZ and C % 8 == 0 and C <= 1024 and 256 % (C // 8) == 0
 
 
 class _Conv2d(Function):
-    """nn.Conv2d (stride 1, same padding) on NHWC activations; weight stays the fp32 OIHW nn.Parameter.  The input may be a logical
-    tensor (x = stand-in, x_coef / x_act = its BatchNorm + activation, applied by the kernels' operand prologue)."""
+    """nn.Conv2d (stride 1, same padding) on NHWC activations; weight stays the fp32 OIHW nn.Parameter."""
 
     @staticmethod
-    def forward(ctx, x, x_coef, x_act, weight, bias, dil, groups, want_stats, bias_grad_zero=False, defer_dgrad=False):
+    def forward(ctx, x, weight, bias, dil, groups, want_stats, bias_grad_zero=False, defer_dgrad=False):
         x, ldx = _nhwc(x)
         Cout, Cin_g = weight.shape[0], weight.shape[1]
-        y, stats, wd = _conv_forward(x, ldx, x_coef, x_act, weight, bias, dil, groups, want_stats)
-        if ctx.needs_input_grad[3]:
+        y, stats, wd = _conv_forward(x, ldx, weight, bias, dil, groups, want_stats)
+        if ctx.needs_input_grad[1]:
             _note_conv_use(weight)
-        ctx.save_for_backward(x, weight, wd, x_coef)
-        ctx.meta = (dil, groups, bias is not None, Cin_g * groups, Cout, x_act)
+        ctx.save_for_backward(x, weight, wd)
+        ctx.meta = (dil, groups, bias is not None, Cin_g * groups, Cout)
         ctx.bias_grad_zero = bias_grad_zero
         # the caller vouches that x is the materialised output of a conv -> BatchNorm(+act) node and has no other consumer
-        ctx.defer_dgrad = bool(defer_dgrad and x_coef is None and weight.shape[2] == 1 and weight.shape[3] == 1 and groups == 1
+        ctx.defer_dgrad = bool(defer_dgrad and weight.shape[2] == 1 and weight.shape[3] == 1 and groups == 1
                                and Cout <= 8 and weight.is_contiguous() and _dz_fusable(x.shape[3]))
         ctx.set_materialize_grads(False)                # no zero-filled "gradient" for the non-differentiable stats output
         if want_stats:
@@ -688,9 +660,9 @@ class _Conv2d(Function):
     @staticmethod
     def backward(ctx, gy, *_):
         if gy is None:
-            return (None,) * 10
-        x, weight, wd, x_coef = ctx.saved_tensors
-        dil, groups, has_bias, Cin, Cout, x_act = ctx.meta
+            return (None,) * 8
+        x, weight, wd = ctx.saved_tensors
+        dil, groups, has_bias, Cin, Cout = ctx.meta
         gy, ldg = _nhwc(gy)
         x, ldx = _nhwc(x)
         N, H, W, CinP = x.shape
@@ -698,35 +670,30 @@ class _Conv2d(Function):
         KH, KW = weight.shape[2], weight.shape[3]
         L, dt, st = lib(), dtype_code(x.dtype), stream()
         gx = gw = gb = None
-        if (ctx.needs_input_grad[3] and x_coef is None and not (ctx.needs_input_grad[0] and ctx.defer_dgrad and _FUSE_DZ)
-                and _c1_shape_ok(x, gy, weight, dil, groups)):
-            defer = _wgrad_deferrable(weight)
-            if defer:
-                gx, gw = _conv1x1_bwd([(x, ldx, gy, ldg, weight, wd, ctx.needs_input_grad[0])])[0]
-                if has_bias and ctx.needs_input_grad[4]:
-                    gb = _zero_grad_vec(Cout, x.device) if ctx.bias_grad_zero else _channel_sum(gy)[0, :Cout]
-                return gx, None, None, gw, gb, None, None, None, None, None
-            gw = _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, None, None, weight, dil, groups, Cin, Cout, defer=False)
-        if ctx.needs_input_grad[0]:
+        need_gx, need_gw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = _zero_grad_vec(Cout, x.device) if ctx.bias_grad_zero else _channel_sum(gy)[0, :Cout]
+        if need_gw and not (need_gx and ctx.defer_dgrad and _FUSE_DZ) and _c1_shape_ok(x, gy, weight, dil, groups):
+            # 1x1: data gradient + weight-gradient slabs from ONE pass over gy and x
+            gx, gw = _conv1x1_bwd([(x, ldx, gy, ldg, weight, wd, need_gx, _wgrad_deferrable(weight))])[0]
+            return gx, gw, gb, None, None, None, None, None
+        if need_gx:
             gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=x.device)
             if ctx.defer_dgrad and _FUSE_DZ:
                 # never written: the BatchNorm backward in front computes dz = gy * W per vector itself (egm_bn_cls_bwd_*)
                 _defer_dz(gx, ("cls", gy, ldg, weight.detach(), Cout, Cin))
             else:
                 L.call("egm_conv_fwd", dt, ptr(gy), ldg, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
-        if ctx.needs_input_grad[3] and gw is None:
-            gw = _conv_wgrad(x, ldx, x_coef, x_act, gy, ldg, None, None, weight, dil, groups, Cin, Cout)
-        if has_bias and ctx.needs_input_grad[4]:
-            gb = _zero_grad_vec(Cout, x.device) if ctx.bias_grad_zero else _channel_sum(gy)[0, :Cout]
-        return gx, None, None, gw, gb, None, None, None, None, None
+        if need_gw and gw is None:
+            gw = _conv_wgrad(x, ldx, gy, ldg, weight, dil, groups, Cin, Cout)
+        return gx, gw, gb, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, dil=1, groups=1, want_stats=False, bias_grad_zero=False, defer_dgrad=False):
-    """x: NHWC tensor or Lazy (consumed through the conv's operand prologue, never materialised).
+    """x: NHWC tensor (a Lazy is materialised first).
     defer_dgrad: x is the materialised result of ops.conv_bn_act and feeds nothing else -- a 1x1 conv to <= 8 channels (the classifier)
     then leaves its data gradient to that BatchNorm's backward (see _defer_dz)."""
-    xt, xc, xa = _unlazy(x)
-    return _Conv2d.apply(xt, xc, xa, weight, bias, dil, groups, want_stats, bias_grad_zero, defer_dgrad)
+    return _Conv2d.apply(materialize(x), weight, bias, dil, groups, want_stats, bias_grad_zero, defer_dgrad)
 
 
 def _conv_dgrad(dy, wd, N, H, W, CoutP, CinP, KH, KW, dil, x_split):
@@ -790,7 +757,7 @@ class _BnActCls(Function):
         L.call("egm_nchw_to_nhwc", dt, ptr(g), ptr(dl), 8, N, nc, H, W, st)
         gy = gw = gb = None
         if ctx.needs_input_grad[3]:
-            gw = _conv_wgrad(z, C, None, ACT_NONE, dl, 8, None, None, weight, 1, 1, Cin, nc)
+            gw = _conv_wgrad(z, C, dl, 8, weight, 1, 1, Cin, nc)
         if has_bias and ctx.needs_input_grad[4]:
             gb = _channel_sum(dl)[0, :nc]
         if ctx.needs_input_grad[0]:
@@ -818,21 +785,19 @@ def bn_act_cls(x, weight, bias):
 class _ConvBN(Function):
     """conv -> BatchNorm (-> act, applied by whoever consumes the result) as ONE autograd node.
 
-    forward : y = conv(prologue(x)) with the BN statistics from the conv epilogue; egm_bn_finalize -> coef.  Returns the RAW conv
-              output y as the stand-in of the logical z = act(scale*y + shift), and coef (see Lazy).
-    backward: receives dL/dz.  Partial sums (dz, y) -> egm_bn_bwd_coefs -> the weight-gradient kernel computes dy = f(dz, y) while
-              staging it (EGM_PRE_BN_BWD) and writes it out once as a by-product; the data gradient reads that.  No BatchNorm apply
-              pass in either direction."""
+    forward : y = conv(x) with the BN statistics from the conv epilogue; egm_bn_finalize -> coef.  Returns the RAW conv output y as the
+              stand-in of the logical z = act(scale*y + shift), and coef (see Lazy).
+    backward: receives dL/dz (or a stand-in whose producer left dz to this node, see _defer_dz).  Partial sums (dz, y) ->
+              egm_bn_bwd_coefs -> dy in one apply pass -> the conv's weight and data gradients."""
 
     @staticmethod
-    def forward(ctx, x, x_coef, x_act, weight, bias, gamma, beta, running_mean, running_var, eps, momentum, act, training, dil, groups,
-                x_split=0):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, eps, momentum, act, training, dil, groups, x_split=0):
         """x_split = Cs > 0: x is a channel concatenation [Cs | rest] with no other consumer (ops.upcat): backward writes the gradient
         as two dense tensors where the kernel can (egm_conv_fwd_split) and hands them to the concat's backward (see _defer_dz)."""
         x, ldx = _nhwc(x)
-        ctx.x_split = int(x_split) if (x_coef is None and x_split and 0 < x_split < x.shape[3] and x_split % 8 == 0) else 0
+        ctx.x_split = int(x_split) if (x_split and 0 < x_split < x.shape[3] and x_split % 8 == 0) else 0
         Cout, Cin_g = weight.shape[0], weight.shape[1]
-        y, stats, wd = _conv_forward(x, ldx, x_coef, x_act, weight, bias, dil, groups, training)
+        y, stats, wd = _conv_forward(x, ldx, weight, bias, dil, groups, training)
         CoutP, npix, dev = y.shape[3], _npix(y), y.device
         L, st = lib(), stream()
         coef = _f32((4, CoutP), dev)                    # scale, shift, save_mean, save_rstd
@@ -842,10 +807,10 @@ class _ConvBN(Function):
         else:
             L.call("egm_bn_eval_coeffs", ptr(gamma.detach()), ptr(beta.detach()), ptr(running_mean), ptr(running_var), eps,
                    ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]), CoutP, Cout, st)
-        if ctx.needs_input_grad[3]:
+        if ctx.needs_input_grad[1]:
             _note_conv_use(weight)
-        ctx.save_for_backward(x, weight, wd, x_coef, y, coef)
-        ctx.meta = (dil, groups, bias is not None, Cin_g * groups, Cout, x_act, act, training)
+        ctx.save_for_backward(x, weight, wd, y, coef)
+        ctx.meta = (dil, groups, bias is not None, Cin_g * groups, Cout, act, training)
         ctx.mark_non_differentiable(coef)
         ctx.set_materialize_grads(False)
         return y, coef
@@ -853,27 +818,25 @@ class _ConvBN(Function):
     @staticmethod
     def backward(ctx, gz, _):
         if gz is None:
-            return (None,) * 16
-        x, weight, wd, x_coef, y, coef = ctx.saved_tensors
-        dil, groups, has_bias, Cin, Cout, x_act, act, training = ctx.meta
+            return (None,) * 14
+        x, weight, wd, y, coef = ctx.saved_tensors
+        dil, groups, has_bias, Cin, Cout, act, training = ctx.meta
         pend = _DEFERRED_DZ.pop(gz.data_ptr(), None) if _DEFERRED_DZ else None      # gz is a stand-in: dz comes from its producer's inputs
         gz, ldg = _nhwc(gz)
         x, ldx = _nhwc(x)
         y, ldy = _nhwc(y)
         N, H, W, CinP = x.shape
         CoutP, npix, dev = y.shape[3], _npix(y), y.device
-        KH, KW = weight.shape[2], weight.shape[3]
         L, dt, st = lib(), dtype_code(x.dtype), stream()
         scale, shift, mean, rstd = coef[0], coef[1], coef[2], coef[3]
         nb = L.query("egm_channel_partials_blocks", npix, CoutP)
         part = _f32(nb * 2 * CoutP, dev)
         sums, cf4 = _f32((2, CoutP), dev), _f32((4, CoutP), dev)
         train = 1 if training else 0
-        need_gx, need_gw = ctx.needs_input_grad[0], ctx.needs_input_grad[3]
-        gx = gw = gb = dy = None
+        need_gx, need_gw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dy = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev)
         if pend is not None:
             kind = pend[1][0]
-            dy = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev)
             if kind == "cls":
                 _, dl, lddl, wcls, nc, ldw = pend[1]
                 head = ("egm_bn_cls", (dt, ptr(dl), lddl, ptr(wcls), nc, ldw), (npix, CoutP))
@@ -884,35 +847,18 @@ class _ConvBN(Function):
             L.call("egm_bn_bwd_coefs", ptr(part), nb, npix, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), train, ptr(sums), ptr(cf4), CoutP, st)
             L.call(head[0] + "_bwd_apply", *head[1], ptr(y), ldy, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), act, train, ptr(sums),
                    ptr(dy), CoutP, *head[2], st)
-            gx, gw = _conv_grads(x, ldx, x_coef, x_act, dy, weight, wd, dil, groups, Cin, Cout, need_gx, need_gw, ctx.x_split)
-            if has_bias and ctx.needs_input_grad[4]:
-                gb = _bn_conv_bias_grad(Cout, dy, training, dev)
-            ggamma = sums[1, :Cout] if ctx.needs_input_grad[5] else None
-            gbeta = sums[0, :Cout] if ctx.needs_input_grad[6] else None
-            return gx, None, None, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None, None
-        L.call("egm_bn_act_bwd_reduce", dt, ptr(gz), ldg, ptr(y), ldy, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), act, ptr(part),
-               npix, CoutP, st)
-        L.call("egm_bn_bwd_coefs", ptr(part), nb, npix, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), train, ptr(sums),
-               ptr(cf4), CoutP, st)
-        if need_gx:
-            dy = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev)
-        if need_gw and _FUSE_BN_BWD:
-            # the weight-gradient kernel computes dy from (dz, y) while staging and leaves it in `dy` for the data gradient below
-            gw = _conv_wgrad(x, ldx, x_coef, x_act, gz, ldg, (act, cf4, y, ldy), dy, weight, dil, groups, Cin, Cout)
         else:
-            if dy is None:
-                dy = torch.empty((N, H, W, CoutP), dtype=x.dtype, device=dev)
+            L.call("egm_bn_act_bwd_reduce", dt, ptr(gz), ldg, ptr(y), ldy, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), act, ptr(part),
+                   npix, CoutP, st)
+            L.call("egm_bn_bwd_coefs", ptr(part), nb, npix, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), train, ptr(sums),
+                   ptr(cf4), CoutP, st)
             L.call("egm_bn_act_bwd_apply", dt, ptr(gz), ldg, ptr(y), ldy, ptr(scale), ptr(shift), ptr(mean), ptr(rstd), act,
-                   1 if training else 0, ptr(sums), ptr(dy), CoutP, npix, CoutP, st)
-            gx, gw = _conv_grads(x, ldx, x_coef, x_act, dy, weight, wd, dil, groups, Cin, Cout, need_gx, need_gw, ctx.x_split)
-            need_gx = False
-        if need_gx:
-            gx = _conv_dgrad(dy, wd, N, H, W, CoutP, CinP, KH, KW, dil, ctx.x_split)
-        if has_bias and ctx.needs_input_grad[4]:
-            gb = _bn_conv_bias_grad(Cout, dy, training, dev)
-        ggamma = sums[1, :Cout] if ctx.needs_input_grad[5] else None
-        gbeta = sums[0, :Cout] if ctx.needs_input_grad[6] else None
-        return gx, None, None, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None, None
+                   train, ptr(sums), ptr(dy), CoutP, npix, CoutP, st)
+        gx, gw = _conv_grads(x, ldx, dy, weight, wd, dil, groups, Cin, Cout, need_gx, need_gw, ctx.x_split)
+        gb = _bn_conv_bias_grad(Cout, dy, training, dev) if (has_bias and ctx.needs_input_grad[2]) else None
+        ggamma = sums[1, :Cout] if ctx.needs_input_grad[3] else None
+        gbeta = sums[0, :Cout] if ctx.needs_input_grad[4] else None
+        return gx, gw, gb, ggamma, gbeta, None, None, None, None, None, None, None, None, None
 
 
 # environment switch for A/B runs: the max pool at a skip connection fused into its producer / consumer (csrc/pool_fused.hip)
@@ -948,7 +894,7 @@ class _ConvBNPool(Function):
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, eps, momentum, act, training, dil, groups, out_slot):
         x, ldx = _nhwc(x)
         Cout, Cin_g = weight.shape[0], weight.shape[1]
-        y, stats, wd = _conv_forward(x, ldx, None, ACT_NONE, weight, bias, dil, groups, training)
+        y, stats, wd = _conv_forward(x, ldx, weight, bias, dil, groups, training)
         N, H, W, CoutP = y.shape
         npix, dev = _npix(y), y.device
         L, dt, st = lib(), dtype_code(y.dtype), stream()
@@ -1011,7 +957,7 @@ class _ConvBNPool(Function):
                    ptr(sums), ptr(dy), CoutP, npix, CoutP, st)
         gx = gw = gb = None
         if ctx.needs_input_grad[1]:
-            gw = _conv_wgrad(x, ldx, None, ACT_NONE, dy, CoutP, None, None, weight, dil, groups, Cin, Cout)
+            gw = _conv_wgrad(x, ldx, dy, CoutP, weight, dil, groups, Cin, Cout)
         if ctx.needs_input_grad[0]:
             gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=dev)
             L.call("egm_conv_fwd", dt, ptr(dy), CoutP, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
@@ -1023,16 +969,13 @@ class _ConvBNPool(Function):
 
 
 def conv_bn_lazy(x, conv, bn, act, dil=1, groups=1):
-    """conv -> BatchNorm -> activation as an ops.Lazy whatever the fuse_bn() setting: for a consumer whose first pass materialises the
-    tensor itself (ops.mca_layer: BatchNorm apply + the three-axis statistics in one pass)."""
+    """conv -> BatchNorm -> activation as an ops.Lazy: for a consumer whose first pass materialises the tensor itself (ops.mca_layer:
+    BatchNorm apply + the three-axis statistics in one pass)."""
     if bn.training and bn.num_batches_tracked is not None and not getattr(bn, "_egm_counter_managed", False):
         bn.num_batches_tracked.add_(1)
     training = bn.training or bn.running_mean is None
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    if not _FUSE_BN:
-        x = materialize(x)
-    xt, xc, xa = _unlazy(x)
-    y, coef = _ConvBN.apply(xt, xc, xa, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, act,
+    y, coef = _ConvBN.apply(materialize(x), conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, act,
                             training, dil, groups)
     return Lazy(y, coef, act)
 
@@ -1052,7 +995,7 @@ def conv_bn_act_pool(x, conv, bn, act, dil=1, groups=1, out=None):
 
 def pool_fusable(x):
     """True when the fused skip-connection pool applies to the NHWC tensor / Lazy x (switch on, even H and W, <= 1024 channels)."""
-    return _FUSE_POOL and not _FUSE_BN and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and x.shape[1] >= 2 and x.shape[2] >= 2 and x.shape[3] <= 1024
+    return _FUSE_POOL and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and x.shape[1] >= 2 and x.shape[2] >= 2 and x.shape[3] <= 1024
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -1144,7 +1087,7 @@ class _MultiConvBN(Function):
             for k, mk in enumerate(meta):
                 x, weight, bias = flat[5 * k:5 * k + 3]
                 x, ldx = _nhwc(x)
-                convs.append((x, ldx) + _conv_forward(x, ldx, None, ACT_NONE, weight, bias, mk[6], mk[7], mk[5]))
+                convs.append((x, ldx) + _conv_forward(x, ldx, weight, bias, mk[6], mk[7], mk[5]))
         for k, mk in enumerate(meta):
             x, weight, bias, gamma, beta = flat[5 * k:5 * k + 5]
             rm, rv, eps, momentum, act, training, dil, groups, out_slot = mk
@@ -1204,16 +1147,10 @@ class _MultiConvBN(Function):
         grads = [None]
         gxs, gws = [None] * K, [None] * K
         # the 1x1 members (deferrable weight gradients): data gradient + weight-gradient slabs of all of them in ONE fused launch
-        fused, defer_of = [], {}
-        for k in range(K):
-            x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP = per[k][:12]
-            dil, groups = ctx.meta[k][0], ctx.meta[k][1]
-            if ctx.needs_input_grad[1 + 5 * k + 1] and _c1_shape_ok(x, dy, weight, dil, groups):
-                defer_of[k] = _wgrad_deferrable(weight)
-                if defer_of[k]:
-                    fused.append(k)
+        fused = [k for k in range(K) if ctx.needs_input_grad[1 + 5 * k + 1] and _c1_shape_ok(per[k][0], per[k][5], per[k][2], ctx.meta[k][0], ctx.meta[k][1])]
         if fused:
-            res = _conv1x1_bwd([(per[k][0], per[k][1], per[k][5], per[k][11], per[k][2], per[k][3], ctx.needs_input_grad[1 + 5 * k]) for k in fused])
+            res = _conv1x1_bwd([(per[k][0], per[k][1], per[k][5], per[k][11], per[k][2], per[k][3], ctx.needs_input_grad[1 + 5 * k],
+                                 _wgrad_deferrable(per[k][2])) for k in fused])
             for k, (gx_k, gw_k) in zip(fused, res):
                 gxs[k], gws[k] = gx_k, gw_k
         with conv_group():                                    # the other data gradients: one launch per kernel instantiation
@@ -1233,7 +1170,7 @@ class _MultiConvBN(Function):
                 x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP = per[k][:12]
                 dil, groups, has_bias, Cin, Cout, act, training = ctx.meta[k]
                 if ctx.needs_input_grad[1 + 5 * k + 1]:
-                    gws[k] = _conv_wgrad(x, ldx, None, ACT_NONE, dy, CoutP, None, None, weight, dil, groups, Cin, Cout, defer=defer_of.get(k))
+                    gws[k] = _conv_wgrad(x, ldx, dy, CoutP, weight, dil, groups, Cin, Cout)
         for k in range(K):
             x, ldx, weight, wd, g, dy, sums, N, H, W, CinP, CoutP = per[k][:12]
             dil, groups, has_bias, Cin, Cout, act, training = ctx.meta[k]
@@ -1295,7 +1232,7 @@ class _ConvBNEw(Function):
         x, ldx = _nhwc(x)
         p, ldp = _nhwc(p)
         Cout, Cin_g = weight.shape[0], weight.shape[1]
-        y, stats, wd = _conv_forward(x, ldx, None, ACT_NONE, weight, bias, 1, 1, training)
+        y, stats, wd = _conv_forward(x, ldx, weight, bias, 1, 1, training)
         CoutP, npix, dev = y.shape[3], _npix(y), y.device
         if tuple(p.shape) != tuple(y.shape):
             raise RuntimeError(f"conv_bn_ew: element-wise operand {tuple(p.shape)} does not match the conv output {tuple(y.shape)}")
@@ -1340,7 +1277,7 @@ class _ConvBNEw(Function):
         L.call("egm_bn_ew_bwd_apply", dt, mode, ptr(g), ldg, ptr(q), ldq, ptr(y), CoutP, ptr(cf4), act, alpha, ptr(dy), CoutP, ptr(dp),
                CoutP, npix, CoutP, st)
         gb = None
-        gx, gw = _conv_grads(x, ldx, None, ACT_NONE, dy, weight, wd, 1, 1, Cin, Cout, ctx.needs_input_grad[0], ctx.needs_input_grad[2])
+        gx, gw = _conv_grads(x, ldx, dy, weight, wd, 1, 1, Cin, Cout, ctx.needs_input_grad[0], ctx.needs_input_grad[2])
         if has_bias and ctx.needs_input_grad[3]:
             gb = _bn_conv_bias_grad(Cout, dy, training, dev)
         ggamma = sums[1, :Cout] if ctx.needs_input_grad[4] else None
@@ -1552,7 +1489,7 @@ def pw_sites(sites=None):
 
 def pw_applicable(x, convs, site="ew"):
     """True when the 1x1 convs `convs` (nn.Conv2d holders) reading the NHWC tensor / Lazy x can take the moment form."""
-    if not _FUSE_PW or _FUSE_BN or site not in _PW_SITES:
+    if not _FUSE_PW or site not in _PW_SITES:
         return False
     for c in convs:
         if tuple(c.weight.shape[2:]) != (1, 1) or c.groups != 1 or pad8(c.weight.shape[1]) != x.shape[3]:
@@ -1595,20 +1532,18 @@ def bn_act(y, bn, act, stats=None, out=None):
 
 
 def conv_bn_act(x, conv, bn, act, dil=1, groups=1, out=None, lazy=False):
-    """conv -> BatchNorm -> activation (statistics from the conv epilogue).  x: NHWC tensor or Lazy.
-    lazy=True returns the result as a Lazy (for a consumer that is a convolution: the BatchNorm apply never runs as a pass);
-    otherwise the result is materialised, into the destination view `out` when given."""
+    """conv -> BatchNorm -> activation (statistics from the conv epilogue).  x: NHWC tensor (a Lazy is materialised first).
+    lazy="force" returns the result as a Lazy for a consumer that applies the BatchNorm in a pass of its own (MCALayer statistics, the
+    classifier inside the apply pass); otherwise the result is materialised, into the destination view `out` when given."""
     if bn.training and bn.num_batches_tracked is not None and not getattr(bn, "_egm_counter_managed", False):
         bn.num_batches_tracked.add_(1)                  # bookkeeping counter (int64), as nn.BatchNorm2d does
     training = bn.training or bn.running_mean is None
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    if not _FUSE_BN and not (_FUSE_BN_NARROW and isinstance(x, Lazy) and conv.weight.shape[0] <= 32):
-        x = materialize(x)
-    xt, xc, xa = _unlazy(x)
-    y, coef = _ConvBN.apply(xt, xc, xa, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, act,
+    x = materialize(x)
+    y, coef = _ConvBN.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, act,
                             training, dil, groups, getattr(x, "_egm_split", 0))
     z = Lazy(y, coef, act)
-    if out is None and (lazy == "force" or (lazy and _FUSE_BN)):    # "force": the consumer materialises the tensor in a pass of its own
+    if out is None and lazy == "force":                 # the consumer materialises the tensor in a pass of its own
         return z
     return z.materialize(out)
 

@@ -27,12 +27,11 @@ class DoubleConv(nn.Sequential):
         )
 
     def forward(self, x, out=None, lazy=False, pool=False):
-        """x: NHWC; out: optional destination view (a concat slot); lazy: hand the result on as an ops.Lazy (the caller feeds it to a
-        convolution).  The first BatchNorm+ReLU is never a pass: the second conv applies it while staging its input.
+        """x: NHWC; out: optional destination view (a concat slot); lazy="force": hand the result on as an ops.Lazy (the caller feeds it
+        to a consumer that applies the BatchNorm itself, e.g. the classifier inside the apply pass).
         pool=True: -> (result, maxpool2(result)), the skip tensor and the next level's input from ONE BatchNorm apply pass (or from
         the separate pool kernel when the fused form does not apply: odd sizes, switch off)."""
-        narrow = ops.fuse_bn_narrow() and not pool and self[3].out_channels <= 32
-        x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU, lazy="force" if narrow else True)
+        x = ops.conv_bn_act(x, self[0], self[1], ACT_RELU)
         if pool:
             if ops.pool_fusable(x):
                 return ops.conv_bn_act_pool(x, self[3], self[4], ACT_RELU, out=out)
@@ -87,8 +86,8 @@ class OutConv(nn.Sequential):
             out = ops.bn_act_cls(x, self[0].weight, self[0].bias)
             out._egm_nchw_logits = True
             return out
-        x = ops.materialize(x) if (isinstance(x, ops.Lazy) and not ops.fuse_bn()) else x
-        return ops.conv2d(x, self[0].weight, self[0].bias, defer_dgrad=sole_consumer and not isinstance(x, ops.Lazy))
+        was_lazy = isinstance(x, ops.Lazy)
+        return ops.conv2d(ops.materialize(x), self[0].weight, self[0].bias, defer_dgrad=sole_consumer and not was_lazy)
 
 
 class _SegNetBase(nn.Module):
@@ -167,5 +166,5 @@ class UNet(_SegNetBase):
         y = self.up1(x5, x4s)
         y = self.up2(y, x3s)
         y = self.up3(y, x2s)
-        y = self.up4(y, x1s, lazy="force" if ops.fuse_cls() else True)   # the 1x1 classifier applies up4's last BatchNorm+ReLU itself
+        y = self.up4(y, x1s, lazy="force" if ops.fuse_cls() else False)   # the 1x1 classifier applies up4's last BatchNorm+ReLU itself
         return self._exit(self.out_conv(y, sole_consumer=True))

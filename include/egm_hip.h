@@ -36,14 +36,6 @@ typedef void* egm_stream_t; /* hipStream_t */
 
 enum egm_status { EGM_OK = 0, EGM_ERR_ARG = -1, EGM_ERR_LAUNCH = -2, EGM_ERR_UNSUPPORTED = -3 };
 enum egm_dtype { EGM_F32 = 0, EGM_BF16 = 1 };
-/* Operand prologue of the convolution kernels (K2 folded into its consumer): the kernel computes its LOGICAL input operand from
- * what is in memory while staging it, so a BatchNorm apply pass / a BatchNorm-backward apply pass and their tensors never exist.
- *   EGM_PRE_BN_ACT  x' = act(x*cf[0][c] + cf[1][c])                                  x = raw conv output of the producing layer,
- *                                                                                    cf = scale | shift (rows of egm_bn_finalize's output)
- *   EGM_PRE_BN_BWD  x' = cf[0][c]*x*act'(aux*cf[0][c]+cf[1][c]) + cf[2][c] + cf[3][c]*aux
- *                                                                                    x = dz, aux = y (the BatchNorm input), cf from egm_bn_bwd_coefs
- * cf rows are fp32, `C` floats apart (C = padded channel count of the operand).  Zero padding stays exactly zero. */
-enum egm_prologue { EGM_PRE_NONE = 0, EGM_PRE_BN_ACT = 1, EGM_PRE_BN_BWD = 2 };
 enum egm_act { EGM_ACT_NONE = 0, EGM_ACT_RELU = 1, EGM_ACT_SIGMOID = 2, EGM_ACT_SILU = 3 /* x*sigmoid(x): Conv, src/EGM-UNet.py:25-43 */ };
 
 int egm_version(void);
@@ -100,9 +92,9 @@ int egm_conv_c7_mode(int mode);
 int egm_conv_split_ok(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, int csplit);
 int egm_conv_fwd_split(int dtype, const void* x, int ldx, const void* wf, void* y, int ldy, void* y2, int ldy2, int csplit, int N,
                        int H, int W, int Cin, int Cout, int KH, int KW, int dil, egm_stream_t s);
-/* Name of the kernel egm_conv_fwd_pre launches for a shape, spelled like the rows of a rocprofv3 kernel trace (e.g.
- * "conv_igemm_pipe_kernel<2, 3, 3, 2, 0>"); returns its length, copies at most buflen-1 characters into buf (may be NULL). */
-int egm_conv_kernel_name(int dtype, int pre_mode, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen);
+/* Name of the kernel egm_conv_fwd launches for a shape, spelled like the rows of a rocprofv3 kernel trace (e.g.
+ * "conv_igemm_pipe_kernel<2, 3, 3, 2>"); returns its length, copies at most buflen-1 characters into buf (may be NULL). */
+int egm_conv_kernel_name(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen);
 /* y = conv(x, wf) (+bias).  Cin/Cout are the PADDED counts of wf.  bias (fp32, bias_n <= Cout valid entries; the rest count as 0) may be NULL.
  * stats, when non-NULL, receives per-pixel-tile partial sums [ntiles][2][Cout] of y and y*y
  * (consumed by egm_bn_finalize); egm_conv_stats_tiles() gives ntiles for the same dtype/shape/kernel.
@@ -110,13 +102,6 @@ int egm_conv_kernel_name(int dtype, int pre_mode, int N, int H, int W, int Cin, 
 int egm_conv_fwd(int dtype, const void* x, int ldx, const void* wf, const void* bias_f32, int bias_n, void* y, int ldy,
                  float* stats, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, egm_stream_t s);
 int egm_conv_stats_tiles(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
-int egm_conv_stats_tiles_pre(int dtype, int pre_mode, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
-/* egm_conv_fwd whose input operand is a logical tensor (enum egm_prologue above): conv -> BatchNorm -> ReLU -> conv chains
- * (DoubleConv src/EGM-UNet.py:44-55, BasicConv chains :1256-1278) read the producer's raw output; a data gradient reads (dz, y).
- * pre_aux / pre_ld_aux: the second source of EGM_PRE_BN_BWD, same geometry as x. */
-int egm_conv_fwd_pre(int dtype, const void* x, int ldx, int pre_mode, int pre_act, const float* pre_cf, const void* pre_aux,
-                     int pre_ld_aux, const void* wf, const void* bias_f32, int bias_n, void* y, int ldy, float* stats, int N, int H,
-                     int W, int Cin, int Cout, int KH, int KW, int dil, egm_stream_t s);
 /* Weight gradient: dw_oihw_f32 [CoutR][CinR/groups][KH][KW] (+)= sum_pixels dy (x) x.
  * Cin/Cout are padded counts of the activation buffers, CinR/CoutR the real (unpadded) ones.
  * workspace: egm_conv_wgrad_workspace() bytes.  accumulate != 0 adds to dw. */
@@ -124,22 +109,15 @@ long long egm_conv_wgrad_workspace(int N, int H, int W, int Cin, int Cout, int K
 int egm_conv_wgrad(int dtype, const void* x, int ldx, const void* dy, int lddy, float* dw_oihw_f32, void* workspace,
                    int N, int H, int W, int Cin, int Cout, int CinR, int CoutR, int KH, int KW, int dil, int groups,
                    int accumulate, egm_stream_t s);
-/* slab count of a call with (pre != 0) or without operand prologues (the two may be planned differently) */
-int egm_conv_wgrad_slabs_pre(int dtype, int pre, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
-/* egm_conv_wgrad with logical operands: x = act(bn(y_prev)) (EGM_PRE_BN_ACT on x, the conv's input as the forward saw it) and/or
- * dy = BatchNorm backward of (dz, y) (EGM_PRE_BN_BWD on dy).  dy_out (may be NULL): the logical dy [N,H,W,Cout] is also written
- * there, once, as a by-product of the staging, for the data-gradient call that follows (this replaces egm_bn_act_bwd_apply).
- * Same slabs / workspace / deferred form as egm_conv_wgrad. */
-int egm_conv_wgrad_pre(int dtype, const void* x, int ldx, int xpre_mode, int xpre_act, const float* xpre_cf, const void* dy, int lddy,
-                       int dypre_mode, int dypre_act, const float* dypre_cf, const void* dypre_aux, int dypre_ld_aux,
-                       void* dy_out, int ld_dy_out, float* dw_oihw_f32, void* workspace, int N, int H, int W, int Cin, int Cout,
-                       int CinR, int CoutR, int KH, int KW, int dil, int groups, int accumulate, egm_stream_t s);
 /* Deferred form: egm_conv_wgrad with dw == NULL writes only the partial slabs (egm_conv_wgrad_slabs() of them) into the
  * workspace; egm_wgrad_reduce_multi() then finishes MANY convolutions in one launch.  table_dev: device array of 56-byte
  * entries {const float* slab; float* dw; int nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate, chunk0, pad;};
  * chunks per entry = ceil(taps*CoutP*CinP / egm_wgrad_reduce_chunk()), chunk0 / total_chunks as for egm_conv_pack_multi. */
-int egm_conv_wgrad_kernel_name(int dtype, int pre, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen);   /* as egm_conv_kernel_name */
+int egm_conv_wgrad_kernel_name(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen);   /* as egm_conv_kernel_name */
 int egm_conv_wgrad_slabs(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
+/* The reduction of ONE convolution's slabs, at once (what egm_conv_wgrad with dw != NULL runs behind its slab kernel). */
+int egm_wgrad_reduce(const float* slabs, float* dw_oihw_f32, int nslab, int taps, int CoutP, int CinP, int CoutR, int CinR, int groups,
+                     int accumulate, egm_stream_t s);
 int egm_wgrad_reduce_chunk(void);   /* packed elements reduced by one workgroup of egm_wgrad_reduce_multi */
 int egm_wgrad_reduce_multi(const void* table_dev, int n, long long total_chunks, egm_stream_t s);
 /* Depthwise 3x3 (RecursiveGatedAttention.dwconv, src/EGM-UNet.py:507-509): y = (dw3x3(x, w) + b) * scale.
@@ -212,9 +190,8 @@ int egm_bn_mca_bwd_reduce(int dtype, const void* dxo, int ldd, const float* gate
 int egm_bn_mca_bwd_apply(int dtype, const void* dxo, int ldd, const float* gates, const float* coef, int no_spatial, const void* y,
                          int ldy, const float* scale, const float* shift, const float* save_mean, const float* save_rstd, int act,
                          int train, const float* sums, void* dy, int lddy, int N, int H, int W, int C, egm_stream_t s);
-/* Second stage of the backward when dy is consumed as a logical tensor (EGM_PRE_BN_BWD): partial tiles of egm_bn_act_bwd_reduce
- * -> sums [2][C] (dbeta | dgamma) and cf [4][C] = scale | shift | cb | cc with dy = scale*dzp + cb + cc*y; replaces
- * egm_reduce_tiles + egm_bn_act_bwd_apply (same arithmetic: the two forms of dy agree bit for bit). */
+/* Second stage of the BatchNorm backward: partial tiles of egm_bn_act_bwd_reduce -> sums [2][C] (dbeta | dgamma) and
+ * cf [4][C] = scale | shift | cb | cc with dy = scale*dzp + cb + cc*y (what the fused apply passes read). */
 int egm_bn_bwd_coefs(const float* partials, int ntiles, long long count, const float* scale, const float* shift,
                      const float* save_mean, const float* save_rstd, int train, float* sums_2xC, float* cf_4xC, int C,
                      egm_stream_t s);

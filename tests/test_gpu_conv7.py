@@ -21,7 +21,7 @@ def test_conv7x7_c16_matches_generic_kernel_and_torch(shape, with_bias):
     gy = torch.randn(N, H, W, 16, generator=g).to(DEV).to(torch.bfloat16)
     L = lib()
     buf = __import__("ctypes").create_string_buffer(96)
-    L.cdll.egm_conv_kernel_name(dtype_code(torch.bfloat16), 0, N, H, W, 16, 16, 7, 7, 1, buf, 96)
+    L.cdll.egm_conv_kernel_name(dtype_code(torch.bfloat16), N, H, W, 16, 16, 7, 7, 1, buf, 96)
     assert buf.value.decode() == "conv7x7_c16_kernel"       # the kernel under test is the one the shape takes
     res = []
     old = L.cdll.egm_conv_c7_mode(-1)

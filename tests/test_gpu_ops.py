@@ -161,7 +161,7 @@ def test_conv_tile_kernel_matches_four_wave_kernel_and_torch(case):
             y = torch.full((N, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
             st = torch.zeros(nt, 2, Cout, dtype=torch.float32, device=DEV)
             buf = ctypes.create_string_buffer(96)
-            L.cdll.egm_conv_kernel_name(1, 0, N, H, W, Cin, Cout, 3, 3, 1, ctypes.cast(buf, ctypes.c_void_p), 96)
+            L.cdll.egm_conv_kernel_name(1, N, H, W, Cin, Cout, 3, 3, 1, ctypes.cast(buf, ctypes.c_void_p), 96)
             L.call("egm_conv_fwd", 1, ptr(xg), Cin, ptr(wf), ptr(bg), Cout if bias else 0, ptr(y), Cout, ptr(st), N, H, W, Cin, Cout, 3, 3, 1, stream())
             torch.cuda.synchronize()
             outs.append((buf.value.decode(), y, st.sum(0)))

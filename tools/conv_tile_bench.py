@@ -48,7 +48,7 @@ for name, ci, co, hw in shapes:
         nt = L.query("egm_conv_stats_tiles", 1, N, hw, hw, ci, co, 3, 3, 1)
         st.append(torch.zeros(nt, 2, co, dtype=torch.float32, device="cuda"))
         buf = ctypes.create_string_buffer(96)
-        L.cdll.egm_conv_kernel_name(1, 0, N, hw, hw, ci, co, 3, 3, 1, ctypes.cast(buf, ctypes.c_void_p), 96)
+        L.cdll.egm_conv_kernel_name(1, N, hw, hw, ci, co, 3, 3, 1, ctypes.cast(buf, ctypes.c_void_p), 96)
         names.append(buf.value.decode())
 
     def run(mode):
