@@ -31,6 +31,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 // conv7x7_c16.hip: weight gradient of the 16 -> 16 channel 7x7 conv (transposed 16x16x32 MFMA operands, all taps in one wave)
 int egm_conv_c7_wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
@@ -84,6 +85,70 @@ struct WgradParams {
     int ngroups;                 // tap groups
     int dma;                     // bf16: stage through LDS-DMA into two LDS images (no VGPR staging, one barrier per tile)
 };
+
+// ---- epilogue shared by the slab kernels: per wave NTAPS accumulator blocks in the MFMA D layout
+//      (column = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5))
+// Sum the C pixel-row waves of each (wa, wb) pair into the wc == 0 wave, in wave order: the others park their blocks in LDS side by
+// side (16 bytes per lane and instruction), ONE barrier pair.  (Three rounds of 4-byte LDS traffic and six barriers before: 2-3 us of
+// every launch with C = 4.)  LDS: pairs x (C - 1) x NTAPS x 4 KB, see wgrad_plan.
+template <int NTAPS>
+__device__ __forceinline__ void wgrad_reduce_rows(f32x16_t (&acc)[NTAPS], unsigned char* smem, int wa, int wb, int wc, int A, int C, int lane) {
+    if (C == 1) return;
+    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+    __syncthreads();                                                    // the images are dead
+    f32x4_t* park = reinterpret_cast<f32x4_t*>(smem) + (long long)(wb * A + wa) * (C - 1) * (NTAPS * 4 * 64) + lane;
+    if (wc > 0) {
+        f32x4_t* mine = park + (wc - 1) * (NTAPS * 4 * 64);
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4_t v; v.x = acc[t][4 * j]; v.y = acc[t][4 * j + 1]; v.z = acc[t][4 * j + 2]; v.w = acc[t][4 * j + 3];
+                mine[(t * 4 + j) * 64] = v;
+            }
+    }
+    __syncthreads();
+    if (wc == 0) {
+        for (int r = 1; r < C; ++r) {
+            const f32x4_t* src = park + (r - 1) * (NTAPS * 4 * 64);
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4_t v = src[(t * 4 + j) * 64];
+                    acc[t][4 * j] += v.x; acc[t][4 * j + 1] += v.y; acc[t][4 * j + 2] += v.z; acc[t][4 * j + 3] += v.w;
+                }
+        }
+    }
+}
+// One wave's blocks -> slab[tap0 + t][co0 + row][ci] (`slab` = this workgroup's slab).  Every store is a uniform row pointer plus ONE
+// per-lane 32-bit offset: the r03 form re-derived a 64-bit address with three integer multiplies per store, ~100 clocks x 144 stores
+// = 5-7 us at the end of every launch.
+template <int NTAPS>
+__device__ __forceinline__ void wgrad_store_block(float* __restrict__ slab, const f32x16_t (&acc)[NTAPS], int tap0, int co0, int ci, int Cout,
+                                                  int Cin, int lane) {
+    if (ci >= Cin) return;
+    const int h = lane >> 5;
+    const unsigned lo = (unsigned)((co0 + 4 * h) * Cin + ci);            // the lane's first row inside a tap (taps x Cout x Cin < 2^31 floats)
+    float* tp = slab + (long long)tap0 * Cout * Cin;                     // uniform
+    if (co0 + 32 <= Cout) {                                              // uniform: the whole 32-row block exists
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) (tp + ((i & 3) + 8 * (i >> 2)) * Cin)[lo] = acc[t][i];
+            tp += (long long)Cout * Cin;
+        }
+    } else {
+        const int lim = Cout - co0 - 4 * h;                              // rows of the block this lane's half holds
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if ((i & 3) + 8 * (i >> 2) < lim) (tp + ((i & 3) + 8 * (i >> 2)) * Cin)[lo] = acc[t][i];
+            tp += (long long)Cout * Cin;
+        }
+    }
+}
 
 template <int NTAPS> struct Window;   // staged window of a tap group
 template <> struct Window<9> { static constexpr int WH = 3, WW = 3; };
@@ -340,38 +405,10 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradParams& p, const int 
     }
     }
     // ---- reduce the C pixel-row waves of each (wa, wb) pair through LDS (fixed order), then one slab per workgroup
-    for (int r = 1; r < p.C; ++r) {
-        __syncthreads();
-        float* buf = reinterpret_cast<float*>(smem) + (wb * p.A + wa) * (NTAPS * 16 * 64);
-        if (wc == r) {
-#pragma unroll
-            for (int t = 0; t < NTAPS; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) buf[(t * 16 + i) * 64 + lane] = acc[t][i];
-        }
-        __syncthreads();
-        if (wc == 0) {
-#pragma unroll
-            for (int t = 0; t < NTAPS; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[t][i] += buf[(t * 16 + i) * 64 + lane];
-        }
-    }
-    // ---- write the partial block: slab[split][tap][co][ci]; D layout: col(ci) = lane&31, row(co) = f(reg, lane>>5)
-    const int h = lane >> 5, r31 = lane & 31;
-    const int ci = ci_base + wb * 32 + r31;
-    const long long taps = (long long)p.KH * p.KW;
-    float* slab = p.slab + ((long long)split * taps) * p.Cout * p.Cin;
-    if (wc == 0 && ci < p.Cin) {
-#pragma unroll
-        for (int t = 0; t < NTAPS; ++t) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int co = co_base + wa * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (co < p.Cout) slab[((long long)(tap0 + t) * p.Cout + co) * p.Cin + ci] = acc[t][i];
-            }
-        }
-    }
+    wgrad_reduce_rows<NTAPS>(acc, smem, wa, wb, wc, p.A, p.C, lane);
+    if (wc == 0)
+        wgrad_store_block<NTAPS>(p.slab + (long long)split * p.KH * p.KW * p.Cout * p.Cin, acc, tap0, co_base + wa * 32, ci_base + wb * 32 + (lane & 31),
+                                 p.Cout, p.Cin, lane);
 #ifdef EGM_CONV_TIMING
     __syncthreads();
     if (tid == 0 && by == 0 && bz == 0) {       // debug build: phase totals of wave 0 overwrite the first slab floats
@@ -415,15 +452,50 @@ __global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2) ? 2 : 1) void c
 //   barrier per tile.
 // ROT: the row-rotation consumer loop (9 taps, every wave walks all rows of the tile: p.C == 1); its own instantiation, because a kernel
 // that carries both consumer loops spills (660 bytes per lane)
+// ---- the producers' global loads, written out so that their completion is counted here and not by the compiler (see the body)
+__device__ __forceinline__ u32x4_t ws_rsrc(const void* base, unsigned num_records) {       // raw buffer descriptor, byte offsets
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    u32x4_t r;
+    r.x = (unsigned)a; r.y = (unsigned)(a >> 32) & 0xffffu; r.z = num_records; r.w = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ u32x4_t ws_load16(u32x4_t rsrc, unsigned voff) {   // 16 bytes at rsrc.base + voff; zeros when voff >= num_records
+    u32x4_t r;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(rsrc));
+    return r;
+}
+template <int N> __device__ __forceinline__ void ws_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N)); }
+__device__ __forceinline__ void ws_landed(u32x4_t& r) { asm volatile("" : "+v"(r)); }   // uses of r stay behind the wait in front of this
+
+#ifdef EGM_WS_TIMING
+// diagnostic build (tools/diag_wgrad_ws.py): shader-clock totals of wave 0 (consumer) and wave 4 (producer) of the workgroups with
+// blockIdx.y == blockIdx.z == 0 go BEHIND the slabs (the tool allocates them), [split][32] = {barrier, LDS write (+vmcnt wait), tile walk + load issue, MFMA, tiles, 100 MHz ticks of the loop, kernel entry, loop start, loop end and dump time in 100 MHz ticks mod 2^24, ...} x 2
+#define EGM_WS_ENTRY() const long long rte_ = __builtin_amdgcn_s_memrealtime()
+#define EGM_WS_T0() long long tph_[4] = {0, 0, 0, 0}; int ntl_ = 0; const long long rt0_ = __builtin_amdgcn_s_memrealtime(); long long tmk_ = __builtin_amdgcn_s_memtime()
+#define EGM_WS_TICK(i) do { const long long t_ = __builtin_amdgcn_s_memtime(); tph_[i] += t_ - tmk_; tmk_ = t_; } while (0)
+#define EGM_WS_COUNT() (++ntl_)
+#define EGM_WS_LOOPEND() const long long rt1_ = __builtin_amdgcn_s_memrealtime()
+#define EGM_WS_DUMP(cond, off) do { if ((cond) && lane == 0 && by == 0 && bz == 0) { \
+        float* dg_ = p.slab + (long long)p.nsplit * p.KH * p.KW * p.Cout * p.Cin + (long long)split * 32 + (off); \
+        for (int i_ = 0; i_ < 4; ++i_) dg_[i_] = (float)tph_[i_]; \
+        dg_[4] = (float)ntl_; dg_[5] = (float)(rt1_ - rt0_); dg_[6] = (float)(rte_ & 0xffffff); dg_[7] = (float)(rt0_ & 0xffffff); \
+        dg_[8] = (float)(rt1_ & 0xffffff); dg_[9] = (float)(__builtin_amdgcn_s_memrealtime() & 0xffffff); } } while (0)
+#else
+#define EGM_WS_ENTRY() do { } while (0)
+#define EGM_WS_T0() do { } while (0)
+#define EGM_WS_TICK(i) do { } while (0)
+#define EGM_WS_COUNT() do { } while (0)
+#define EGM_WS_LOOPEND() do { } while (0)
+#define EGM_WS_DUMP(cond, off) do { } while (0)
+#endif
 template <int NTAPS, bool ROT>
 __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using M = WMma<bf16_t>;
     constexpr int WH = Window<NTAPS>::WH, WW = Window<NTAPS>::WW;
-    constexpr bool DROW = (NTAPS == 3);
-    constexpr int PH = TH + WH - 1;
-    constexpr int PWC = DROW ? TW + 2 * kMaxRowDil : TW + WW - 1;
-    const int PW = DROW ? TW + 2 * p.dil : TW + WW - 1;
+    static_assert(NTAPS >= 5, "the planner sends the 5-, 7- and 9-tap layers here (whole kernel rows at dilation 1, or tap by tap)");
+    EGM_WS_ENTRY();
+    constexpr int PH = TH + WH - 1, PW = TW + WW - 1;
     constexpr int RB = 64, VPR = 4;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -438,14 +510,14 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
     const int co_base = cot * 32 * p.A, ci_base = cit * 32 * p.B;
 
     int offy, offx, tap0;
-    if (DROW) { offy = (grp - 1) * p.dil; offx = -p.dil; tap0 = grp * 3; }
-    else if (p.dil == 1) {
+    if (p.dil == 1) {
         if (NTAPS == 9 || NTAPS == 1) { offy = -(p.KH / 2); offx = -(p.KW / 2); tap0 = 0; }
         else { offy = grp - p.KH / 2; offx = -(p.KW / 2); tap0 = grp * p.KW; }
     } else { offy = (grp / p.KW - p.KH / 2) * p.dil; offx = (grp % p.KW - p.KW / 2) * p.dil; tap0 = grp; }
 
     const int ndy = p.A * TH * TW * VPR, nx = p.B * PH * PW * VPR;
-    const int img_bytes = (p.A * TH * TW + p.B * PH * PW) * RB;           // one dy + x image pair; two of them, then the coefficients
+    // one dy + x image pair (two of them); the x image is padded to whole 4 KB producer slots (256 threads x 16 bytes)
+    const int img_bytes = p.A * TH * TW * RB + ((p.B * PH * PW * RB + 4095) & ~4095);
     const bf16_t* __restrict__ xg = reinterpret_cast<const bf16_t*>(p.x);
     const bf16_t* __restrict__ dyg = reinterpret_cast<const bf16_t*>(p.dy);
 
@@ -453,7 +525,7 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
     auto tile_ok = [&](int pt, int& n, int& oy0, int& ox0) __attribute__((always_inline)) {
         n = pt / tpi; const int trem = pt - n * tpi;
         oy0 = (trem / p.tiles_x) * TH; ox0 = (trem % p.tiles_x) * TW;
-        return !(p.dil > 1 && (oy0 + offy >= p.H || oy0 + offy + TH <= 0 || ox0 + offx >= p.W || ox0 + offx + (DROW ? PW : TW) <= 0));
+        return !(p.dil > 1 && (oy0 + offy >= p.H || oy0 + offy + TH <= 0 || ox0 + offx >= p.W || ox0 + offx + TW <= 0));
     };
     auto next_tile = [&](int pt, int& n, int& oy0, int& ox0) __attribute__((always_inline)) {
         while (pt < p.npt && !tile_ok(pt, n, oy0, ox0)) pt += p.nsplit;
@@ -468,105 +540,107 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
     int pt1 = pt0 < p.npt ? next_tile(pt0 + p.nsplit, n1, oy1, ox1) : p.npt;
 
     if (producer) {
-        // ---- producer state: 16-byte vector i = ptid + 256 k of the dy image / the x image (block-major [32-ch block][pixel][4 vectors])
-        constexpr int DYVEC = ((DROW ? 1 : 2) * TH * TW * VPR + 255) / 256;
-        constexpr int XVEC = ((DROW ? 1 : 2) * PH * PWC * VPR + 255) / 256;
-        // one tile's staging registers.  There are TWO sets, i.e. two tiles in flight from memory behind the one being written to LDS:
-        // a tile is 16-38 KB per CU and a round trip ~2 us, so ONE tile in flight caps the HBM-bound layers (<= 64 channels at
-        // 512^2 / 256^2) near 3 TB/s whatever the consumers do.
-        struct Regs { uint4 dy[DYVEC], x[XVEC]; };
-#ifndef EGM_WGRAD_DEEP
-#define EGM_WGRAD_DEEP 1          // 0: one staging set everywhere (A/B builds)
-#endif
-        constexpr bool DEEP = EGM_WGRAD_DEEP;
-        Regs ra, rb;
-        const int v4 = ptid & 3;                                        // the thread's vector inside a 32-channel row (same for all its slots)
-        // slot geometry -> (inside the tensor?, pixel offset from the tile's / patch's first pixel, channel offset inside the block set)
-        // The slot arithmetic must stay INSIDE the tile loop: hoisted out of it, its ~27 per-slot invariants do not fit the register
-        // budget, and a scratch reload issued behind a burst of global loads waits for the whole burst (vmcnt retires in order) --
-        // measured 1000 clk per slot.  `opaque()` hides the thread index from the loop-invariant code motion, once per call.
-        auto opaque = [](int v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
-        int tix = ptid;                                                 // re-made opaque at the top of issue_tile / write_tile
-        auto dy_geom = [&](int k, int oy_, int ox_, int& rel, int& cl) __attribute__((always_inline)) {
-            const int i = tix + k * 256, pix = (i >> 2) & (TH * TW - 1), blk = i >> 10;     // TH*TW*VPR = 1024
-            const int py = pix >> 5, px = pix & 31;
-            cl = blk * 32 + (tix & 3) * 8;
-            rel = py * p.W + px;
-            return i < ndy && oy_ + py < p.H && ox_ + px < p.W && co_base + cl < p.Cout;
-        };
-        // x slots: (block, patch row, patch column) packed once per thread (the patch width is a run-time value for dilated rows, and
-        // integer division has no instruction on this machine: ~25 per quotient, per slot, per tile otherwise)
-        int xpk[XVEC];
+        // ---- producer program, instantiated per (A, B): the slot counts are compile-time, every tile issues exactly NV loads
+        auto run = [&](auto na_, auto nb_) __attribute__((always_inline)) {
+            constexpr int NA = decltype(na_)::value, NB = decltype(nb_)::value;
+            // 16-byte vector i = ptid + 256 k of the dy image / the x image (block-major [32-ch block][pixel][4 vectors])
+            constexpr int NDY = NA * TH * TW * VPR / 256, NX = (NB * PH * PW * VPR + 255) / 256, NV = NDY + NX;
+            static_assert(TH * TW * VPR == 1024, "dy slot k: block k >> 2, pixel rows 2 (k & 3) + {0, 1}");
+            // one tile's staging registers.  There are TWO sets, i.e. two tiles in flight from memory behind the one being written to
+            // LDS: a tile is 16-38 KB per CU and a round trip ~2 us, so ONE tile in flight caps the HBM-bound layers (<= 64 channels at
+            // 512^2 / 256^2) near 3 TB/s whatever the consumers do.
+            struct Regs { u32x4_t dy[NDY], x[NX]; };
+            Regs ra, rb;
+            // A producer wave shares its SIMD with a consumer and gets one VALU instruction in ~4.7 clocks: the r03 form of this loop
+            // spent ~75 instructions per slot (addresses, four bounds tests, a branch, a zeroed destination), 1 500 per tile = 7 000
+            // clocks, and THAT was the tile period of every layer (the consumers need 1 150-5 800).  Now every slot is one raw buffer
+            // load whose offset is a register made once per kernel: the tile's first pixel goes into the buffer descriptor (scalar
+            // arithmetic), a slot that does not exist for this thread (channel beyond Cin / Cout, vector beyond the patch) holds an
+            // offset beyond num_records and reads zeros, and only tiles that touch the image border test rows and columns per slot.
+            // The loads and their waits are written out (ws_load16 / ws_wait_vm): the compiler's own vmcnt bookkeeping waited for
+            // the set issued LAST as well before every LDS write (vmcnt(0..8) where 19-38 loads may stay in flight), which is one
+            // tile in flight, not two.  Every tile -- also the ones behind the last, whose descriptors have num_records = 0 -- issues
+            // exactly NV loads, so "at most NV outstanding" means "this set has landed, the other may be on its way".
+            constexpr unsigned OOB = 0x80000000u;                           // = num_records of the descriptors
+            const int v4 = ptid & 3;                                        // the thread's vector inside a 32-channel row (all its slots)
+            const int dpy0 = ptid >> 7, dpx = (ptid >> 2) & 31;             // dy slot k: pixel (dpy0 + 2 (k & 3), dpx) of block k >> 2
+            unsigned dyoff[NDY];                                            // byte offset from the tile's first pixel, or OOB
 #pragma unroll
-        for (int k = 0; k < XVEC; ++k) {
-            const int i = ptid + k * 256, q = i >> 2, npp = PH * PW;
-            const int blk = q / npp, pix = q - blk * npp, py = pix / PW, px = pix - py * PW;
-            xpk[k] = (i < nx && ci_base + blk * 32 + v4 * 8 < p.Cin) ? (blk << 20) | (py << 10) | px : -1;
-        }
-        auto x_geom = [&](int k, int iy0, int ix0, int& rel, int& cl) __attribute__((always_inline)) {
-            const int pk = xpk[k], blk = pk >> 20, py = (pk >> 10) & 1023, px = pk & 1023;
-            cl = blk * 32 + (tix & 3) * 8;
-            rel = py * p.W + px;
-            const int iy = iy0 + py, ix = ix0 + px;
-            return pk >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        };
-        auto issue_tile = [&](Regs& rg, int n, int oy_, int ox_) __attribute__((always_inline)) {
-            uint4 (&rdy)[DYVEC] = rg.dy; uint4 (&rx)[XVEC] = rg.x;
-            tix = opaque(ptid);
-            const long long o_dy = (long long)(n * p.H + oy_) * p.W + ox_;                // first pixel of the dy tile (inside the image)
-            const long long o_x = (long long)(n * p.H + oy_ + offy) * p.W + ox_ + offx;   // first pixel of the x patch (may be outside)
-            const bf16_t* dbase = dyg + o_dy * p.lddy + co_base;
-            const bf16_t* xbase = xg + o_x * p.ldx + ci_base;
-#pragma unroll
-            for (int k = 0; k < DYVEC; ++k) {
-                int rel, cl;
-                const bool ok = dy_geom(k, oy_, ox_, rel, cl);
-                rdy[k] = make_uint4(0, 0, 0, 0);
-                if (ok) rdy[k] = *reinterpret_cast<const uint4*>(dbase + rel * p.lddy + cl);
+            for (int k = 0; k < NDY; ++k) {
+                const int bq = k >> 2, py = dpy0 + 2 * (k & 3);
+                dyoff[k] = co_base + bq * 32 + v4 * 8 < p.Cout ? (unsigned)((py * p.W + dpx) * p.lddy + bq * 32 + v4 * 8) * 2u : OOB;
             }
+            // x slots: (patch row, patch column) and the byte offset from the patch's first pixel, once per thread
+            unsigned xoff[NX];
+            int xpk[NX];
 #pragma unroll
-            for (int k = 0; k < XVEC; ++k) {
-                int rel, cl;
-                const bool ok = x_geom(k, oy_ + offy, ox_ + offx, rel, cl);
-                rx[k] = make_uint4(0, 0, 0, 0);
-                if (ok) rx[k] = *reinterpret_cast<const uint4*>(xbase + rel * p.ldx + cl);
+            for (int k = 0; k < NX; ++k) {
+                constexpr int npp = PH * PW;
+                const int i = ptid + k * 256, q = i >> 2;
+                const int blk = q / npp, pix = q - blk * npp, py = pix / PW, px = pix - py * PW;
+                const bool ok = i < NB * npp * VPR && ci_base + blk * 32 + v4 * 8 < p.Cin;
+                xoff[k] = ok ? (unsigned)((py * p.W + px) * p.ldx + blk * 32 + v4 * 8) * 2u : OOB;
+                xpk[k] = (py << 16) | px;
             }
-        };
-        // LDS write of the tile held in registers into image pair `buf`
-        auto write_tile = [&](Regs& rg, int buf) __attribute__((always_inline)) {
-            uint4 (&rdy)[DYVEC] = rg.dy; uint4 (&rx)[XVEC] = rg.x;
-            tix = opaque(ptid);
-            unsigned char* dyb = smem + buf * img_bytes;
-            unsigned char* xb = dyb + p.A * (TH * TW) * RB;
+            auto issue_tile = [&](Regs& rg, int pt, int n, int oy_, int ox_) __attribute__((always_inline)) {
+                const long long o_dy = (long long)(n * p.H + oy_) * p.W + ox_;            // first pixel of the dy tile (inside the image)
+                const long long o_x = (long long)(n * p.H + oy_ + offy) * p.W + ox_ + offx;   // first pixel of the x patch (may be outside)
+                const unsigned nrec = pt < p.npt ? OOB : 0u;                              // behind the last tile: every slot reads zeros
+                const u32x4_t rdsc = ws_rsrc(dyg + (pt < p.npt ? o_dy * p.lddy + co_base : 0), nrec);
+                const u32x4_t xdsc = ws_rsrc(xg + (pt < p.npt ? o_x * p.ldx + ci_base : 0), nrec);
+                const int rows = dpx < p.W - ox_ ? p.H - oy_ : 0;                         // rows of the tile this thread's column has
 #pragma unroll
-            for (int k = 0; k < DYVEC; ++k)
-                if (tix + k * 256 < ndy) *reinterpret_cast<uint4*>(dyb + (tix + k * 256) * 16) = rdy[k];
+                for (int k = 0; k < NDY; ++k) rg.dy[k] = ws_load16(rdsc, dpy0 + 2 * (k & 3) < rows ? dyoff[k] : OOB);
+                const int iy0 = oy_ + offy, ix0 = ox_ + offx;
+                if (iy0 >= 0 && iy0 + PH <= p.H && ix0 >= 0 && ix0 + PW <= p.W) {         // the whole patch inside the image
 #pragma unroll
-            for (int k = 0; k < XVEC; ++k)
-                if (tix + k * 256 < nx) *reinterpret_cast<uint4*>(xb + (tix + k * 256) * 16) = rx[k];
-        };
-        if constexpr (DEEP) {
-            // Producers run one tile ahead in LDS and THREE ahead in registers: set `cur` holds tile pt1 (written to LDS this iteration,
-            // then re-used for tile pt3), set `oth` holds tile pt2.  The loop is unrolled by two so the sets swap roles by name.
+                    for (int k = 0; k < NX; ++k) rg.x[k] = ws_load16(xdsc, xoff[k]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) {
+                        const int iy = iy0 + (xpk[k] >> 16), ix = ix0 + (xpk[k] & 0xffff);
+                        const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                        rg.x[k] = ws_load16(xdsc, ok ? xoff[k] : OOB);
+                    }
+                }
+            };
+            // LDS write of the tile held in registers into image pair `buf`, once at most `younger` loads are outstanding
+            auto write_tile = [&](Regs& rg, int buf, auto younger) __attribute__((always_inline)) {
+                ws_wait_vm<decltype(younger)::value>();
+#pragma unroll
+                for (int k = 0; k < NDY; ++k) ws_landed(rg.dy[k]);
+#pragma unroll
+                for (int k = 0; k < NX; ++k) ws_landed(rg.x[k]);
+                unsigned char* dyb = smem + buf * img_bytes + ptid * 16;
+                unsigned char* xb = dyb + NA * (TH * TW) * RB;
+#pragma unroll
+                for (int k = 0; k < NDY; ++k) *reinterpret_cast<u32x4_t*>(dyb + k * 4096) = rg.dy[k];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) *reinterpret_cast<u32x4_t*>(xb + k * 4096) = rg.x[k];
+            };
+            // Producers run one tile ahead in LDS and THREE ahead in registers: set `cur` holds tile pt1 (written to LDS this
+            // iteration, then re-used for tile pt3), set `oth` holds tile pt2.  The loop is unrolled by two so the sets swap roles by name.
             int n2 = 0, oy2 = 0, ox2 = 0;
             int pt2 = pt1 < p.npt ? next_tile(pt1 + p.nsplit, n2, oy2, ox2) : p.npt;
-            if (pt0 < p.npt) issue_tile(ra, n0, oy0, ox0);
+            issue_tile(ra, pt0, n0, oy0, ox0);
             __syncthreads();                                            // (the consumers' barrier count)
-            if (pt0 < p.npt) {
-                write_tile(ra, 0);
-                if (pt1 < p.npt) issue_tile(ra, n1, oy1, ox1);
-                if (pt2 < p.npt) issue_tile(rb, n2, oy2, ox2);
-            }
+            write_tile(ra, 0, std::integral_constant<int, 0>());
+            issue_tile(ra, pt1, n1, oy1, ox1);
+            issue_tile(rb, pt2, n2, oy2, ox2);
             __syncthreads();
             int buf = 0;
+            EGM_WS_T0();
             auto step = [&](Regs& cur) __attribute__((always_inline)) {
                 int n3 = 0, oy3 = 0, ox3 = 0;
                 const int pt3 = pt2 < p.npt ? next_tile(pt2 + p.nsplit, n3, oy3, ox3) : p.npt;
-                if (pt1 < p.npt) {
-                    write_tile(cur, buf ^ 1);                           // registers -> the image pair the consumers are NOT reading
-                    if (pt3 < p.npt) issue_tile(cur, n3, oy3, ox3);     // the freed set takes the tile three ahead
-                }
+                EGM_WS_TICK(2);
+                write_tile(cur, buf ^ 1, std::integral_constant<int, NV>());   // registers -> the image pair the consumers are NOT reading
+                EGM_WS_TICK(1);
+                issue_tile(cur, pt3, n3, oy3, ox3);                     // the freed set takes the tile three ahead
+                EGM_WS_TICK(2);
                 __syncthreads();
+                EGM_WS_TICK(0);
+                EGM_WS_COUNT();
                 buf ^= 1;
                 pt0 = pt1; pt1 = pt2; n1 = n2; oy1 = oy2; ox1 = ox2;
                 pt2 = pt3; n2 = n3; oy2 = oy3; ox2 = ox3;
@@ -576,29 +650,15 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
                 if (pt0 >= p.npt) break;
                 step(rb);
             }
-        } else {
-        // Producers run one tile ahead in LDS and two ahead in registers.
-        if (pt0 < p.npt) issue_tile(ra, n0, oy0, ox0);
-        __syncthreads();                                                // (the consumers' barrier count)
-        if (pt0 < p.npt) {
-            write_tile(ra, 0);
-            if (pt1 < p.npt) issue_tile(ra, n1, oy1, ox1);
-        }
-        __syncthreads();
-        int buf = 0;
-        while (pt0 < p.npt) {
-            int n2 = 0, oy2 = 0, ox2 = 0;
-            const int pt2 = pt1 < p.npt ? next_tile(pt1 + p.nsplit, n2, oy2, ox2) : p.npt;
-            if (pt1 < p.npt) {
-                write_tile(ra, buf ^ 1);                                // registers -> the image pair the consumers are NOT reading
-                if (pt2 < p.npt) issue_tile(ra, n2, oy2, ox2);          // the freed registers take the tile after next
-            }
-            __syncthreads();
-            buf ^= 1;
-            pt0 = pt1; pt1 = pt2; n1 = n2; oy1 = oy2; ox1 = ox2;
-        }
-        }
-        for (int r = 1; r < p.C; ++r) { __syncthreads(); __syncthreads(); }   // the consumers' cross-wave reduction
+            EGM_WS_LOOPEND();
+            ws_wait_vm<0>();                                            // the zero-reads issued behind the last tile
+            EGM_WS_DUMP(wv == 4, 16);
+        };
+        if (p.A == 1 && p.B == 1) run(std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
+        else if (p.A == 2 && p.B == 1) run(std::integral_constant<int, 2>(), std::integral_constant<int, 1>());
+        else if (p.A == 1) run(std::integral_constant<int, 1>(), std::integral_constant<int, 2>());
+        else run(std::integral_constant<int, 2>(), std::integral_constant<int, 2>());
+        if (p.C > 1) { __syncthreads(); __syncthreads(); }             // the consumers' cross-wave reduction (wgrad_reduce_rows)
         return;
     }
 
@@ -616,7 +676,7 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
         auto load_step = [&](int ry, int k0, M::Frag& fa, M::Frag (&fb)[NTAPS]) __attribute__((always_inline)) {
             fa = M::load(ablk, ry * TW + k0, lane);
 #pragma unroll
-            for (int t = 0; t < NTAPS; ++t) fb[t] = M::load(bblk, DROW ? ry * PW + k0 + t * p.dil : (ry + t / WW) * PW + k0 + t % WW, lane);
+            for (int t = 0; t < NTAPS; ++t) fb[t] = M::load(bblk, (ry + t / WW) * PW + k0 + t % WW, lane);
         };
         auto mma_step = [&](const M::Frag& fa, const M::Frag (&fb)[NTAPS]) __attribute__((always_inline)) {
 #pragma unroll
@@ -677,49 +737,28 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
     };
     __syncthreads();
     __syncthreads();
+    EGM_WS_T0();
     {
         int buf = 0;
         while (pt0 < p.npt) {
             int n2 = 0, oy2 = 0, ox2 = 0;
             const int pt2 = pt1 < p.npt ? next_tile(pt1 + p.nsplit, n2, oy2, ox2) : p.npt;
             mfma_tile(buf);
+            EGM_WS_TICK(3);
             __syncthreads();
+            EGM_WS_TICK(0);
+            EGM_WS_COUNT();
             buf ^= 1;
             pt0 = pt1; pt1 = pt2;
         }
     }
+    EGM_WS_LOOPEND();
     // ---- reduce the C pixel-row waves of each (wa, wb) pair through LDS (fixed order), then one slab per workgroup
-    for (int r = 1; r < p.C; ++r) {
-        __syncthreads();
-        float* rb = reinterpret_cast<float*>(smem) + (wb * p.A + wa) * (NTAPS * 16 * 64);
-        if (wc == r) {
-#pragma unroll
-            for (int t = 0; t < NTAPS; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) rb[(t * 16 + i) * 64 + lane] = acc[t][i];
-        }
-        __syncthreads();
-        if (wc == 0) {
-#pragma unroll
-            for (int t = 0; t < NTAPS; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[t][i] += rb[(t * 16 + i) * 64 + lane];
-        }
-    }
-    const int h = lane >> 5, r31 = lane & 31;
-    const int ci = ci_base + wb * 32 + r31;
-    const long long taps = (long long)p.KH * p.KW;
-    float* slab = p.slab + ((long long)split * taps) * p.Cout * p.Cin;
-    if (wc == 0 && ci < p.Cin) {
-#pragma unroll
-        for (int t = 0; t < NTAPS; ++t) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int co = co_base + wa * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (co < p.Cout) slab[((long long)(tap0 + t) * p.Cout + co) * p.Cin + ci] = acc[t][i];
-            }
-        }
-    }
+    wgrad_reduce_rows<NTAPS>(acc, smem, wa, wb, wc, p.A, p.C, lane);
+    if (wc == 0)
+        wgrad_store_block<NTAPS>(p.slab + (long long)split * p.KH * p.KW * p.Cout * p.Cin, acc, tap0, co_base + wa * 32, ci_base + wb * 32 + (lane & 31),
+                                 p.Cout, p.Cin, lane);
+    EGM_WS_DUMP(wv == 0, 0);
 }
 
 template <int NTAPS, bool ROT>
@@ -904,8 +943,9 @@ int wgrad_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW
     // (measured: 9 % faster on the 2 x 2-block layers, i.e. Cin, Cout > 32; slower on the narrow and the dilated ones, which keep
     //  the register-staged pipeline)
     pl->dma = (dtype == EGM_BF16 && !pl->ws && !dma_off && A * B == 4 && pl->ntaps == 9 && 2 * pl->smem <= 156 * 1024) ? 1 : 0;
+    if (pl->ws) pl->smem = (size_t)A * TH * TW * rb + (((size_t)B * (TH + wh - 1) * pw * rb + 4095) & ~(size_t)4095);   // whole producer slots
     if (pl->dma || pl->ws) pl->smem *= 2;
-    const size_t red_bytes = pl->C > 1 ? (size_t)A * B * pl->ntaps * 16 * 64 * sizeof(float) : 0;   // cross-wave reduction buffer
+    const size_t red_bytes = pl->C > 1 ? (size_t)A * B * (pl->C - 1) * pl->ntaps * 16 * 64 * sizeof(float) : 0;   // wgrad_reduce_rows' parking area
     if (pl->smem < red_bytes) pl->smem = red_bytes;
     pl->slab_bytes = (long long)nsplit * KH * KW * Cout * Cin * (long long)sizeof(float);
     return EGM_OK;
@@ -1012,7 +1052,7 @@ int launch_wgrad_ws(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
 }
 template <typename T, int NTAPS>
 int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2 && NTAPS >= 5) {
         if (pl.ws) return launch_wgrad_ws<NTAPS>(p, pl, st);
     }
     return launch_wgrad_4w<T, NTAPS>(p, pl, st);
