@@ -178,18 +178,29 @@ __device__ __forceinline__ void conv_direct_body(const DirectParams& p, const in
                 pk.y = (uint32_t)f32_to_bf16(acc[nt][gq * 4 + 2]) | ((uint32_t)f32_to_bf16(acc[nt][gq * 4 + 3]) << 16);
                 *reinterpret_cast<uint2*>(ot + r31 * OROW + (nt * 32 + gq * 8 + h * 4) * 2) = pk;
             }
-        // read back whole channel vectors (same wave: LDS operations complete in order) and store coalesced
+        // read back whole channel vectors (same wave: LDS operations complete in order) and store them as they are, coalesced: a uniform
+        // block pointer plus one per-lane offset; the statistics, when asked for, see the stored values
+        {
+            bf16_t* yblk = yg + (long long)blk * 32 * p.ldy + co0;
+            const long long left = npix - (long long)blk * 32;                  // pixels of this block inside the tensor
+            const bool whole = left >= 32 && co0 + NT * 32 <= p.Cout;
+            uint4 raw[NV / 2];
 #pragma unroll
-        for (int it = 0; it < NV / 2; ++it) {
-            const int pl = it * (64 / NV) + slot;
-            const long long po = (long long)blk * 32 + pl;
-            const int co = co0 + cvo * 8;
-            float v[8];
-            load8(reinterpret_cast<const bf16_t*>(ot + pl * OROW + cvo * 16), v);
-            if (po < npix && co < p.Cout) {
-                store8(yg + po * p.ldy + co, v);
+            for (int it = 0; it < NV / 2; ++it) raw[it] = *reinterpret_cast<const uint4*>(ot + (it * (64 / NV) + slot) * OROW + cvo * 16);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
+            for (int it = 0; it < NV / 2; ++it) {
+                const int pl = it * (64 / NV) + slot;
+                if (whole || (pl < left && co0 + cvo * 8 < p.Cout)) {
+                    *reinterpret_cast<uint4*>(yblk + (long long)it * (64 / NV) * p.ldy + (unsigned)(slot * p.ldy + cvo * 8)) = raw[it];
+                    if (p.stats != nullptr) {
+                        const uint32_t u[4] = {raw[it].x, raw[it].y, raw[it].z, raw[it].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float lo = __uint_as_float(u[j] << 16), hi = __uint_as_float(u[j] & 0xffff0000u);
+                            ssum[2 * j] += lo; ssq[2 * j] += lo * lo; ssum[2 * j + 1] += hi; ssq[2 * j + 1] += hi * hi;
+                        }
+                    }
+                }
             }
         }
     }

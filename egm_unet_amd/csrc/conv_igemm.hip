@@ -515,6 +515,11 @@ __device__ __forceinline__ void conv_igemm_pipe_body(const ConvParams& p, const 
             // never over the weights: weights that are staged once per workgroup must survive every epilogue.
             unsigned char* ot = smem + wv * 32 * OROW;        // wave-private 32 px x NT*32 couts, one tile row at a time
             const int cv = lane % NV, slot = lane / NV;
+            // this tile's first output element (uniform), what of the tile lies inside the tensor, the lane's place in a row group
+            bf16_t* ytile = yg + ((long long)(cur.n * p.H + cur.oy0) * p.W + cur.ox0) * p.ldy + co0;
+            const int rows_in = p.H - cur.oy0, cols_in = p.W - cur.ox0, couts_in = p.Cout - co0;
+            const bool whole = rows_in >= THR && cols_in >= TW && couts_in >= NT * 32;
+            const unsigned lane_off = (unsigned)((R * wv * p.W + slot) * p.ldy + cv * 8);
             // D layout: col (pixel) = lane&31, row (cout) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
             for (int m = 0; m < R; ++m) {
@@ -534,19 +539,25 @@ __device__ __forceinline__ void conv_igemm_pipe_body(const ConvParams& p, const 
                         pk.y = (uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 2]) | ((uint32_t)f32_to_bf16(acc[m][nt][gq * 4 + 3]) << 16);
                         *reinterpret_cast<uint2*>(ot + r31 * OROW + (nt * 32 + gq * 8 + h * 4) * 2) = pk;
                     }
-                // read back whole channel vectors (same wave: its LDS ops complete in order) and store coalesced
-                const int oy = cur.oy0 + R * wv + m;
+                // read back whole channel vectors (same wave: its LDS ops complete in order) and store them as they are, coalesced:
+                // a uniform row pointer plus one per-lane offset (the r03 form rebuilt a 64-bit address with three integer multiplies
+                // per store and converted the vector to fp32 and back; the statistics, when asked for, still see the stored values)
+                bf16_t* yrow = ytile + (long long)m * p.W * p.ldy;
+                uint4 raw[NV / 2];
+#pragma unroll
+                for (int it = 0; it < NV / 2; ++it) raw[it] = *reinterpret_cast<const uint4*>(ot + (it * (64 / NV) + slot) * OROW + cv * 16);
 #pragma unroll
                 for (int it = 0; it < NV / 2; ++it) {         // 32 pixels / (64/NV pixel slots)
-                    const int pl = it * (64 / NV) + slot;
-                    const int ox = cur.ox0 + pl;
-                    const int co = co0 + cv * 8;
-                    float v[8];
-                    load8(reinterpret_cast<const bf16_t*>(ot + pl * OROW + cv * 16), v);
-                    if (oy < p.H && ox < p.W && co < p.Cout) {
-                        store8(yg + ((long long)(cur.n * p.H + oy) * p.W + ox) * p.ldy + co, v);
+                    if (whole || (R * wv + m < rows_in && it * (64 / NV) + slot < cols_in && cv * 8 < couts_in)) {
+                        *reinterpret_cast<uint4*>(yrow + (long long)it * (64 / NV) * p.ldy + lane_off) = raw[it];
+                        if (p.stats != nullptr) {
+                            const uint32_t u[4] = {raw[it].x, raw[it].y, raw[it].z, raw[it].w};
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; ssq[j] += v[j] * v[j]; }
+                            for (int j = 0; j < 4; ++j) {
+                                const float lo = __uint_as_float(u[j] << 16), hi = __uint_as_float(u[j] & 0xffff0000u);
+                                ssum[2 * j] += lo; ssq[2 * j] += lo * lo; ssum[2 * j + 1] += hi; ssq[2 * j + 1] += hi * hi;
+                            }
+                        }
                     }
                 }
             }
