@@ -11,6 +11,7 @@ Prints ONE JSON line (rank 0) with the extra `roofline` (dominant kernel, timed 
 instrumented step outside the timed region) and `cpu_baseline` (CPU oracle on a bounded sample) objects.
 """
 import argparse
+import struct
 import contextlib
 import ctypes
 import json
@@ -63,7 +64,7 @@ class KernelTimer:
         def timed(name, *args):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = 1
-            if name in ("egm_conv_fwd", "egm_conv_wgrad"):
+            if name in ("egm_conv_fwd", "egm_conv_wgrad", "egm_conv_wgrad_multi"):
                 # idempotent (same inputs, outputs overwritten with the same values): the first call does the work of the step,
                 # REPS more are timed as a train, which matches the per-launch durations rocprofv3 reports for the graph replay
                 self._orig(name, *args)
@@ -93,6 +94,15 @@ class KernelTimer:
                 N, H, W, Cin, Cout = args[7:12]
                 KH, KW, dil = args[14:17]
                 kind = "wgrad"
+            elif name == "egm_conv_wgrad_multi":
+                # one launch of several layers: its time is shared out by the members' roofline times
+                mem = self._wgrad_members(args)
+                roofs = [max(2.0 * m[0] * m[1] * m[2] * m[3] * m[4] * m[5] * m[6] / (MFMA_BF16_PEAK_TFLOPS * 1e12),
+                             2.0 * m[0] * m[1] * m[2] * (m[3] + m[4]) / (HBM_PEAK_GBS * 1e9)) for m in mem]
+                for m, rf in zip(mem, roofs):
+                    r = rows.setdefault(("wgrad*", m[5], m[7], m[3], m[4], m[1], m[2]), [0, 0.0])
+                    r[0] += 1; r[1] += e0.elapsed_time(e1) * rf / sum(roofs)
+                continue
             else:
                 continue
             key = (kind, KH, dil, Cin, Cout, H, W)
@@ -133,6 +143,23 @@ class KernelTimer:
                         "frac_of_layer_roofline": round(roof_t / t, 3)})
         return out
 
+    _WGRAD_DESC = struct.Struct("<3Q14i")        # egm_conv_wgrad_desc (include/egm_hip.h)
+
+    def _wgrad_members(self, args):
+        """egm_conv_wgrad_multi(dtype, descs, n, stream) -> [(N, H, W, Cin, Cout, KH, KW, dil)] of its members"""
+        blob, n = args[1], args[2]
+        out = []
+        for i in range(n):
+            f = self._WGRAD_DESC.unpack_from(blob, i * self._WGRAD_DESC.size)
+            out.append((f[5], f[6], f[7], f[8], f[9], f[12], f[13], f[14]))
+        return out
+
+    def _multi_name(self, args):
+        """kernel of an egm_conv_wgrad_multi call as a trace prints it: the members' kernel, its merged form when there are several"""
+        mem = self._wgrad_members(args)
+        k = self._kernel_name("egm_conv_wgrad_kernel_name", args[0], *mem[0][:5], *mem[0][5:8])
+        return k.replace("_kernel<", "_multi_kernel<") if len(mem) > 1 else k
+
     def _kernel_name(self, entry, dtype, N, H, W, Cin, Cout, KH, KW, dil):
         """The kernel a conv call takes, spelled as in a rocprofv3 kernel trace (egm_conv_kernel_name / egm_conv_wgrad_kernel_name), so
         that the per-launch averages below sit beside the matching rows of profiles/*_kernel_trace_summary.md."""
@@ -168,6 +195,8 @@ class KernelTimer:
                 k = self._kernel_name("egm_conv_kernel_name", args[0], *args[9:17])
             elif name == "egm_conv_wgrad":
                 k = self._kernel_name("egm_conv_wgrad_kernel_name", args[0], *args[7:12], *args[14:17])
+            elif name == "egm_conv_wgrad_multi":
+                k = self._multi_name(args)
             keyed.append(k)
         # a launch group merges the members that run the SAME kernel instantiation; a member alone of its kind launches under its own name
         members = {}
@@ -188,6 +217,18 @@ class KernelTimer:
                 KH, KW, dil = args[14:17]
                 flops = 2.0 * N * H * W * Cin * Cout * KH * KW
                 key = self._kernel_name("egm_conv_wgrad_kernel_name", args[0], N, H, W, Cin, Cout, KH, KW, dil)
+            elif name == "egm_conv_wgrad_multi":
+                # ONE launch (ops._launch_pending_slabs hands over members of one kernel instantiation): flop, bytes and the roofline
+                # time of the launch are the sums over its members
+                key = self._multi_name(args)
+                a = agg.setdefault(key, [0, 0.0, 0.0, 0.0, 0.0, 0, 0.0])
+                a[0] += 1; a[1] += e0.elapsed_time(e1); a[5] += 1
+                for N, H, W, Cin, Cout, KH, KW, dil in self._wgrad_members(args):
+                    fl = 2.0 * N * H * W * Cin * Cout * KH * KW
+                    byts = 2.0 * (N * H * W * (Cin + Cout) + KH * KW * Cin * Cout)          # as for a single launch: operands once each
+                    a[2] += fl; a[3] += byts; a[6] += byts
+                    a[4] += 1e3 * max(fl / (MFMA_BF16_PEAK_TFLOPS * 1e12), byts / (HBM_PEAK_GBS * 1e9))
+                continue
             a = agg.setdefault(key, [0, 0.0, 0.0, 0.0, 0.0, 0, 0.0])
             a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += flops
             if flops:
@@ -574,7 +615,7 @@ def main():
         from egm_unet_amd import ops as _ops
         grouped = _ops.group_convs()
         _ops.group_convs(False)                 # every conv launched (and timed) on its own: inside a launch group the calls only record
-        try:
+        try:                                    # (the deferred weight-gradient slab kernels stay merged: egm_conv_wgrad_multi is one timed call)
             with KernelTimer(lib()) as kt:
                 eager_step()
         finally:

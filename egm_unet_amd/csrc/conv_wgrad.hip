@@ -450,8 +450,9 @@ __global__ __launch_bounds__(256, (NTAPS <= 3 && sizeof(T) == 2) ? 2 : 1) void c
 //     whole tile periods hide the global latency.
 //   A consumer and a producer wave share each SIMD: staging runs beside the consumers' MFMAs instead of in front of them.  One
 //   barrier per tile.
-// ROT: the row-rotation consumer loop (9 taps, every wave walks all rows of the tile: p.C == 1); its own instantiation, because a kernel
-// that carries both consumer loops spills (660 bytes per lane)
+// CC: 1, 2, 4 = the row-rotation consumer loop of the 9-tap layers with C = CC pixel-row waves per (cout, cin) block pair (one
+// instantiation each: a kernel that carries two consumer loops spills, 660-5 000 bytes per lane); 0 = the plain loop, C at run time
+// (5- and 7-tap rows; the 9-tap layers with EGM_WGRAD_ROT=0, for A/B runs)
 // ---- the producers' global loads, written out so that their completion is counted here and not by the compiler (see the body)
 __device__ __forceinline__ u32x4_t ws_rsrc(const void* base, unsigned num_records) {       // raw buffer descriptor, byte offsets
     const unsigned long long a = reinterpret_cast<unsigned long long>(base);
@@ -488,7 +489,7 @@ __device__ __forceinline__ void ws_landed(u32x4_t& r) { asm volatile("" : "+v"(r
 #define EGM_WS_LOOPEND() do { } while (0)
 #define EGM_WS_DUMP(cond, off) do { } while (0)
 #endif
-template <int NTAPS, bool ROT>
+template <int NTAPS, int CC>
 __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const int bx, const int by, const int bz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using M = WMma<bf16_t>;
@@ -654,10 +655,14 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
             ws_wait_vm<0>();                                            // the zero-reads issued behind the last tile
             EGM_WS_DUMP(wv == 4, 16);
         };
-        if (p.A == 1 && p.B == 1) run(std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
-        else if (p.A == 2 && p.B == 1) run(std::integral_constant<int, 2>(), std::integral_constant<int, 1>());
-        else if (p.A == 1) run(std::integral_constant<int, 1>(), std::integral_constant<int, 2>());
-        else run(std::integral_constant<int, 2>(), std::integral_constant<int, 2>());
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        if constexpr (CC == 1) run(I2(), I2());                         // C = 4 / (A B) fixes the block counts of the rotation kernels
+        else if constexpr (CC == 4) run(I1(), I1());
+        else if constexpr (CC == 2) { if (p.A == 2) run(I2(), I1()); else run(I1(), I2()); }
+        else if (p.A == 1 && p.B == 1) run(I1(), I1());
+        else if (p.A == 2 && p.B == 1) run(I2(), I1());
+        else if (p.A == 1) run(I1(), I2());
+        else run(I2(), I2());
         if (p.C > 1) { __syncthreads(); __syncthreads(); }             // the consumers' cross-wave reduction (wgrad_reduce_rows)
         return;
     }
@@ -682,8 +687,8 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) acc[t] = M::mma(fa, fb[t], acc[t]);
         };
-        if constexpr (ROT) {
-            static_assert(NTAPS == 9, "row rotation is the 3x3 form");
+        if constexpr (CC != 0) {
+            static_assert(NTAPS == 9 && (CC == 1 || CC == 2 || CC == 4), "row rotation is the 3x3 form");
             {
                 // Row rotation (the 64-wide layers: every wave walks ALL rows of the tile).  Tap (r, s) of output row ry reads patch row
                 // ry + r, and that is the row tap (r - 1, s) reads one step later: the three patch rows of a step stay in registers and
@@ -694,34 +699,53 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
                 // taps come last in a step, so the new row's reads have six MFMAs to land.
                 // one step = one output row: reads patch row ry + 2 into `n` and the NEXT row's dy fragment, multiplies with the rows held
                 // in (a, b, n); the callers rotate the three row sets, so no fragment is ever moved between registers
-                auto row_step = [&](int ry, int k0, M::Frag (&ra)[3], M::Frag (&rb)[3], M::Frag (&rn)[3], M::Frag& fa, M::Frag& fan)
-                                    __attribute__((always_inline)) {
+                // The pixel rows and the two 16-pixel k-steps of a tile are shared out so that every wave rotates: C = 1 all 8 rows, both
+                // k-steps; C = 2 all 8 rows of k-step wc; C = 4 rows 4 (wc >> 1) .. +4 of k-step wc & 1 (r04: the narrow layers, which
+                // took rows wc, wc + C, ... with all nine patch fragments re-read per step, ran 62-69 clocks per MFMA against 41 here).
+                // one pass = the wave's rows of one k-step; ab / bb point at (first row, k-step) of the dy / x block, so that every read
+                // below is that base plus an immediate
+                auto rot_pass = [&](const unsigned char* ab, const unsigned char* bb, auto nrows_) __attribute__((always_inline)) {
+                    constexpr int NR = decltype(nrows_)::value;
+                    auto row_step = [&](auto ry_, M::Frag (&ra)[3], M::Frag (&rb)[3], M::Frag (&rn)[3], M::Frag& fa, M::Frag& fan)
+                                        __attribute__((always_inline)) {
+                        constexpr int ry = decltype(ry_)::value;
 #pragma unroll
-                    for (int sx = 0; sx < 3; ++sx) rn[sx] = M::load(bblk, (ry + 2) * PW + k0 + sx, lane);
-                    if (ry + 1 < TH) fan = M::load(ablk, (ry + 1) * TW + k0, lane);
+                        for (int sx = 0; sx < 3; ++sx) rn[sx] = M::load(bb, (ry + 2) * PW + sx, lane);
+                        if constexpr (ry + 1 < NR) fan = M::load(ab, (ry + 1) * TW, lane);
 #pragma unroll
-                    for (int sx = 0; sx < 3; ++sx) acc[sx] = M::mma(fa, ra[sx], acc[sx]);
+                        for (int sx = 0; sx < 3; ++sx) acc[sx] = M::mma(fa, ra[sx], acc[sx]);
 #pragma unroll
-                    for (int sx = 0; sx < 3; ++sx) acc[3 + sx] = M::mma(fa, rb[sx], acc[3 + sx]);
+                        for (int sx = 0; sx < 3; ++sx) acc[3 + sx] = M::mma(fa, rb[sx], acc[3 + sx]);
 #pragma unroll
-                    for (int sx = 0; sx < 3; ++sx) acc[6 + sx] = M::mma(fa, rn[sx], acc[6 + sx]);
-                    __builtin_amdgcn_sched_barrier(0);              // keeps the next steps' reads from being hoisted (spills otherwise)
-                };
-#pragma unroll 1
-                for (int k0 = 0; k0 < TW; k0 += M::kStep) {
+                        for (int sx = 0; sx < 3; ++sx) acc[6 + sx] = M::mma(fa, rn[sx], acc[6 + sx]);
+                        __builtin_amdgcn_sched_barrier(0);          // keeps the next steps' reads from being hoisted (spills otherwise)
+                    };
+                    using std::integral_constant;
                     M::Frag r0[3], r1[3], r2[3], f0, f1;
 #pragma unroll
-                    for (int sx = 0; sx < 3; ++sx) { r0[sx] = M::load(bblk, k0 + sx, lane); r1[sx] = M::load(bblk, PW + k0 + sx, lane); }
-                    f0 = M::load(ablk, k0, lane);
-                    static_assert(TH == 8, "the row rotation below is written out for 8-row tiles");
-                    row_step(0, k0, r0, r1, r2, f0, f1);
-                    row_step(1, k0, r1, r2, r0, f1, f0);
-                    row_step(2, k0, r2, r0, r1, f0, f1);
-                    row_step(3, k0, r0, r1, r2, f1, f0);
-                    row_step(4, k0, r1, r2, r0, f0, f1);
-                    row_step(5, k0, r2, r0, r1, f1, f0);
-                    row_step(6, k0, r0, r1, r2, f0, f1);
-                    row_step(7, k0, r1, r2, r0, f1, f0);
+                    for (int sx = 0; sx < 3; ++sx) { r0[sx] = M::load(bb, sx, lane); r1[sx] = M::load(bb, PW + sx, lane); }
+                    f0 = M::load(ab, 0, lane);
+                    row_step(integral_constant<int, 0>(), r0, r1, r2, f0, f1);
+                    row_step(integral_constant<int, 1>(), r1, r2, r0, f1, f0);
+                    row_step(integral_constant<int, 2>(), r2, r0, r1, f0, f1);
+                    row_step(integral_constant<int, 3>(), r0, r1, r2, f1, f0);
+                    if constexpr (NR == 8) {
+                        row_step(integral_constant<int, 4>(), r1, r2, r0, f0, f1);
+                        row_step(integral_constant<int, 5>(), r2, r0, r1, f1, f0);
+                        row_step(integral_constant<int, 6>(), r0, r1, r2, f0, f1);
+                        row_step(integral_constant<int, 7>(), r1, r2, r0, f1, f0);
+                    }
+                };
+                static_assert(TH == 8 && TW == 2 * M::kStep, "the row rotation is written out for 8-row, two-k-step tiles");
+                constexpr int KB = M::kStep * M::kRowBytes;           // bytes between the k-steps of a row
+                if constexpr (CC == 1) {
+#pragma unroll 1
+                    for (int ks = 0; ks < 2; ++ks) rot_pass(ablk + ks * KB, bblk + ks * KB, std::integral_constant<int, 8>());
+                } else if constexpr (CC == 2) {
+                    rot_pass(ablk + wc * KB, bblk + wc * KB, std::integral_constant<int, 8>());
+                } else {
+                    const int r0w = (wc >> 1) * 4, ko = (wc & 1) * KB;
+                    rot_pass(ablk + r0w * TW * M::kRowBytes + ko, bblk + r0w * PW * M::kRowBytes + ko, std::integral_constant<int, 4>());
                 }
                 return;
             }
@@ -761,15 +785,15 @@ __device__ __forceinline__ void conv_wgrad_ws_body(const WgradParams& p, const i
     EGM_WS_DUMP(wv == 0, 0);
 }
 
-template <int NTAPS, bool ROT>
+template <int NTAPS, int CC>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_kernel(WgradParams p) {
-    conv_wgrad_ws_body<NTAPS, ROT>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+    conv_wgrad_ws_body<NTAPS, CC>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
-template <int NTAPS, bool ROT>
+template <int NTAPS, int CC>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_ws_multi_kernel(WgradMulti m) {
     int bx, by, bz;
     const int i = wgrad_multi_member(m, bx, by, bz);
-    conv_wgrad_ws_body<NTAPS, ROT>(m.p[i], bx, by, bz);
+    conv_wgrad_ws_body<NTAPS, CC>(m.p[i], bx, by, bz);
 }
 
 // sum slabs in fixed order and scatter to fp32 OIHW (real, possibly grouped, shape).
@@ -988,16 +1012,16 @@ int launch_wgrad_group(const EgmGroupRec* recs, int n, hipStream_t st) {
     }
     return launch_wgrad_group_impl(recs, n, st, conv_wgrad_kernel<T, NTAPS>, conv_wgrad_multi_kernel<T, NTAPS>, 256, "conv_wgrad (group)");
 }
-template <int NTAPS, bool ROT>
+template <int NTAPS, int CC>
 int launch_wgrad_ws_group(const EgmGroupRec* recs, int n, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ws_multi_kernel<NTAPS, ROT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ws_multi_kernel<NTAPS, CC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_wgrad_ws_multi: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    return launch_wgrad_group_impl(recs, n, st, conv_wgrad_ws_kernel<NTAPS, ROT>, conv_wgrad_ws_multi_kernel<NTAPS, ROT>, 512, "conv_wgrad_ws (group)");
+    return launch_wgrad_group_impl(recs, n, st, conv_wgrad_ws_kernel<NTAPS, CC>, conv_wgrad_ws_multi_kernel<NTAPS, CC>, 512, "conv_wgrad_ws (group)");
 }
 // records the launch when a group is open on this thread
 inline bool wgrad_record(int (*fn)(const EgmGroupRec*, int, hipStream_t), const WgradParams& p, dim3 grid, size_t smem) {
@@ -1027,18 +1051,18 @@ int launch_wgrad_4w(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     EGM_CHECK_LAUNCH("conv_wgrad");
     return EGM_OK;
 }
-template <int NTAPS, bool ROT>
+template <int NTAPS, int CC>
 int launch_wgrad_ws_rot(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ws_kernel<NTAPS, ROT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ws_kernel<NTAPS, CC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "conv_wgrad_ws: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     dim3 grid(pl.nsplit, pl.nco_tiles * pl.nci_tiles, pl.ngroups);
-    if (wgrad_record(&launch_wgrad_ws_group<NTAPS, ROT>, p, grid, pl.smem)) return EGM_OK;
-    hipLaunchKernelGGL((conv_wgrad_ws_kernel<NTAPS, ROT>), grid, dim3(512), pl.smem, st, p);
+    if (wgrad_record(&launch_wgrad_ws_group<NTAPS, CC>, p, grid, pl.smem)) return EGM_OK;
+    hipLaunchKernelGGL((conv_wgrad_ws_kernel<NTAPS, CC>), grid, dim3(512), pl.smem, st, p);
     EGM_CHECK_LAUNCH("conv_wgrad_ws");
     return EGM_OK;
 }
@@ -1046,9 +1070,13 @@ template <int NTAPS>
 int launch_wgrad_ws(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
     if constexpr (NTAPS == 9) {
         static const bool rot_on = getenv("EGM_WGRAD_ROT") ? atoi(getenv("EGM_WGRAD_ROT")) != 0 : true;
-        if (pl.C == 1 && rot_on) return launch_wgrad_ws_rot<NTAPS, true>(p, pl, st);
+        if (rot_on) {
+            if (pl.C == 1) return launch_wgrad_ws_rot<NTAPS, 1>(p, pl, st);
+            if (pl.C == 2) return launch_wgrad_ws_rot<NTAPS, 2>(p, pl, st);
+            return launch_wgrad_ws_rot<NTAPS, 4>(p, pl, st);
+        }
     }
-    return launch_wgrad_ws_rot<NTAPS, false>(p, pl, st);
+    return launch_wgrad_ws_rot<NTAPS, 0>(p, pl, st);
 }
 template <typename T, int NTAPS>
 int launch_wgrad(const WgradParams& p, const WgradPlan& pl, hipStream_t st) {
@@ -1095,7 +1123,7 @@ extern "C" int egm_conv_wgrad_kernel_name(int dtype, int N, int H, int W, int Ci
     static const bool rot_on = getenv("EGM_WGRAD_ROT") ? atoi(getenv("EGM_WGRAD_ROT")) != 0 : true;
     if (pl.c7) snprintf(tmp, sizeof(tmp), pl.c7 == 1 ? "conv7x7_c16_wgrad_kernel" : "conv3x3d_c16_wgrad_kernel");
     else if (dtype == EGM_BF16 && pl.ws)
-        snprintf(tmp, sizeof(tmp), "conv_wgrad_ws_kernel<%d, %s>", pl.ntaps, (pl.ntaps == 9 && pl.C == 1 && rot_on) ? "true" : "false");
+        snprintf(tmp, sizeof(tmp), "conv_wgrad_ws_kernel<%d, %d>", pl.ntaps, (pl.ntaps == 9 && rot_on) ? pl.C : 0);
     else
         snprintf(tmp, sizeof(tmp), "conv_wgrad_kernel<%s, %d>", dtype == EGM_BF16 ? "bf16_t" : "float", pl.ntaps);
     const int n = (int)strlen(tmp);
@@ -1153,6 +1181,22 @@ extern "C" int egm_conv_wgrad(int dtype, const void* x, int ldx, const void* dy,
     if (rc != EGM_OK) return rc;
     if (dw == nullptr) return EGM_OK;                  // slabs only: the caller reduces later with egm_wgrad_reduce_multi
     return egm_wgrad_reduce((const float*)workspace, dw, pl.nsplit, KH * KW, Cout, Cin, CoutR, CinR, groups, accumulate, s);
+}
+
+/* The slab-only form of up to EGM_WGRAD_MULTI_MAX independent convolutions as one call: those that take the same kernel instantiation
+ * share ONE launch (group.h; egm_conv_wgrad_kernel_name tells which do), the others follow one by one.  For the deferred weight
+ * gradients of a backward pass, whose slabs nobody reads before egm_wgrad_reduce_multi: a merged launch has one pipeline fill and
+ * drain where four launches have four (5-8 us + 5 us each on the 3x3 layers of the benchmarked step). */
+extern "C" int egm_conv_wgrad_multi(int dtype, const egm_conv_wgrad_desc* d, int n, egm_stream_t s) {
+    EGM_REQUIRE(d && n > 0 && n <= EGM_WGRAD_MULTI_MAX, "conv_wgrad_multi: 1..%d convolutions per call", EGM_WGRAD_MULTI_MAX);
+    EGM_REQUIRE(!egm_group_recording(), "conv_wgrad_multi: called inside an open launch group");
+    int rc = egm_group_begin();
+    if (rc != EGM_OK) return rc;
+    for (int i = 0; i < n && rc == EGM_OK; ++i)
+        rc = egm_conv_wgrad(dtype, d[i].x, d[i].ldx, d[i].dy, d[i].lddy, nullptr, d[i].slabs, d[i].N, d[i].H, d[i].W, d[i].Cin, d[i].Cout, d[i].Cin_real,
+                            d[i].Cout_real, d[i].KH, d[i].KW, d[i].dil, d[i].groups, 0, s);
+    if (rc != EGM_OK) { egm_group_abort(); return rc; }
+    return egm_group_end(s);
 }
 
 /* slabs [nslab][taps][CoutP][CinP] summed in slab order -> dw fp32 OIHW (real, possibly grouped, shape); one convolution, at once */

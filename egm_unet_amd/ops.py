@@ -3,6 +3,7 @@
 Activations are NHWC tensors ``[N, H, W, C]`` (fp32 or bf16, C a multiple of 8, possibly a channel-slice view of a
 wider buffer).  torch is used for memory (torch.empty / views), streams and autograd bookkeeping only.
 """
+import ctypes
 import os
 import struct
 import weakref
@@ -321,6 +322,7 @@ def _flush_wgrads(ready_only=False):
     gradient tensor autograd has already adopted and leaves the others pending."""
     if not ready_only:
         _wgrad_run[0] = None
+    _launch_pending_slabs()
     if not _pending_wgrad:
         return
     todo, later = [], []
@@ -496,12 +498,17 @@ def _wgrad_deferrable(weight):
             and not weight._backward_hooks and not torch.is_grad_enabled())
 
 
-def _queue_wgrad(ws, weight, nslab, taps, CoutP, CinP, Cout, Cin, groups, gw):
+def _wgrad_run_begin():
     run = torch._C._current_graph_task_id()
     if run != _wgrad_run[0]:              # per engine run (an aborted backward never ran its callback: its entries are dead)
         _pending_wgrad.clear()
+        _pending_slab_launch.clear()
         Variable._execution_engine.queue_callback(_flush_wgrads)
         _wgrad_run[0] = run
+
+
+def _queue_wgrad(ws, weight, nslab, taps, CoutP, CinP, Cout, Cin, groups, gw):
+    _wgrad_run_begin()
     _pending_wgrad.append((ws, weight, nslab, taps, CoutP, CinP, Cout, Cin, groups, weakref.ref(gw), gw.data_ptr()))
 
 
@@ -570,6 +577,51 @@ def _conv_grads(x, ldx, dy, weight, wd, dil, groups, Cin, Cout, need_gx, need_gw
     return gx, gw
 
 
+_MERGE_WGRAD = os.environ.get("EGM_MERGE_WGRAD", "1") != "0"
+_pending_slab_launch = []                 # deferred slab-kernel launches (argument tuples holding their tensors)
+
+
+def merge_wgrads(enabled=None):
+    """Get / set whether the slab kernels of deferred weight gradients are launched together when backward ends (merged launches)."""
+    global _MERGE_WGRAD
+    if enabled is not None:
+        _MERGE_WGRAD = bool(enabled)
+    return _MERGE_WGRAD
+
+
+_WGRAD_DESC = struct.Struct("<3Q14i")       # egm_conv_wgrad_desc
+_wgrad_names = {}
+
+
+def _wgrad_kernel_of(dt, N, H, W, CinP, CoutP, KH, KW, dil):
+    key = (dt, N, H, W, CinP, CoutP, KH, KW, dil)
+    name = _wgrad_names.get(key)
+    if name is None:
+        buf = ctypes.create_string_buffer(96)
+        lib().cdll.egm_conv_wgrad_kernel_name(dt, N, H, W, CinP, CoutP, KH, KW, dil, ctypes.cast(buf, ctypes.c_void_p), 96)
+        name = _wgrad_names[key] = buf.value
+    return name
+
+
+def _launch_pending_slabs():
+    """The queued slab kernels, in queue order, those of one kernel instantiation four to a launch (egm_conv_wgrad_multi)."""
+    if not _pending_slab_launch:
+        return
+    L, st = lib(), stream()
+    todo = list(_pending_slab_launch)
+    _pending_slab_launch.clear()
+    buckets = {}
+    for ent in todo:
+        dt, x, ldx, gy, ldg, ws, N, H, W, CinP, CoutP, Cin, Cout, KH, KW, dil, groups = ent
+        buckets.setdefault((dt, _wgrad_kernel_of(dt, N, H, W, CinP, CoutP, KH, KW, dil)), []).append(ent)
+    per = 4                                                            # EGM_WGRAD_MULTI_MAX
+    for (dt, _name), ents in buckets.items():
+        for i in range(0, len(ents), per):
+            blob = b"".join(_WGRAD_DESC.pack(x.data_ptr(), gy.data_ptr(), ws.data_ptr(), ldx, ldg, N, H, W, CinP, CoutP, Cin, Cout, KH, KW, dil, groups, 0)
+                            for _dt, x, ldx, gy, ldg, ws, N, H, W, CinP, CoutP, Cin, Cout, KH, KW, dil, groups in ents[i:i + per])
+            L.call("egm_conv_wgrad_multi", dt, blob, len(ents[i:i + per]), st)
+
+
 def _conv_wgrad(x, ldx, gy, ldg, weight, dil, groups, Cin, Cout, defer=None):
     """Weight gradient of one conv; deferred slab reduction when that is safe."""
     N, H, W, CinP = x.shape
@@ -581,8 +633,14 @@ def _conv_wgrad(x, ldx, gy, ldg, weight, dil, groups, Cin, Cout, defer=None):
     ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=x.device)
     if defer is None:                     # (a caller that asked already -- _wgrad_deferrable consumes the use note -- passes the answer)
         defer = _wgrad_deferrable(weight)
-    L.call("egm_conv_wgrad", dt, ptr(x), ldx, ptr(gy), ldg, None if defer else ptr(gw), ptr(ws), N, H, W, CinP, CoutP, Cin, Cout, KH, KW, dil,
-           groups, 0, st)
+    if defer and _MERGE_WGRAD:
+        _wgrad_run_begin()
+        # nothing reads the slabs before the end-of-backward reduction: the launch itself waits for it too and shares launches with the
+        # other deferred ones (_flush_wgrads); x and gy stay alive in the queue entry
+        _pending_slab_launch.append((dt, x, ldx, gy, ldg, ws, N, H, W, CinP, CoutP, Cin, Cout, KH, KW, dil, groups))
+    else:
+        L.call("egm_conv_wgrad", dt, ptr(x), ldx, ptr(gy), ldg, None if defer else ptr(gw), ptr(ws), N, H, W, CinP, CoutP, Cin, Cout, KH, KW,
+               dil, groups, 0, st)
     if defer:
         nslab = L.query("egm_conv_wgrad_slabs", dt, N, H, W, CinP, CoutP, KH, KW, dil)
         _queue_wgrad(ws, weight, nslab, KH * KW, CoutP, CinP, Cout, Cin, groups, gw)

@@ -114,6 +114,16 @@ int egm_conv_wgrad(int dtype, const void* x, int ldx, const void* dy, int lddy, 
  * entries {const float* slab; float* dw; int nslab, taps, CoutP, CinP, CoutR, CinR, groups, accumulate, chunk0, pad;};
  * chunks per entry = ceil(taps*CoutP*CinP / egm_wgrad_reduce_chunk()), chunk0 / total_chunks as for egm_conv_pack_multi. */
 int egm_conv_wgrad_kernel_name(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil, char* buf, int buflen);   /* as egm_conv_kernel_name */
+/* egm_conv_wgrad's slab-only form (dw == NULL) for 1..EGM_WGRAD_MULTI_MAX independent convolutions in one call: members that take the
+ * same kernel instantiation (egm_conv_wgrad_kernel_name) run as ONE launch.  Arguments per member as egm_conv_wgrad's; slabs =
+ * its workspace.  (The reference has no counterpart: torch.autograd launches cudnn's weight-gradient kernel per conv, train_utils'
+ * loss.backward(); here the slabs of a backward pass have no reader before egm_wgrad_reduce_multi, so their launches can wait.) */
+#define EGM_WGRAD_MULTI_MAX 4
+typedef struct egm_conv_wgrad_desc {
+    const void* x; const void* dy; void* slabs;
+    int ldx, lddy, N, H, W, Cin, Cout, Cin_real, Cout_real, KH, KW, dil, groups, pad_;
+} egm_conv_wgrad_desc;
+int egm_conv_wgrad_multi(int dtype, const egm_conv_wgrad_desc* descs, int n, egm_stream_t stream);
 int egm_conv_wgrad_slabs(int dtype, int N, int H, int W, int Cin, int Cout, int KH, int KW, int dil);
 /* The reduction of ONE convolution's slabs, at once (what egm_conv_wgrad with dw != NULL runs behind its slab kernel). */
 int egm_wgrad_reduce(const float* slabs, float* dw_oihw_f32, int nslab, int taps, int CoutP, int CinP, int CoutR, int CinR, int groups,

@@ -69,3 +69,53 @@ def test_conv_bias_gradient_in_front_of_a_frozen_batchnorm_is_the_channel_sum():
     y = F.relu(bn(conv(x.permute(0, 3, 1, 2))))
     y.backward(go.permute(0, 3, 1, 2))
     assert float((gb - conv.bias.grad).norm() / conv.bias.grad.norm()) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_merged_slab_launches_give_the_gradients_of_separate_launches(dtype):
+    """ops.merge_wgrads: the slab kernels of the deferred weight gradients wait for the end of backward and share launches
+    (egm_conv_wgrad_multi).  Same kernels on the same operands: every gradient must be bit-equal to the launch-at-once form -- which also
+    shows that no x / dy tensor of a queued launch was overwritten before the launch ran."""
+    from egm_unet_amd import ops
+    default = ops.merge_wgrads()
+    got = {}
+    try:
+        for merged in (False, True):
+            ops.merge_wgrads(merged)
+            m, x, gl = _model_and_batch(dtype)
+            m(x)["out"].backward(gl)
+            torch.cuda.synchronize()
+            assert not ops._pending_slab_launch and not ops._pending_wgrad
+            got[merged] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    finally:
+        ops.merge_wgrads(default)
+    assert got[True].keys() == got[False].keys() and len(got[True]) > 100
+    for k in got[True]:
+        assert torch.equal(got[True][k], got[False][k]), k
+
+
+def test_conv_wgrad_multi_equals_single_launches_and_refuses_bad_calls():
+    """egm_conv_wgrad_multi through the C ABI: four 3x3 layers of one kernel instantiation (one merged launch) and a 1x1 beside them give
+    the slabs of four egm_conv_wgrad calls, bit for bit; n = 0 / n > EGM_WGRAD_MULTI_MAX are refused."""
+    import struct
+    from egm_unet_amd._lib import lib, ptr, stream
+    L = lib()
+    desc = struct.Struct("<3Q14i")
+    g = torch.Generator().manual_seed(5)
+    shapes = [(2, 40, 36, 32, 32, 3), (1, 64, 64, 32, 32, 3), (2, 33, 70, 32, 24, 3), (2, 16, 48, 16, 32, 3)]
+    keep, blob, want = [], b"", []
+    for N, H, W, Cin, Cout, K in shapes:
+        x = torch.randn(N, H, W, Cin, generator=g).to(DEV).bfloat16()
+        dy = torch.randn(N, H, W, Cout, generator=g).to(DEV).bfloat16()
+        nfl = L.query("egm_conv_wgrad_workspace", N, H, W, Cin, Cout, K, K) // 4 + 4
+        ws1 = torch.zeros(nfl, dtype=torch.float32, device=DEV); ws2 = torch.zeros_like(ws1)
+        L.call("egm_conv_wgrad", 1, ptr(x), Cin, ptr(dy), Cout, None, ptr(ws1), N, H, W, Cin, Cout, Cin, Cout, K, K, 1, 1, 0, stream())
+        blob += desc.pack(x.data_ptr(), dy.data_ptr(), ws2.data_ptr(), Cin, Cout, N, H, W, Cin, Cout, Cin, Cout, K, K, 1, 1, 0)
+        keep.append((x, dy)); want.append((ws1, ws2))
+    L.call("egm_conv_wgrad_multi", 1, blob, len(shapes), stream())
+    torch.cuda.synchronize()
+    for ws1, ws2 in want:
+        assert torch.equal(ws1, ws2)
+    for n in (0, 5):
+        with pytest.raises(RuntimeError, match="conv_wgrad_multi"):
+            L.call("egm_conv_wgrad_multi", 1, blob, n, stream())
