@@ -794,8 +794,14 @@ ConvPlan conv_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH, in
         const long long npt4 = (long long)N * egm_cdiv(H, 16) * egm_cdiv(W, TW);
         if (npt4 >= 256) c.R = 4;
     }
+    static const int r1_on = getenv("EGM_PIPE_R1") ? atoi(getenv("EGM_PIPE_R1")) : 1;   // (r04: 20.1 -> 18.7 us per bottleneck conv)
+    if (r1_on && c.pipe && KH == 3 && dil == 1 && c.R == 2 && Cout > 32 && Cin >= 128) {
+        // the bottleneck (256 -> 256 at 32^2: 32 tiles of 8 x 32 pixels x 8 cout tiles = 256 workgroups, one per CU): 4-row tiles, 512
+        const long long wgs2 = (long long)N * egm_cdiv(H, 8) * egm_cdiv(W, TW) * egm_cdiv(Cout, 32);
+        if (wgs2 <= 256) c.R = 1;
+    }
     c.tiles_y = egm_cdiv(H, 4 * c.R); c.tiles_x = egm_cdiv(W, TW); c.npt = N * c.tiles_y * c.tiles_x;
-    c.NT = (c.R == 4) ? (Cout <= 32 ? 1 : 2) : conv_nt(c.npt, Cout);
+    c.NT = (c.R == 4) ? (Cout <= 32 ? 1 : 2) : (c.R == 1 ? 1 : conv_nt(c.npt, Cout));
     c.nct = egm_cdiv(Cout, 32 * c.NT);
     if (!c.pipe) { c.G = c.npt; return c; }
     if (c.R == 4) {
@@ -902,6 +908,7 @@ extern "C" int egm_conv_fwd(int dtype, const void* x, int ldx, const void* wf, c
         hipStream_t st = (hipStream_t)s;
         if (KH == 3 && dil == 1) {
             if (c.R == 4) return launch_pipe<1, 3, 3, 4>(p, c.G, st);                      // tall tiles: Cout <= 32 only (conv_plan)
+            if (c.R == 1) return launch_pipe<1, 3, 3, 1>(p, c.G, st);
             return NT == 2 ? launch_pipe<2, 3, 3, 2>(p, c.G, st) : launch_pipe<1, 3, 3, 2>(p, c.G, st);
         }
         if (KH == 7) return NT == 2 ? launch_pipe<2, 1, 7, 2>(p, c.G, st) : launch_pipe<1, 1, 7, 2>(p, c.G, st);

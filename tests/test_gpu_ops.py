@@ -90,6 +90,8 @@ CONV_CASES = [
     (8, 128, 128, 48, 96, 3, 1, 1, False),   # Cout = 3 x 32: 16 rows x 32 couts with three cout tiles per group, 3 chunks
     # LDS-free activation path (conv_direct.hip): wide-in / narrow-out 1x1, ragged and 32-aligned rows; dilated on aligned rows
     (2, 40, 44, 112, 16, 1, 1, 1, True),
+    # 4-row tiles of the pipelined kernel (few pixels, many channels: the bottleneck convs), ragged
+    (8, 32, 32, 256, 256, 3, 1, 1, False), (2, 20, 40, 128, 96, 3, 1, 1, True),
     # more 1x1 shapes: 4-14 channel chunks, 64- and 128-cout tiles, ragged pixel counts, Cout that is no multiple of 32
     (2, 30, 30, 128, 128, 1, 1, 1, True), (1, 33, 17, 256, 192, 1, 1, 1, False), (2, 16, 16, 448, 64, 1, 1, 1, False),
     (1, 20, 20, 224, 32, 1, 1, 1, True), (3, 9, 9, 8, 8, 1, 1, 1, True), (2, 31, 31, 64, 40, 1, 1, 1, False),
