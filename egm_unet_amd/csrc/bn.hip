@@ -408,6 +408,44 @@ extern "C" int egm_channel_sums(int dtype, const void* x, int ld, long long npix
     return EGM_OK;
 }
 
+/* ---- the bias gradients of a whole backward pass as two launches (db = sum over pixels of dy, nn.Conv2d biases that no BatchNorm follows:
+ * src/EGM-UNet.py:1256-1313 branch heads / tails, 1362-1390 attention convs, 1499 classifier).  One by one they were ~25 pairs of
+ * egm_channel_sums + egm_reduce_tiles per step, 5 us each for tensors that take 1-2 us to read; here every tensor keeps the block count,
+ * the per-block pixel set and the summation order of that pair (channel_partials_body<T, 0> and tiles_reduce are the same code), so the
+ * result is bit-identical to it.
+ * table: device array of 2n egm_bsum_entry -- entries [0, n) carry chunk0 = first stage-1 block of the tensor (nblk blocks each),
+ * entries [n, 2n) the same tensors with chunk0 = first stage-2 block (C/8 blocks each). */
+typedef egm_bsum_entry BsumEntry;
+static_assert(sizeof(BsumEntry) == 56, "egm_bsum_entry layout");
+
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sums_multi_kernel(const BsumEntry* __restrict__ tab, int n) {
+    const int k = egm_find_entry(tab, n, (long long)blockIdx.x);
+    const BsumEntry e = tab[k];
+    channel_partials_body<T, 0>((const T*)e.x, e.ld, (const T*)nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, e.npix, e.C, e.part,
+                                (int)blockIdx.x - e.chunk0, e.nblk);
+}
+__global__ __launch_bounds__(1024) void bias_reduce_multi_kernel(const BsumEntry* __restrict__ tab, int n) {
+    __shared__ double red[2048];
+    const int k = egm_find_entry(tab, n, (long long)blockIdx.x);
+    const BsumEntry e = tab[k];
+    const int c0 = ((int)blockIdx.x - e.chunk0) * 8;
+    double s, q;
+    tiles_reduce(e.part, e.nblk, e.C, c0, s, q, red);
+    const int c = c0 + (threadIdx.x & 7);
+    if (threadIdx.x < 8 && c < e.Cout) e.out[c] = (float)s;
+}
+
+extern "C" int egm_bias_grad_multi(int dtype, const void* table_dev, int n, long long blocks1, long long blocks2, egm_stream_t s) {
+    EGM_REQUIRE(table_dev && n > 0 && blocks1 > 0 && blocks2 > 0 && blocks1 < (1LL << 30) && blocks2 < (1LL << 30), "bias_grad_multi: bad args");
+    const BsumEntry* tab = (const BsumEntry*)table_dev;
+    EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_sums_multi_kernel<T>), dim3((unsigned)blocks1), dim3(256), 0, (hipStream_t)s, tab, n));
+    EGM_CHECK_LAUNCH("bias_grad_multi (partials)");
+    hipLaunchKernelGGL(bias_reduce_multi_kernel, dim3((unsigned)blocks2), dim3(1024), 0, (hipStream_t)s, tab + n, n);
+    EGM_CHECK_LAUNCH("bias_grad_multi (reduce)");
+    return EGM_OK;
+}
+
 extern "C" int egm_reduce_tiles_batched(const float* tiles, int batch, int ntiles, int C, float* out, egm_stream_t s) {
     EGM_REQUIRE(tiles && out && batch > 0 && ntiles > 0 && C > 0, "reduce_tiles_batched: bad args");
     hipLaunchKernelGGL(reduce_tiles_kernel, dim3((C + 7) / 8, batch), dim3(1024), 0, (hipStream_t)s, tiles, ntiles, C, out);

@@ -193,7 +193,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
     }
     const int wbo = WOFF + ((wc * NT * 32 + r31) * 2 + (h ^ ((r31 >> 3) & 1))) * 16;
 
+#ifdef EGM_TILE_MFMA16_PROXY
+    // TIMING PROXY ONLY (tools/conv_tile_bench.py under EGM_LIB_TAG=mfma16; results are wrong): every v_mfma_f32_32x32x16_bf16 is
+    // replaced by two v_mfma_f32_16x16x32_bf16 on the same operand registers (same MFMA cycles, 2 x 16, same LDS reads, DMA and barriers),
+    // each writing one 4-register block of the accumulator tile -- the instruction mix a two-taps-per-MFMA kernel would issue, without its
+    // fragment layout.  Bounds what the instruction swap can return before the layout is worked out.
+    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+#endif
     f32x16_t acc[R][NT];
+#define EGM_ACC(m, nt, i) acc[m][nt][i]
     float ssum[8], ssq[8];
     zero8(ssum); zero8(ssq);
 
@@ -223,7 +231,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
                     const int r = rho - m;
                     if (r >= 0 && r < 3) {
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[r][nt], fb, acc[m][nt], 0, 0, 0);
+                        for (int nt = 0; nt < NT; ++nt) {
+#ifdef EGM_TILE_MFMA16_PROXY
+                            f32x16_t& a = acc[m][nt];
+                            if (((r * 3 + s) & 1) == 0) {
+                                f32x4_t t0 = __builtin_shufflevector(a, a, 0, 1, 2, 3), t1 = __builtin_shufflevector(a, a, 4, 5, 6, 7);
+                                t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[r][nt], fb, t0, 0, 0, 0);
+                                t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[r][nt], fb, t1, 0, 0, 0);
+                                a[0] = t0[0]; a[1] = t0[1]; a[2] = t0[2]; a[3] = t0[3]; a[4] = t1[0]; a[5] = t1[1]; a[6] = t1[2]; a[7] = t1[3];
+                            } else {
+                                f32x4_t t0 = __builtin_shufflevector(a, a, 8, 9, 10, 11), t1 = __builtin_shufflevector(a, a, 12, 13, 14, 15);
+                                t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[r][nt], fb, t0, 0, 0, 0);
+                                t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[r][nt], fb, t1, 0, 0, 0);
+                                a[8] = t0[0]; a[9] = t0[1]; a[10] = t0[2]; a[11] = t0[3]; a[12] = t1[0]; a[13] = t1[1]; a[14] = t1[2]; a[15] = t1[3];
+                            }
+#else
+                            acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[r][nt], fb, acc[m][nt], 0, 0, 0);
+#endif
+                        }
                     }
                 }
                 const int gi = s * (R + 2) + rho;
@@ -249,12 +274,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int co = co0 + wc * NT * 32 + nt * 32 + gq * 8 + h * 4 + j;
-                            acc[m][nt][gq * 4 + j] += co < p.bias_n ? p.bias[co] : 0.f;
+                            EGM_ACC(m, nt, gq * 4 + j) += co < p.bias_n ? p.bias[co] : 0.f;
                         }
                     }
                     uint2 v;
-                    v.x = pack_bf16x2(acc[m][nt][gq * 4 + 0], acc[m][nt][gq * 4 + 1]);
-                    v.y = pack_bf16x2(acc[m][nt][gq * 4 + 2], acc[m][nt][gq * 4 + 3]);
+                    v.x = pack_bf16x2(EGM_ACC(m, nt, gq * 4 + 0), EGM_ACC(m, nt, gq * 4 + 1));
+                    v.y = pack_bf16x2(EGM_ACC(m, nt, gq * 4 + 2), EGM_ACC(m, nt, gq * 4 + 3));
                     *reinterpret_cast<uint2*>(ot + r31 * OROW + (nt * 32 + gq * 8 + h * 4) * 2) = v;
                 }
             // read back whole channel vectors (same wave: its LDS operations complete in order) and store coalesced
@@ -327,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[m][nt][i] = 0.f;
+                    for (int i = 0; i < 16; ++i) EGM_ACC(m, nt, i) = 0.f;
         }
         if (!(p.dbg & 2)) compute(bc, with_dma, q);
         EGM_TICK(2);
@@ -430,6 +455,9 @@ int egm_conv_tile_plan(int dtype, int N, int H, int W, int Cin, int Cout, int KH
     if (Cout % 32 != 0) return 0;
     if (egm_group_recording()) return 0;                     // merged launches of small sibling convs stay on the 4-wave kernel
     if (!(egm_conv_tile_mode(-1) & 1)) return 0;
+    static int min_cin = -1;
+    if (min_cin < 0) min_cin = getenv("EGM_TILE_MIN_CIN") ? atoi(getenv("EGM_TILE_MIN_CIN")) : 16;
+    if (Cin < min_cin) return 0;
     const int tx = egm_cdiv(W, TW);
     int best = -1, best_nct = 0, best_npt = 0;
     long long best_score = -1;

@@ -322,6 +322,7 @@ def _flush_wgrads(ready_only=False):
     gradient tensor autograd has already adopted and leaves the others pending."""
     if not ready_only:
         _wgrad_run[0] = None
+    _flush_bgrads(ready_only)
     _launch_pending_slabs()
     if not _pending_wgrad:
         return
@@ -362,6 +363,77 @@ def _flush_wgrads(ready_only=False):
 
 def flush_ready_wgrads():
     _flush_wgrads(ready_only=True)
+
+
+# deferred bias gradients: db = sum over pixels of dy for every nn.Conv2d bias that no BatchNorm follows, as ONE pair of launches when
+# backward ends (egm_bias_grad_multi) instead of a pair per layer inside it.  Same hand-over protocol as the deferred weight gradients:
+# backward() returns an unfilled [Cout] tensor that autograd adopts as bias.grad (no reference kept here, so it is not copied), the
+# queue entry keeps dy alive and finds the tensor again through a weak reference or bias.grad's address.
+_DEFER_BGRAD = os.environ.get("EGM_DEFER_BGRAD", "1") != "0"
+_pending_bgrad = []
+_bgrad_table = DeviceTable()
+_bgrad_table_partial = DeviceTable()
+_BSUM_ENTRY = struct.Struct("<3Qq6i")       # egm_bsum_entry
+
+
+def defer_bgrads(enabled=None):
+    """Get / set whether conv bias gradients are left to the one multi-tensor pass at the end of backward."""
+    global _DEFER_BGRAD
+    if enabled is not None:
+        _DEFER_BGRAD = bool(enabled)
+    return _DEFER_BGRAD
+
+
+def _bias_grad(gy, Cout, bias=None, defer=False):
+    """db[c] = sum over pixels of gy[..., c] (gy NHWC, channels padded) -> fp32 [Cout].  defer: the conv's weight gradient is being
+    deferred in this backward (so this is the only use of the layer in it) -- the bias gradient then joins the end-of-backward pass."""
+    if (defer and _DEFER_BGRAD and bias is not None and bias.is_leaf and bias.grad is None and not bias._backward_hooks
+            and not torch.is_grad_enabled()):
+        gy, ldg = _nhwc(gy)
+        gb = torch.empty(Cout, dtype=torch.float32, device=gy.device)
+        _wgrad_run_begin()
+        _pending_bgrad.append((gy, ldg, _npix(gy), gy.shape[3], Cout, bias, weakref.ref(gb), gb.data_ptr()))
+        return gb
+    return _channel_sum(gy)[0, :Cout]
+
+
+def _flush_bgrads(ready_only=False):
+    if not _pending_bgrad:
+        return
+    todo, later = [], []
+    for ent in _pending_bgrad:
+        bias, gref, gptr = ent[5], ent[6], ent[7]
+        g = gref()
+        if g is None and bias.grad is not None and bias.grad.data_ptr() == gptr:
+            g = bias.grad
+        if g is not None:
+            todo.append(ent)
+        elif ready_only:
+            later.append(ent)
+        elif bias.grad is not None:
+            raise RuntimeError("deferred conv bias gradient lost its destination: bias.grad exists but is not the buffer backward() "
+                               "returned (tensor hook / gradient copy); set EGM_DEFER_BGRAD=0 for this model")
+        # else: the gradient was discarded (torch.autograd.grad() result dropped, bias not among backward(inputs=...))
+    _pending_bgrad[:] = later
+    if not todo:
+        return
+    L = lib()
+    by_dtype = {}
+    for ent in todo:
+        by_dtype.setdefault(ent[0].dtype, []).append(ent)
+    for dtype, ents in by_dtype.items():
+        dev = ents[0][0].device
+        nblks = [L.query("egm_channel_partials_blocks", npix, C) for _gy, _ld, npix, C, *_ in ents]
+        ws = torch.empty(sum(nb * 2 * ent[3] for nb, ent in zip(nblks, ents)), dtype=torch.float32, device=dev)
+        blob1, blob2, b1, b2, off = bytearray(), bytearray(), 0, 0, 0
+        for nb, (gy, ldg, npix, C, Cout, _bias, _gref, gptr) in zip(nblks, ents):
+            part = ws.data_ptr() + 4 * off
+            blob1 += _BSUM_ENTRY.pack(gy.data_ptr(), part, gptr, npix, ldg, C, Cout, nb, b1, 0)
+            blob2 += _BSUM_ENTRY.pack(gy.data_ptr(), part, gptr, npix, ldg, C, Cout, nb, b2, 0)
+            b1 += nb; b2 += C // 8; off += nb * 2 * C
+        _bgrad_table.reserve(dev); _bgrad_table_partial.reserve(dev)
+        table = (_bgrad_table_partial if ready_only else _bgrad_table).get(bytes(blob1 + blob2), dev)
+        L.call("egm_bias_grad_multi", dtype_code(dtype), ptr(table), len(ents), b1, b2, stream())
 
 
 def _channel_sum(t):
@@ -503,6 +575,7 @@ def _wgrad_run_begin():
     if run != _wgrad_run[0]:              # per engine run (an aborted backward never ran its callback: its entries are dead)
         _pending_wgrad.clear()
         _pending_slab_launch.clear()
+        _pending_bgrad.clear()
         Variable._execution_engine.queue_callback(_flush_wgrads)
         _wgrad_run[0] = run
 
@@ -706,6 +779,7 @@ class _Conv2d(Function):
         ctx.save_for_backward(x, weight, wd)
         ctx.meta = (dil, groups, bias is not None, Cin_g * groups, Cout)
         ctx.bias_grad_zero = bias_grad_zero
+        ctx.bias = bias                                 # (a leaf parameter: looked at in backward for the deferred bias gradient)
         # the caller vouches that x is the materialised output of a conv -> BatchNorm(+act) node and has no other consumer
         ctx.defer_dgrad = bool(defer_dgrad and weight.shape[2] == 1 and weight.shape[3] == 1 and groups == 1
                                and Cout <= 8 and weight.is_contiguous() and _dz_fusable(x.shape[3]))
@@ -729,11 +803,12 @@ class _Conv2d(Function):
         L, dt, st = lib(), dtype_code(x.dtype), stream()
         gx = gw = gb = None
         need_gx, need_gw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        defer = _wgrad_deferrable(weight) if need_gw else False     # (consumes the weight's use note: asked once per backward)
         if has_bias and ctx.needs_input_grad[2]:
-            gb = _zero_grad_vec(Cout, x.device) if ctx.bias_grad_zero else _channel_sum(gy)[0, :Cout]
+            gb = _zero_grad_vec(Cout, x.device) if ctx.bias_grad_zero else _bias_grad(gy, Cout, ctx.bias, defer)
         if need_gw and not (need_gx and ctx.defer_dgrad and _FUSE_DZ) and _c1_shape_ok(x, gy, weight, dil, groups):
             # 1x1: data gradient + weight-gradient slabs from ONE pass over gy and x
-            gx, gw = _conv1x1_bwd([(x, ldx, gy, ldg, weight, wd, need_gx, _wgrad_deferrable(weight))])[0]
+            gx, gw = _conv1x1_bwd([(x, ldx, gy, ldg, weight, wd, need_gx, defer)])[0]
             return gx, gw, gb, None, None, None, None, None
         if need_gx:
             gx = torch.empty((N, H, W, CinP), dtype=x.dtype, device=x.device)
@@ -743,7 +818,7 @@ class _Conv2d(Function):
             else:
                 L.call("egm_conv_fwd", dt, ptr(gy), ldg, ptr(wd), None, 0, ptr(gx), CinP, None, N, H, W, CoutP, CinP, KH, KW, dil, st)
         if need_gw and gw is None:
-            gw = _conv_wgrad(x, ldx, gy, ldg, weight, dil, groups, Cin, Cout)
+            gw = _conv_wgrad(x, ldx, gy, ldg, weight, dil, groups, Cin, Cout, defer=defer)
         return gx, gw, gb, None, None, None, None, None
 
 
@@ -802,6 +877,7 @@ class _BnActCls(Function):
             _note_conv_use(weight)
         ctx.save_for_backward(z, weight)
         ctx.meta = (nc, Cin, bias is not None)
+        ctx.bias = bias
         return logits
 
     @staticmethod
@@ -814,10 +890,11 @@ class _BnActCls(Function):
         dl = torch.empty((N, H, W, 8), dtype=z.dtype, device=dev)            # NHWC, channels nc..7 zero-filled
         L.call("egm_nchw_to_nhwc", dt, ptr(g), ptr(dl), 8, N, nc, H, W, st)
         gy = gw = gb = None
+        defer = _wgrad_deferrable(weight) if ctx.needs_input_grad[3] else False
         if ctx.needs_input_grad[3]:
-            gw = _conv_wgrad(z, C, dl, 8, weight, 1, 1, Cin, nc)
+            gw = _conv_wgrad(z, C, dl, 8, weight, 1, 1, Cin, nc, defer=defer)
         if has_bias and ctx.needs_input_grad[4]:
-            gb = _channel_sum(dl)[0, :nc]
+            gb = _bias_grad(dl, nc, ctx.bias, defer)
         if ctx.needs_input_grad[0]:
             gy = torch.empty((N, H, W, C), dtype=z.dtype, device=dev)
             if _FUSE_DZ and _dz_fusable(C):

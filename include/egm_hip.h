@@ -149,6 +149,14 @@ int egm_channel_sums(int dtype, const void* x, int ld, long long npix, int C, fl
 int egm_reduce_tiles(const float* tiles, int ntiles, int C, float* out_2xC, egm_stream_t s);
 /* batch independent reductions: tiles [batch][ntiles][2][C] -> out [batch][2][C] */
 int egm_reduce_tiles_batched(const float* tiles, int batch, int ntiles, int C, float* out, egm_stream_t s);
+/* The bias gradients (db[c] = sum over pixels of dy[., c]) of up to a whole backward pass in two launches; bit-identical, per tensor, to
+ * egm_channel_sums + egm_reduce_tiles (same blocks, same order).  Replaces the per-layer bias reduction autograd performs for the
+ * nn.Conv2d(bias=True) layers of src/EGM-UNet.py:1256-1313, 1362-1390, 1499 (torch: grad_bias = dy.sum((0, 2, 3))).
+ * table_dev: device array of 2n egm_bsum_entry; [0, n): chunk0 = index of the tensor's first partial-sum block (nblk =
+ * egm_channel_partials_blocks(npix, C) blocks each, blocks1 in all); [n, 2n): the same tensors with chunk0 = index of the first
+ * reduction block (C / 8 each, blocks2 in all).  part = nblk * 2 * C floats of workspace, out = Cout floats (c < Cout <= C written). */
+typedef struct { const void* x; float* part; float* out; long long npix; int ld, C, Cout, nblk, chunk0, pad; } egm_bsum_entry;
+int egm_bias_grad_multi(int dtype, const void* table_dev, int n, long long blocks1, long long blocks2, egm_stream_t s);
 
 /* ---- BatchNorm2d (train-mode batch statistics / eval-mode running statistics) + activation -----
  * (nn.BatchNorm2d + ReLU/Sigmoid: src/EGM-UNet.py:50-51,878-879,966-973) */

@@ -119,3 +119,76 @@ def test_conv_wgrad_multi_equals_single_launches_and_refuses_bad_calls():
     for n in (0, 5):
         with pytest.raises(RuntimeError, match="conv_wgrad_multi"):
             L.call("egm_conv_wgrad_multi", 1, blob, n, stream())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_deferred_bias_gradients_equal_the_per_layer_reductions(dtype):
+    """ops.defer_bgrads: the bias gradients of the convs no BatchNorm follows are summed by ONE egm_bias_grad_multi call when backward
+    ends.  Same blocks, same order per tensor: every gradient of the model must be bit-equal to the per-layer form, nothing may stay
+    queued, and at least one bias must really have taken the deferred path."""
+    from egm_unet_amd import ops
+    default = ops.defer_bgrads()
+    got, queued = {}, {}
+    try:
+        for deferred in (False, True):
+            ops.defer_bgrads(deferred)
+            m, x, gl = _model_and_batch(dtype)
+            seen = []
+            orig = ops._flush_bgrads
+
+            def spy(ready_only=False, _seen=seen, _orig=orig):
+                _seen.append(len(ops._pending_bgrad))
+                return _orig(ready_only)
+            ops._flush_bgrads = spy
+            try:
+                m(x)["out"].backward(gl)
+            finally:
+                ops._flush_bgrads = orig
+            torch.cuda.synchronize()
+            assert not ops._pending_bgrad
+            queued[deferred] = max(seen) if seen else 0
+            got[deferred] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    finally:
+        ops.defer_bgrads(default)
+    assert queued[False] == 0 and queued[True] >= 8, queued
+    assert got[True].keys() == got[False].keys() and len(got[True]) > 100
+    for k in got[True]:
+        assert torch.equal(got[True][k], got[False][k]), k
+
+
+def test_bias_grad_multi_equals_channel_sums_and_refuses_bad_calls():
+    """egm_bias_grad_multi through the C ABI against egm_channel_sums + egm_reduce_tiles per tensor (bit for bit), ragged pixel counts,
+    padded channel counts, a pixel stride larger than the channel count, both dtypes."""
+    import struct
+    from egm_unet_amd._lib import lib, ptr, stream
+    L = lib()
+    ent = struct.Struct("<3Qq6i")
+    g = torch.Generator().manual_seed(9)
+    for code, dtype in ((0, torch.float32), (1, torch.bfloat16)):
+        cases = [(2 * 33 * 17, 8, 8, 3), (4096, 64, 64, 64), (1, 16, 16, 9), (70001, 32, 48, 30), (8 * 64 * 64, 256, 256, 256)]
+        keep, b1, b2, n1, n2, outs = [], b"", b"", 0, 0, []
+        for npix, C, ld, Cout in cases:
+            t = torch.randn(npix, ld, generator=g).to(DEV).to(dtype)
+            nb = L.query("egm_channel_partials_blocks", npix, C)
+            part_ref = torch.empty(nb * 2 * C, dtype=torch.float32, device=DEV)
+            ref = torch.empty(2, C, dtype=torch.float32, device=DEV)
+            L.call("egm_channel_sums", code, ptr(t), ld, npix, C, ptr(part_ref), stream())
+            L.call("egm_reduce_tiles", ptr(part_ref), nb, C, ptr(ref), stream())
+            part = torch.empty(nb * 2 * C, dtype=torch.float32, device=DEV)
+            out = torch.full((C,), -7.0, dtype=torch.float32, device=DEV)
+            b1 += ent.pack(t.data_ptr(), part.data_ptr(), out.data_ptr(), npix, ld, C, Cout, nb, n1, 0)
+            b2 += ent.pack(t.data_ptr(), part.data_ptr(), out.data_ptr(), npix, ld, C, Cout, nb, n2, 0)
+            n1 += nb; n2 += C // 8
+            keep.append((t, part)); outs.append((out, ref, Cout, t, C))
+        table = torch.frombuffer(bytearray(b1 + b2), dtype=torch.uint8).to(DEV)
+        L.call("egm_bias_grad_multi", code, ptr(table), len(cases), n1, n2, stream())
+        torch.cuda.synchronize()
+        for out, ref, Cout, t, C in outs:
+            assert torch.equal(out[:Cout], ref[0, :Cout])
+            assert bool((out[Cout:] == -7.0).all())                       # channels beyond Cout are not written
+            want = t[:, :Cout].double().sum(0)
+            assert torch.allclose(out[:Cout].double(), want, rtol=1e-4, atol=1e-2 * max(1.0, float(want.abs().max())) * 1e-2)
+        with pytest.raises(RuntimeError, match="bias_grad_multi"):
+            L.call("egm_bias_grad_multi", code, ptr(table), 0, n1, n2, stream())
+        with pytest.raises(RuntimeError, match="bias_grad_multi"):
+            L.call("egm_bias_grad_multi", code, None, len(cases), n1, n2, stream())
