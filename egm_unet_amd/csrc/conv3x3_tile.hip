@@ -300,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_tile_kernel(TileParams p) {
                     const bool ok = t.ox0 + pl < p.W;
                     uint4 rw = raw[it2];
                     if (!ok) rw = make_uint4(0, 0, 0, 0);             // pixels right of the image: no store, nothing in the statistics
-                    if (ok) *reinterpret_cast<uint4*>(yrow + (long long)pl * ldo) = rw;
+                    if (ok) egm_store16_conv(yrow + (long long)pl * ldo, rw);
                     float v[8];
                     v[0] = __uint_as_float(rw.x << 16); v[1] = __uint_as_float(rw.x & 0xffff0000u);
                     v[2] = __uint_as_float(rw.y << 16); v[3] = __uint_as_float(rw.y & 0xffff0000u);

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wreg_kernel(WregParams p) {
                 uint4 rw = raw[m][i2];
                 if (!ok) rw = make_uint4(0, 0, 0, 0);
                 unsigned char* dst = ok ? reinterpret_cast<unsigned char*>(yrow + (long long)pl * p.ldy) : dump;
-                *reinterpret_cast<uint4*>(dst) = rw;
+                egm_store16_conv(dst, rw);
                 float v[8];
                 v[0] = __uint_as_float(rw.x << 16); v[1] = __uint_as_float(rw.x & 0xffff0000u);
                 v[2] = __uint_as_float(rw.y << 16); v[3] = __uint_as_float(rw.y & 0xffff0000u);

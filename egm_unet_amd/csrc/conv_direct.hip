@@ -191,7 +191,7 @@ __device__ __forceinline__ void conv_direct_body(const DirectParams& p, const in
             for (int it = 0; it < NV / 2; ++it) {
                 const int pl = it * (64 / NV) + slot;
                 if (whole || (pl < left && co0 + cvo * 8 < p.Cout)) {
-                    *reinterpret_cast<uint4*>(yblk + (long long)it * (64 / NV) * p.ldy + (unsigned)(slot * p.ldy + cvo * 8)) = raw[it];
+                    egm_store16_conv(yblk + (long long)it * (64 / NV) * p.ldy + (unsigned)(slot * p.ldy + cvo * 8), raw[it]);
                     if (p.stats != nullptr) {
                         const uint32_t u[4] = {raw[it].x, raw[it].y, raw[it].z, raw[it].w};
 #pragma unroll

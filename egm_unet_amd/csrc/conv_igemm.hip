@@ -549,7 +549,7 @@ __device__ __forceinline__ void conv_igemm_pipe_body(const ConvParams& p, const 
 #pragma unroll
                 for (int it = 0; it < NV / 2; ++it) {         // 32 pixels / (64/NV pixel slots)
                     if (whole || (R * wv + m < rows_in && it * (64 / NV) + slot < cols_in && cv * 8 < couts_in)) {
-                        *reinterpret_cast<uint4*>(yrow + (long long)it * (64 / NV) * p.ldy + lane_off) = raw[it];
+                        egm_store16_conv(yrow + (long long)it * (64 / NV) * p.ldy + lane_off, raw[it]);
                         if (p.stats != nullptr) {
                             const uint32_t u[4] = {raw[it].x, raw[it].y, raw[it].z, raw[it].w};
 #pragma unroll

@@ -1,0 +1,313 @@
+// bf16 C = act(alpha * A * B^T + bias) + R for the large nn.Linear products of the CLIP ViT / CLIPSeg path (clip/model.py:173-206, 487-501;
+// models/clipseg.py:79-133): the 8-wave LDS-DMA kernel.  Same arithmetic, k order and rounding as gemm_nt128_kernel (csrc/vit.hip), which
+// it replaces on the shapes that fill the chip with 256 x 256 tiles -- results are bit-identical to it (tests/test_gpu_gemm_dma.py).
+//
+// Structure (the GEMM twin of conv3x3_tile.hip; one workgroup = 8 waves = 4 (M) x 2 (N), one workgroup per CU, 2 waves per SIMD):
+//   * tile 256 (M) x 256 (N); wave tile 64 x 128 = 2 x 4 accumulator tiles of v_mfma_f32_32x32x16_bf16 (A operand = rows of B, B operand =
+//     rows of A, so a lane ends with 4 consecutive n of one m per register quad).  6 fragment reads per 8 MFMAs.
+//   * K loop = 64-deep stages.  A stage = 256 rows of A + 256 rows of B, 128 B each, global -> LDS by LDS-DMA (global_load_lds_dwordx4,
+//     1 KiB per wave-instruction: 8 rows x 128 B): 64 instructions per stage, 8 per wave, issued two per k-step of the MFMA phase.
+//   * LDS image: rows of 128 B without padding; WHICH 16-byte k-slot of its row a DMA lane fetches is chosen by the lane's source address,
+//     slot s of row r holds k-slot s ^ (r & 7): eight consecutive rows of one k-slot lie in eight different 16-byte bank groups, so every
+//     ds_read_b128 fragment read is conflict-free and the swizzle costs nothing.
+//   * two stage buffers (2 x 64 KiB), one barrier per stage: stage t+1 streams in while stage t is multiplied.
+//   * persistent over tiles (stage list = (tile, chunk) pairs; the first stage of the next tile is in flight during the last MFMA phase and
+//     has landed when the epilogue runs).  Epilogue: alpha, bias, activation and residual in fp32 on the accumulators, ONE rounding, then
+//     through a wave-private LDS tile (in the stage buffer that was just consumed; one extra barrier per tile hands it back) to whole
+//     16-byte vectors: every row of C gets 128 contiguous bytes per store group.
+//   * rows beyond M / N read a zero page (no branches in the DMA stream, compile-time instruction counts).
+//   * XCD-aware tile order: the workgroups of one XCD walk the m-tiles congruent to the XCD index, n fastest, so an A row panel is read
+//     from HBM by one XCD and shared by the n-tiles through its L2.
+#include "gemm_dma.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+__device__ uint4 egm_gemm_zero_page[4];
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int STAGE = (BM + BN) * BK * 2;            // 65536 bytes
+constexpr int BOFF = BM * BK * 2;                    // B image behind the A image
+constexpr int KT = 8;                                // DMA instructions per wave and stage
+constexpr int SMEM = 2 * STAGE;
+
+struct Params {
+    const bf16_t* A; const bf16_t* B; bf16_t* C; const float* bias; const bf16_t* R;
+    int lda, ldb, ldc, ldr, M, N, K, act;
+    float alpha;
+    int tiles_m, tiles_n;
+};
+
+template <int ACT>
+__device__ __forceinline__ float act_of(float v) {                     // gemm_act of csrc/vit.hip
+    if (ACT == 1) return v > 0.f ? v : 0.f;
+    if (ACT == 2) return v / (1.f + expf(-1.702f * v));                // QuickGELU
+    return v;
+}
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    f32x2_t v; v.x = lo; v.y = hi;
+    const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+    return *reinterpret_cast<const uint32_t*>(&b);
+}
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr));
+}
+
+template <bool HAS_R, int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) unsigned char* lds_p;
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3, nslot = gridDim.x >> 3;
+    const int mt_cnt = (p.tiles_m - xcd + 7) >> 3;                    // m-tiles xcd, xcd + 8, ... of this XCD
+    const int cnt = mt_cnt * p.tiles_n;
+    if (slot >= cnt) return;                                          // (whole workgroup)
+    const int ntl = (cnt - slot + nslot - 1) / nslot;
+    const int nch = p.K / BK;
+    const int S = ntl * nch;
+    const int tid = threadIdx.x, lane = tid & 63, r31 = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wv >> 1, wc = wv & 1;
+    const unsigned smem_lds = (unsigned)(unsigned long long)(lds_p)smem;
+
+    // ---- per-lane DMA sources.  Instruction k of this wave is stage instruction j = wv + 8k: k < 4 -> rows 8j .. 8j+7 of the A tile,
+    //      k >= 4 -> rows 8(j - 32) .. of the B tile; lane l -> row 8j + (l >> 3), LDS slot l & 7, k-slot (l & 7) ^ (l >> 3).
+    const int drow = 8 * wv + (lane >> 3);                            // row of instruction k: drow + 64 (k & 3)
+    const int dks = ((lane & 7) ^ (lane >> 3)) * 8;                   // element offset of the k-slot inside the 64-deep chunk
+    const int relA = drow * p.lda + dks, relB = drow * p.ldb + dks;
+    const void* const zp = reinterpret_cast<const void*>(egm_gemm_zero_page);
+
+    struct Tile { int li, m0, n0; };
+    auto decode = [&](Tile& t) {
+        const int mi = t.li / p.tiles_n;
+        t.m0 = (xcd + 8 * mi) * BM; t.n0 = (t.li - mi * p.tiles_n) * BN;
+    };
+    struct Src { const bf16_t* xa; const bf16_t* xb; int m0, n0; unsigned lds; };
+    auto make_src = [&](const Tile& t, int ch, int bufi) {
+        Src q;
+        q.xa = p.A + (long long)t.m0 * p.lda + ch * BK;
+        q.xb = p.B + (long long)t.n0 * p.ldb + ch * BK;
+        q.m0 = t.m0; q.n0 = t.n0;
+        q.lds = smem_lds + bufi * STAGE + wv * 1024;
+        return q;
+    };
+    auto dma = [&](const Src& q, int k) __attribute__((always_inline)) {
+        const void* src;
+        if (k < 4) {
+            const int row = drow + 64 * k;
+            src = q.m0 + row < p.M ? reinterpret_cast<const void*>(q.xa + relA + 64 * k * p.lda) : zp;
+        } else {
+            const int row = drow + 64 * (k - 4);
+            src = q.n0 + row < p.N ? reinterpret_cast<const void*>(q.xb + relB + 64 * (k - 4) * p.ldb) : zp;
+        }
+        glds16(src, q.lds + k * 8192);
+    };
+
+    Tile it; it.li = slot; decode(it);
+    int it_ch = 0;
+    Tile cu = it;
+    auto advance_issue = [&]() {
+        if (++it_ch == nch) { it_ch = 0; it.li += nslot; if (it.li < cnt) decode(it); }
+    };
+    {
+        const Src q = make_src(it, it_ch, 0);
+#pragma unroll
+        for (int k = 0; k < KT; ++k) dma(q, k);
+        advance_issue();
+    }
+    if (wv >= 4) __builtin_amdgcn_s_setprio(1);                       // the second-dispatched half loses issue arbitration otherwise (conv3x3_tile.hip)
+
+    // ---- fragment read addresses (bytes inside a stage buffer)
+    const int pa = (wr * 64 + r31) * 128, pbb = BOFF + (wc * 128 + r31) * 128;
+    int kso[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kso[ks] = ((2 * ks + h) ^ (r31 & 7)) * 16;
+
+    f32x16_t acc[2][4];
+
+    // MFMA phase of one stage: 4 k-steps of 16.  The fragments of k-step s+1 are read while the MFMAs of k-step s run (two register sets);
+    // the 8 DMA instructions of the next stage go out in the first half of the phase (4 behind the reads of k-step 1, 4 behind those of
+    // k-step 2), so the last of them has two k-steps of MFMA time to land before the wait at the end of the stage.
+    auto compute = [&](int bufi, bool with_dma, const Src& q) __attribute__((always_inline)) {
+        const unsigned char* sb = smem + bufi * STAGE;
+        bf16x8_t fa[2][2], fb[2][4];
+        auto frags = [&](int ks, bf16x8_t (&a)[2], bf16x8_t (&bfr)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sb + pa + i * 4096 + kso[ks]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(sb + pbb + j * 4096 + kso[ks]);
+        };
+        auto mmas = [&](const bf16x8_t (&a)[2], const bf16x8_t (&bfr)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], a[i], acc[i][j], 0, 0, 0);
+        };
+        frags(0, fa[0], fb[0]);
+        frags(1, fa[1], fb[1]);
+        if (with_dma) { dma(q, 0); dma(q, 1); dma(q, 2); dma(q, 3); }
+        mmas(fa[0], fb[0]);
+        frags(2, fa[0], fb[0]);
+        if (with_dma) { dma(q, 4); dma(q, 5); dma(q, 6); dma(q, 7); }
+        mmas(fa[1], fb[1]);
+        frags(3, fa[1], fb[1]);
+        mmas(fa[0], fb[0]);
+        mmas(fa[1], fb[1]);
+    };
+
+    // D layout: column (m) = lane & 31, rows (n) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  The accumulators go through a wave-private
+    // fp32 LDS tile (32 m x 64 n, rows of 256 B, 16-byte slots XOR-swizzled by row & 15) and come back as rows: a lane then holds 8
+    // consecutive n of one m, so the residual is read and C written as whole 16-byte vectors, 128 contiguous bytes per row, and the
+    // bias is 8 values per lane.  alpha, bias, activation, residual in fp32, ONE rounding (the arithmetic of gemm_nt128_kernel).
+    auto epilogue = [&](const Tile& t, int bufi) __attribute__((always_inline)) {
+        unsigned char* ot = smem + bufi * STAGE + wv * 8192;
+        const int cv = lane & 7, sl = lane >> 3;
+        // group g = (row block i = g >> 1, column pair jp = g & 1): 32 m x 64 n.  The residual vectors and the bias of group g+1 are
+        // requested before group g is worked on (one exposed memory latency per tile, not four).
+        uint4 rr[2][4];
+        float4 bq[2][2];
+        auto request = [&](int g, uint4 (&r4)[4], float4 (&b2)[2]) __attribute__((always_inline)) {
+            const int i = g >> 1, jp = g & 1;
+            const int n = t.n0 + wc * 128 + jp * 64 + cv * 8;
+            const int nc = n < p.N ? n : p.N - 8;                     // clamped: lanes beyond N / M load something valid and store nothing
+            if (HAS_R) {
+#pragma unroll
+                for (int it2 = 0; it2 < 4; ++it2) {
+                    const int mr = t.m0 + wr * 64 + i * 32 + sl + it2 * 8;
+                    r4[it2] = *reinterpret_cast<const uint4*>(p.R + (long long)(mr < p.M ? mr : p.M - 1) * p.ldr + nc);
+                }
+            }
+            const float* bp = p.bias != nullptr ? p.bias + nc : reinterpret_cast<const float*>(egm_gemm_zero_page);
+            b2[0] = *reinterpret_cast<const float4*>(bp); b2[1] = *reinterpret_cast<const float4*>(bp + 4);
+        };
+        request(0, rr[0], bq[0]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int i = g >> 1, jp = g & 1;
+            if (g + 1 < 4) request(g + 1, rr[(g + 1) & 1], bq[(g + 1) & 1]);
+            const int n = t.n0 + wc * 128 + jp * 64 + cv * 8;
+            const int mb = t.m0 + wr * 64 + i * 32 + sl;              // + 8 it2
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int j = jp * 2 + jj, c16 = jj * 8 + gq * 2 + h;
+                    const float4 v = make_float4(acc[i][j][gq * 4 + 0], acc[i][j][gq * 4 + 1], acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]);
+                    *reinterpret_cast<float4*>(ot + r31 * 256 + ((c16 ^ (r31 & 15)) * 16)) = v;
+                }
+            const float4 b0 = bq[g & 1][0], b1 = bq[g & 1][1];
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int it2 = 0; it2 < 4; ++it2) {
+                const int pl = it2 * 8 + sl;
+                const float4 x0 = *reinterpret_cast<const float4*>(ot + pl * 256 + (((2 * cv) ^ (pl & 15)) * 16));
+                const float4 x1 = *reinterpret_cast<const float4*>(ot + pl * 256 + (((2 * cv + 1) ^ (pl & 15)) * 16));
+                float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = act_of<ACT>(p.alpha * v[e] + bb[e]);
+                if (HAS_R) {
+                    const uint4 r4 = rr[g & 1][it2];
+                    v[0] += __uint_as_float(r4.x << 16); v[1] += __uint_as_float(r4.x & 0xffff0000u);
+                    v[2] += __uint_as_float(r4.y << 16); v[3] += __uint_as_float(r4.y & 0xffff0000u);
+                    v[4] += __uint_as_float(r4.z << 16); v[5] += __uint_as_float(r4.z & 0xffff0000u);
+                    v[6] += __uint_as_float(r4.w << 16); v[7] += __uint_as_float(r4.w & 0xffff0000u);
+                }
+                uint4 o;
+                o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]); o.z = pack2(v[4], v[5]); o.w = pack2(v[6], v[7]);
+                const int mr = mb + it2 * 8;
+                if (mr < p.M && n < p.N) *reinterpret_cast<uint4*>(p.C + (long long)mr * p.ldc + n) = o;
+            }
+        }
+    };
+
+    // ---- stage pipeline over (tile, chunk)
+    int cu_ch = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int bc = 0;
+    for (int t = 0; t < S; ++t) {
+        const bool more = t + 1 < S;
+        const Src q = make_src(it, it_ch, bc ^ 1);
+        if (more) advance_issue();
+        if (cu_ch == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        }
+        compute(bc, more, q);
+        // stage t+1 has landed (this wave's share), then everybody's has and everybody is done reading stage t
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (++cu_ch == nch) {
+            cu_ch = 0;
+            epilogue(cu, bc);                                         // out tiles live in the buffer just consumed ...
+            cu.li += nslot; if (cu.li < cnt) decode(cu);
+            if (more) {                                               // ... which the DMA of stage t+2 (issued in the next MFMA phase) overwrites
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        bc ^= 1;
+    }
+}
+
+int g_gemm_dma = -1;
+
+}  // namespace
+
+extern "C" int egm_gemm_dma_mode(int mode) {
+    if (g_gemm_dma < 0) g_gemm_dma = getenv("EGM_GEMM_DMA") ? atoi(getenv("EGM_GEMM_DMA")) : 1;
+    const int old = g_gemm_dma;
+    if (mode >= 0) g_gemm_dma = mode;
+    return old;
+}
+
+int egm_gemm_dma_ok(const GemmDmaArgs& a) {
+    if (!egm_gemm_dma_mode(-1)) return 0;
+    if (a.act < 0 || a.act > 2) return 0;
+    if (a.M < 512 || a.N < 256 || a.K < BK || a.K % BK != 0 || a.N % 8 != 0) return 0;
+    if (a.lda % 8 || a.ldb % 8 || a.ldc % 8 || (a.R && a.ldr % 8)) return 0;
+    if (!egm_aligned16(a.A) || !egm_aligned16(a.B) || !egm_aligned16(a.C) || (a.R && !egm_aligned16(a.R)) || (a.bias && !egm_aligned16(a.bias))) return 0;
+    if ((long long)BM * a.lda >= (1LL << 31) || (long long)BN * a.ldb >= (1LL << 31)) return 0;
+    const long long tiles = (long long)egm_cdiv(a.M, BM) * egm_cdiv(a.N, BN);
+    return tiles >= 256;                                             // less than one 256 x 256 tile per CU: the 128-wide kernels fill the chip better (fc2 / proj at N = 768: 183 tiles)
+}
+
+template <bool HAS_R, int ACT>
+static int launch_dma(const Params& p, int grid, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<HAS_R, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "gemm_dma: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_dma_kernel<HAS_R, ACT>), dim3(grid), dim3(512), SMEM, st, p);
+    EGM_CHECK_LAUNCH("gemm_dma");
+    return EGM_OK;
+}
+
+int egm_gemm_dma_launch(const GemmDmaArgs& a, hipStream_t st) {
+    Params p;
+    p.A = (const bf16_t*)a.A; p.B = (const bf16_t*)a.B; p.C = (bf16_t*)a.C; p.bias = a.bias; p.R = (const bf16_t*)a.R;
+    p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc; p.ldr = a.ldr; p.M = a.M; p.N = a.N; p.K = a.K; p.act = a.act; p.alpha = a.alpha;
+    p.tiles_m = egm_cdiv(a.M, BM); p.tiles_n = egm_cdiv(a.N, BN);
+    const long long tiles = (long long)p.tiles_m * p.tiles_n;
+    int grid = 256;                                                   // one workgroup per CU, 32 per XCD; each walks its XCD's tile list
+    if (tiles < grid) grid = (int)((tiles + 7) / 8) * 8;
+    const bool r = a.R != nullptr;
+    switch (a.act) {
+        case 0: return r ? launch_dma<true, 0>(p, grid, st) : launch_dma<false, 0>(p, grid, st);
+        case 1: return r ? launch_dma<true, 1>(p, grid, st) : launch_dma<false, 1>(p, grid, st);
+        case 2: return r ? launch_dma<true, 2>(p, grid, st) : launch_dma<false, 2>(p, grid, st);
+    }
+    EGM_FAIL(EGM_ERR_ARG, "gemm_dma: unknown activation %d", a.act);
+}

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void mca_fused_fwd_kernel(const T* __restrict_
             for (int j = 0; j < 8; ++j) val[j] = to_f32(from_f32<T>(val[j] * ((ghw + gc8[j]) * inv)));
             if (xo != nullptr && py >= 2 && py < MF_TY + 2 && px >= 2 && px < MF_TX + 2) store8(xo + p * ldxo + c0 + v * 8, val);
         }
-        store8(sxo + pix * MF_CB + v * 8, val);
+        store8_lds(sxo + pix * MF_CB + v * 8, val);
     }
     __syncthreads();
     // ---- phase B: u2 = (x_out - avg3 x_out)^2 on the tile + 1-pixel halo (zero outside the image)
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void mca_fused_fwd_kernel(const T* __restrict_
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float u = c[j] - s8[j] * (1.f / 9.f); o2[j] = u * u; }
         }
-        store8(su2 + pix * MF_CB + v * 8, o2);
+        store8_lds(su2 + pix * MF_CB + v * 8, o2);
     }
     __syncthreads();
     // ---- phase C: out = 0.51 xo + 0.2 (max3 - min3) + 0.1 shuffle(xo) + 0.2 avg3(u2)

@@ -6,6 +6,7 @@
 //   patchify / token assembly / text embedding / FiLM / row gather / transposed-conv pixel shuffle
 // Activations are row-major [rows, D] (batch-first tokens), bf16 or fp32; statistics and scores are fp32.
 #include "common.h"
+#include "gemm_dma.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -530,6 +531,12 @@ inline int sgrid(long long total) { long long b = (total + 255) / 256; if (b > 4
 template <typename T>
 int launch_gemm(const GemmParams& p, int transB, int batch, hipStream_t st) {
     using M_ = GMma<T>;
+    if (sizeof(T) == 2 && transB && batch == 1 && !p.c_f32) {      // the products that fill the chip with 256 x 256 tiles: csrc/gemm_dma.hip
+        GemmDmaArgs a;
+        a.A = p.A; a.B = p.B; a.C = p.C; a.bias = p.bias; a.R = p.R;
+        a.lda = p.lda; a.ldb = p.ldb; a.ldc = p.ldc; a.ldr = p.ldr; a.M = p.M; a.N = p.N; a.K = p.K; a.act = p.act; a.alpha = p.alpha;
+        if (egm_gemm_dma_ok(a)) return egm_gemm_dma_launch(a, st);
+    }
     if (sizeof(T) == 2 && transB && p.M >= 128 && p.N >= 96 && p.K % 8 == 0) {          // the large A * B^T products
         // 128 x 256 tiles (32 MFMAs per wave between barriers) when they still give every CU a few workgroups, else 128 x 128
         // 256 x 128 tiles (8 waves; 1/170 staged byte per FLOP instead of 1/128) when they still give every CU two workgroups
