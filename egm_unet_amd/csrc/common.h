@@ -72,32 +72,31 @@ __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
 // One 16-byte store of a kernel's output tensor, with a cache policy.  A plain store leaves its line dirty in the XCD's L2 until it is
 // evicted or written back when the kernel ends (a serial tail of up to the L2's 4 MB per XCD behind every streaming kernel); the next
 // kernel reads the tensor through ITS XCD's L2 anyway.  MODE 0 = plain, 1 = write-through (sc1), 2 = non-temporal.  Measured on the
-// benchmarked step (profiles/r04_ab_runs.md): element-wise / BatchNorm kernels 2 (EGM_STORE_MODE), conv outputs EGM_CONV_STORE_MODE.
+// benchmarked step (profiles/r04_ab_runs.md): element-wise / BatchNorm kernels 2 (EGM_STORE_MODE), conv outputs 1 (EGM_CONV_STORE_MODE).
 #ifndef EGM_STORE_MODE
 #define EGM_STORE_MODE 2
 #endif
 #ifndef EGM_CONV_STORE_MODE
-#define EGM_CONV_STORE_MODE 0
+#define EGM_CONV_STORE_MODE 1
 #endif
 typedef __attribute__((ext_vector_type(4))) unsigned int egm_u32x4;
-template <int MODE>
-__device__ __forceinline__ void egm_store16_as(void* p, egm_u32x4 a) {
+template <int MODE, typename V>
+__device__ __forceinline__ void egm_store16_as(void* p, V a) {
     if (MODE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(a) : "memory");
-    else if (MODE == 2) __builtin_nontemporal_store(a, reinterpret_cast<egm_u32x4*>(p));
-    else *reinterpret_cast<egm_u32x4*>(p) = a;
+    else if (MODE == 2) __builtin_nontemporal_store(a, reinterpret_cast<V*>(p));
+    else *reinterpret_cast<V*>(p) = a;
 }
-__device__ __forceinline__ void egm_store16(void* p, egm_u32x4 a) { egm_store16_as<EGM_STORE_MODE>(p, a); }
 // the same for a conv kernel's output vector (held as uint4)
 __device__ __forceinline__ void egm_store16_conv(void* p, uint4 v) {
     egm_u32x4 a; a.x = v.x; a.y = v.y; a.z = v.z; a.w = v.w;
     egm_store16_as<EGM_CONV_STORE_MODE>(p, a);
 }
 __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
-    egm_u32x4 a, b;
-    a.x = __float_as_uint(v[0]); a.y = __float_as_uint(v[1]); a.z = __float_as_uint(v[2]); a.w = __float_as_uint(v[3]);
-    b.x = __float_as_uint(v[4]); b.y = __float_as_uint(v[5]); b.z = __float_as_uint(v[6]); b.w = __float_as_uint(v[7]);
-    egm_store16(p, a);
-    egm_store16(p + 4, b);
+    // fp32 tensors (the parity path, not the benchmarked one) keep the plain store: handing the values to a vector-typed store builtin
+    // makes the compiler vectorise the arithmetic in front of it into packed multiplies and adds, i.e. changes which multiply-adds are
+    // contracted, and the fp32 results are pinned bit for bit against each other (tests/test_gpu_ops.py: fused MCALayer tail)
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     egm_u32x4 a;
@@ -105,7 +104,7 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     a.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
     a.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
     a.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
-    egm_store16(p, a);
+    egm_store16_as<EGM_STORE_MODE>(p, a);
 }
 // the same packing into an LDS tile (always a plain store: egm_store16's cache-policy forms are global-memory instructions)
 __device__ __forceinline__ void store8_lds(float* p, const float (&v)[8]) {

@@ -30,11 +30,14 @@ __device__ uint4 egm_gemm_zero_page[4];
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int STAGE = (BM + BN) * BK * 2;            // 65536 bytes
+constexpr int BM = 256, BK = 64;
 constexpr int BOFF = BM * BK * 2;                    // B image behind the A image
-constexpr int KT = 8;                                // DMA instructions per wave and stage
-constexpr int SMEM = 2 * STAGE;
+// NT = 32-column blocks per wave: tile 256 x (64 NT).  NT = 4: 256 x 256, the general form.  NT = 3: 256 x 192 for N = 768 (proj / fc2 of
+// ViT-B: 244 tiles = one per CU where 256-wide tiles would leave 73 CUs idle); only offered when no workgroup gets a second tile,
+// because its fp32 out tiles (64 KiB) then may lie across both stage buffers (2 x 56 KiB).
+template <int NT> struct Geom {
+    static constexpr int BN = 64 * NT, STAGE = (BM + BN) * BK * 2, KT = 4 + NT, SMEM = 2 * STAGE;
+};
 
 struct Params {
     const bf16_t* A; const bf16_t* B; bf16_t* C; const float* bias; const bf16_t* R;
@@ -60,9 +63,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr));
 }
 
-template <bool HAS_R, int ACT>
+template <int NT, bool HAS_R, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BN = Geom<NT>::BN, STAGE = Geom<NT>::STAGE, KT = Geom<NT>::KT;
     typedef __attribute__((address_space(3))) unsigned char* lds_p;
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3, nslot = gridDim.x >> 3;
     const int mt_cnt = (p.tiles_m - xcd + 7) >> 3;                    // m-tiles xcd, xcd + 8, ... of this XCD
@@ -76,8 +80,8 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
     const int wr = wv >> 1, wc = wv & 1;
     const unsigned smem_lds = (unsigned)(unsigned long long)(lds_p)smem;
 
-    // ---- per-lane DMA sources.  Instruction k of this wave is stage instruction j = wv + 8k: k < 4 -> rows 8j .. 8j+7 of the A tile,
-    //      k >= 4 -> rows 8(j - 32) .. of the B tile; lane l -> row 8j + (l >> 3), LDS slot l & 7, k-slot (l & 7) ^ (l >> 3).
+    // ---- per-lane DMA sources.  Instruction k of this wave: k < 4 -> rows 8 (wv + 8k) .. + 7 of the A tile, k >= 4 -> rows
+    //      8 (wv + 8 (k - 4)) .. of the B tile (NT instructions); lane l -> row + (l >> 3), LDS slot l & 7, k-slot (l & 7) ^ (l >> 3).
     const int drow = 8 * wv + (lane >> 3);                            // row of instruction k: drow + 64 (k & 3)
     const int dks = ((lane & 7) ^ (lane >> 3)) * 8;                   // element offset of the k-slot inside the 64-deep chunk
     const int relA = drow * p.lda + dks, relB = drow * p.ldb + dks;
@@ -124,37 +128,40 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
     if (wv >= 4) __builtin_amdgcn_s_setprio(1);                       // the second-dispatched half loses issue arbitration otherwise (conv3x3_tile.hip)
 
     // ---- fragment read addresses (bytes inside a stage buffer)
-    const int pa = (wr * 64 + r31) * 128, pbb = BOFF + (wc * 128 + r31) * 128;
+    const int pa = (wr * 64 + r31) * 128, pbb = BOFF + (wc * NT * 32 + r31) * 128;
     int kso[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) kso[ks] = ((2 * ks + h) ^ (r31 & 7)) * 16;
 
-    f32x16_t acc[2][4];
+    f32x16_t acc[2][NT];
 
     // MFMA phase of one stage: 4 k-steps of 16.  The fragments of k-step s+1 are read while the MFMAs of k-step s run (two register sets);
     // the 8 DMA instructions of the next stage go out in the first half of the phase (4 behind the reads of k-step 1, 4 behind those of
     // k-step 2), so the last of them has two k-steps of MFMA time to land before the wait at the end of the stage.
     auto compute = [&](int bufi, bool with_dma, const Src& q) __attribute__((always_inline)) {
         const unsigned char* sb = smem + bufi * STAGE;
-        bf16x8_t fa[2][2], fb[2][4];
-        auto frags = [&](int ks, bf16x8_t (&a)[2], bf16x8_t (&bfr)[4]) __attribute__((always_inline)) {
+        bf16x8_t fa[2][2], fb[2][NT];
+        auto frags = [&](int ks, bf16x8_t (&a)[2], bf16x8_t (&bfr)[NT]) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sb + pa + i * 4096 + kso[ks]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(sb + pbb + j * 4096 + kso[ks]);
+            for (int j = 0; j < NT; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(sb + pbb + j * 4096 + kso[ks]);
         };
-        auto mmas = [&](const bf16x8_t (&a)[2], const bf16x8_t (&bfr)[4]) __attribute__((always_inline)) {
+        auto mmas = [&](const bf16x8_t (&a)[2], const bf16x8_t (&bfr)[NT]) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], a[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], a[i], acc[i][j], 0, 0, 0);
         };
         frags(0, fa[0], fb[0]);
         frags(1, fa[1], fb[1]);
         if (with_dma) { dma(q, 0); dma(q, 1); dma(q, 2); dma(q, 3); }
         mmas(fa[0], fb[0]);
         frags(2, fa[0], fb[0]);
-        if (with_dma) { dma(q, 4); dma(q, 5); dma(q, 6); dma(q, 7); }
+        if (with_dma) {
+#pragma unroll
+            for (int k = 4; k < KT; ++k) dma(q, k);
+        }
         mmas(fa[1], fb[1]);
         frags(3, fa[1], fb[1]);
         mmas(fa[0], fb[0]);
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
     // consecutive n of one m, so the residual is read and C written as whole 16-byte vectors, 128 contiguous bytes per row, and the
     // bias is 8 values per lane.  alpha, bias, activation, residual in fp32, ONE rounding (the arithmetic of gemm_nt128_kernel).
     auto epilogue = [&](const Tile& t, int bufi) __attribute__((always_inline)) {
-        unsigned char* ot = smem + bufi * STAGE + wv * 8192;
+        unsigned char* ot = smem + (NT == 4 ? bufi * STAGE : 0) + wv * 8192;   // (NT = 3: the workgroup's only tile is done, both buffers are free)
         const int cv = lane & 7, sl = lane >> 3;
         // group g = (row block i = g >> 1, column pair jp = g & 1): 32 m x 64 n.  The residual vectors and the bias of group g+1 are
         // requested before group g is worked on (one exposed memory latency per tile, not four).
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
         float4 bq[2][2];
         auto request = [&](int g, uint4 (&r4)[4], float4 (&b2)[2]) __attribute__((always_inline)) {
             const int i = g >> 1, jp = g & 1;
-            const int n = t.n0 + wc * 128 + jp * 64 + cv * 8;
+            const int n = t.n0 + wc * (NT * 32) + jp * 64 + cv * 8;
             const int nc = n < p.N ? n : p.N - 8;                     // clamped: lanes beyond N / M load something valid and store nothing
             if (HAS_R) {
 #pragma unroll
@@ -191,15 +198,18 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
         for (int g = 0; g < 4; ++g) {
             const int i = g >> 1, jp = g & 1;
             if (g + 1 < 4) request(g + 1, rr[(g + 1) & 1], bq[(g + 1) & 1]);
-            const int n = t.n0 + wc * 128 + jp * 64 + cv * 8;
+            const int n = t.n0 + wc * (NT * 32) + jp * 64 + cv * 8;
+            const bool nin = jp * 64 + cv * 8 < NT * 32;              // (NT = 3: the second column group is one 32-column block)
             const int mb = t.m0 + wr * 64 + i * 32 + sl;              // + 8 it2
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const int j = jp * 2 + jj, c16 = jj * 8 + gq * 2 + h;
-                    const float4 v = make_float4(acc[i][j][gq * 4 + 0], acc[i][j][gq * 4 + 1], acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]);
-                    *reinterpret_cast<float4*>(ot + r31 * 256 + ((c16 ^ (r31 & 15)) * 16)) = v;
+                    if (j < NT) {
+                        const float4 v = make_float4(acc[i][j][gq * 4 + 0], acc[i][j][gq * 4 + 1], acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]);
+                        *reinterpret_cast<float4*>(ot + r31 * 256 + ((c16 ^ (r31 & 15)) * 16)) = v;
+                    }
                 }
             const float4 b0 = bq[g & 1][0], b1 = bq[g & 1][1];
             const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
                 uint4 o;
                 o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]); o.z = pack2(v[4], v[5]); o.w = pack2(v[6], v[7]);
                 const int mr = mb + it2 * 8;
-                if (mr < p.M && n < p.N) *reinterpret_cast<uint4*>(p.C + (long long)mr * p.ldc + n) = o;
+                if (mr < p.M && n < p.N && nin) *reinterpret_cast<uint4*>(p.C + (long long)mr * p.ldc + n) = o;
             }
         }
     };
@@ -239,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NT; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         }
@@ -271,43 +281,52 @@ extern "C" int egm_gemm_dma_mode(int mode) {
     return old;
 }
 
-int egm_gemm_dma_ok(const GemmDmaArgs& a) {
+// 0: not taken; 4: 256 x 256 tiles; 3: 256 x 192 tiles (N a multiple of 192 that 256-wide tiles would cut into less than one tile per CU)
+static int gemm_dma_nt(const GemmDmaArgs& a) {
     if (!egm_gemm_dma_mode(-1)) return 0;
     if (a.act < 0 || a.act > 2) return 0;
-    if (a.M < 512 || a.N < 256 || a.K < BK || a.K % BK != 0 || a.N % 8 != 0) return 0;
+    if (a.M < 512 || a.N < 192 || a.K < BK || a.K % BK != 0 || a.N % 8 != 0) return 0;
     if (a.lda % 8 || a.ldb % 8 || a.ldc % 8 || (a.R && a.ldr % 8)) return 0;
     if (!egm_aligned16(a.A) || !egm_aligned16(a.B) || !egm_aligned16(a.C) || (a.R && !egm_aligned16(a.R)) || (a.bias && !egm_aligned16(a.bias))) return 0;
-    if ((long long)BM * a.lda >= (1LL << 31) || (long long)BN * a.ldb >= (1LL << 31)) return 0;
-    const long long tiles = (long long)egm_cdiv(a.M, BM) * egm_cdiv(a.N, BN);
-    return tiles >= 256;                                             // less than one 256 x 256 tile per CU: the 128-wide kernels fill the chip better (fc2 / proj at N = 768: 183 tiles)
+    if ((long long)BM * a.lda >= (1LL << 31) || 256LL * a.ldb >= (1LL << 31)) return 0;
+    const int tm = egm_cdiv(a.M, BM);
+    if ((long long)tm * egm_cdiv(a.N, 256) >= 256) return 4;
+    // less than one 256 x 256 tile per CU (proj / fc2 at N = 768: 183): 192-wide tiles when they give (nearly) every CU exactly one
+    const int tn3 = egm_cdiv(a.N, 192);
+    if (a.N % 192 == 0 && egm_cdiv(tm, 8) * tn3 <= 32 && (long long)tm * tn3 >= 192) return 3;
+    return 0;                                                          // the 128-wide register-staged kernels fill the chip better
 }
+int egm_gemm_dma_ok(const GemmDmaArgs& a) { return gemm_dma_nt(a) != 0; }
 
-template <bool HAS_R, int ACT>
+template <int NT, bool HAS_R, int ACT>
 static int launch_dma(const Params& p, int grid, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<HAS_R, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<NT, HAS_R, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           Geom<NT>::SMEM);
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "gemm_dma: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_dma_kernel<HAS_R, ACT>), dim3(grid), dim3(512), SMEM, st, p);
+    hipLaunchKernelGGL((gemm_dma_kernel<NT, HAS_R, ACT>), dim3(grid), dim3(512), Geom<NT>::SMEM, st, p);
     EGM_CHECK_LAUNCH("gemm_dma");
     return EGM_OK;
 }
+template <int NT>
+static int launch_dma_nt(const Params& p, int grid, bool r, int act, hipStream_t st) {
+    switch (act) {
+        case 0: return r ? launch_dma<NT, true, 0>(p, grid, st) : launch_dma<NT, false, 0>(p, grid, st);
+        case 1: return r ? launch_dma<NT, true, 1>(p, grid, st) : launch_dma<NT, false, 1>(p, grid, st);
+        default: return r ? launch_dma<NT, true, 2>(p, grid, st) : launch_dma<NT, false, 2>(p, grid, st);
+    }
+}
 
 int egm_gemm_dma_launch(const GemmDmaArgs& a, hipStream_t st) {
+    const int nt = gemm_dma_nt(a);
+    EGM_REQUIRE(nt != 0, "gemm_dma: shape not supported (egm_gemm_dma_ok)");
     Params p;
     p.A = (const bf16_t*)a.A; p.B = (const bf16_t*)a.B; p.C = (bf16_t*)a.C; p.bias = a.bias; p.R = (const bf16_t*)a.R;
     p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc; p.ldr = a.ldr; p.M = a.M; p.N = a.N; p.K = a.K; p.act = a.act; p.alpha = a.alpha;
-    p.tiles_m = egm_cdiv(a.M, BM); p.tiles_n = egm_cdiv(a.N, BN);
-    const long long tiles = (long long)p.tiles_m * p.tiles_n;
-    int grid = 256;                                                   // one workgroup per CU, 32 per XCD; each walks its XCD's tile list
-    if (tiles < grid) grid = (int)((tiles + 7) / 8) * 8;
-    const bool r = a.R != nullptr;
-    switch (a.act) {
-        case 0: return r ? launch_dma<true, 0>(p, grid, st) : launch_dma<false, 0>(p, grid, st);
-        case 1: return r ? launch_dma<true, 1>(p, grid, st) : launch_dma<false, 1>(p, grid, st);
-        case 2: return r ? launch_dma<true, 2>(p, grid, st) : launch_dma<false, 2>(p, grid, st);
-    }
-    EGM_FAIL(EGM_ERR_ARG, "gemm_dma: unknown activation %d", a.act);
+    p.tiles_m = egm_cdiv(a.M, BM); p.tiles_n = egm_cdiv(a.N, 64 * nt);
+    const int grid = 256;                                             // one workgroup per CU, 32 per XCD; each walks its XCD's tile list
+    return nt == 4 ? launch_dma_nt<4>(p, grid, a.R != nullptr, a.act, st) : launch_dma_nt<3>(p, grid, a.R != nullptr, a.act, st);
 }

@@ -437,20 +437,78 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 }
 
 // ---- LayerNorm over the last dimension, fp32 statistics; one wave per row ------------------------------------------
+// The row lives in registers: 16-byte vectors (8 bf16 / 4 fp32), up to LN_NV per lane (D <= 64 * LN_NV * vector width: 2048 for bf16), read
+// once, two-pass statistics (mean, then centred second moment) on the registers, written as whole vectors.  (The first version read the
+// row three times with 2-byte loads: 20 us for 15 520 x 768 bf16 = 2.4 TB/s.)  Rows that do not fit take the scalar loop.
+constexpr int LN_NV = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int ldx, const float* __restrict__ g, const float* __restrict__ b,
-                                                        float eps, T* __restrict__ y, int ldy, long long rows, int D) {
+                                                        float eps, T* __restrict__ y, int ldy, long long rows, int D, int vec_ok) {
+    constexpr int VEC = 16 / sizeof(T);
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const T* xr = x + row * ldx;
+    T* yr = y + row * ldy;
+    if (vec_ok) {
+        const int nvec = D / VEC;
+        float v[LN_NV][VEC];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_NV; ++k) {
+            const int iv = lane + 64 * k;
+            if (iv < nvec) {
+                if (sizeof(T) == 2) {
+                    float t8[8];
+                    load8(reinterpret_cast<const bf16_t*>(xr) + iv * 8, t8);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[k][e] = t8[e % 8];
+                } else {
+                    const float4 t4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xr) + iv * 4);
+                    v[k][0] = t4.x; v[k][1 % VEC] = t4.y; v[k][2 % VEC] = t4.z; v[k][3 % VEC] = t4.w;
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) s += v[k][e];
+            }
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_NV; ++k)
+            if (lane + 64 * k < nvec) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { const float d = v[k][e] - mean; q += d * d; }
+            }
+        const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+        for (int k = 0; k < LN_NV; ++k) {
+            const int iv = lane + 64 * k;
+            if (iv < nvec) {
+                float o[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; e += 4) {
+                    const float4 gv = *reinterpret_cast<const float4*>(g + iv * VEC + e), bv = *reinterpret_cast<const float4*>(b + iv * VEC + e);
+                    o[e] = (v[k][e] - mean) * rstd * gv.x + bv.x; o[e + 1] = (v[k][e + 1] - mean) * rstd * gv.y + bv.y;
+                    o[e + 2] = (v[k][e + 2] - mean) * rstd * gv.z + bv.z; o[e + 3] = (v[k][e + 3] - mean) * rstd * gv.w + bv.w;
+                }
+                if (sizeof(T) == 2) {
+                    float t8[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t8[e] = o[e % VEC];
+                    store8(reinterpret_cast<bf16_t*>(yr) + iv * 8, t8);
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(yr) + iv * 4) = make_float4(o[0], o[1 % VEC], o[2 % VEC], o[3 % VEC]);
+                }
+            }
+        }
+        return;
+    }
     float s = 0.f;
     for (int j = lane; j < D; j += 64) s += to_f32(xr[j]);
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
     for (int j = lane; j < D; j += 64) { const float d = to_f32(xr[j]) - mean; q += d * d; }
     const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
-    T* yr = y + row * ldy;
     for (int j = lane; j < D; j += 64) yr[j] = from_f32<T>((to_f32(xr[j]) - mean) * rstd * g[j] + b[j]);
 }
 
@@ -605,8 +663,11 @@ extern "C" int egm_softmax_rows(int dtype, const float* S, int lds_, void* P, in
 extern "C" int egm_layernorm(int dtype, const void* x, int ldx, const float* gamma, const float* beta, float eps, void* y, int ldy, long long rows,
                              int D, egm_stream_t s) {
     EGM_REQUIRE(x && y && gamma && beta && rows > 0 && D > 0 && ldx >= D && ldy >= D, "layernorm: bad args");
+    const int vec = dtype == EGM_BF16 ? 8 : 4;
+    const int vec_ok = D % vec == 0 && D <= 64 * LN_NV * vec && ldx % vec == 0 && ldy % vec == 0 && egm_aligned16(x) && egm_aligned16(y) &&
+                       egm_aligned16(gamma) && egm_aligned16(beta);
     EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((layernorm_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)s, (const T*)x,
-                                                 ldx, gamma, beta, eps, (T*)y, ldy, rows, D));
+                                                 ldx, gamma, beta, eps, (T*)y, ldy, rows, D, vec_ok));
     EGM_CHECK_LAUNCH("layernorm");
     return EGM_OK;
 }

@@ -84,13 +84,14 @@ def test_fused_attention_head64_vs_torch(L):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_layernorm_vs_torch(dtype):
+@pytest.mark.parametrize("D", [768, 512, 64, 1024, 2048, 100, 4096])    # register-resident vector path (ragged lane counts, its limit) and the scalar loop
+def test_layernorm_vs_torch(dtype, D):
     from egm_unet_amd.clip import ops as O
     g = torch.Generator().manual_seed(4)
-    x = torch.randn(37, 768, generator=g) * 3 + 1
-    ln = torch.nn.LayerNorm(768)
+    x = torch.randn(37, D, generator=g) * 3 + 1
+    ln = torch.nn.LayerNorm(D)
     with torch.no_grad():
-        ln.weight.copy_(1 + 0.1 * torch.randn(768, generator=g)); ln.bias.copy_(0.1 * torch.randn(768, generator=g))
+        ln.weight.copy_(1 + 0.1 * torch.randn(D, generator=g)); ln.bias.copy_(0.1 * torch.randn(D, generator=g))
     if dtype == torch.bfloat16:
         x = x.bfloat16().float()
     y = O.layernorm(x.to(DEV).to(dtype), ln.to(DEV))

@@ -20,8 +20,10 @@ def _run(M, N, K, act, with_bias, with_r, lda_pad=0, seed=0):
     return A, B, bias, R, out
 
 
-# (M, N, K): ViT-B/16 at 32 x 485 tokens (qkv / proj / fc1 / fc2), ragged M, N not a multiple of 256, one k-chunk, many tiles per workgroup
-SHAPES = [(15520, 2304, 768), (15520, 768, 768), (15520, 3072, 768), (15520, 768, 3072), (4099, 1032, 64), (8192, 2048, 128), (33000, 512, 192)]
+# (M, N, K): ViT-B/16 at 32 x 485 tokens (qkv / proj / fc1 / fc2: proj and fc2 take the 192-wide tiles), ragged M, a shape neither tile form
+# takes, one k-chunk, many tiles per workgroup, 192-wide tiles with a ragged last row of tiles
+SHAPES = [(15520, 2304, 768), (15520, 768, 768), (15520, 3072, 768), (15520, 768, 3072), (4099, 1032, 64), (8192, 2048, 128), (33000, 512, 192),
+          (12000, 960, 128)]
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
