@@ -290,10 +290,13 @@ static int gemm_dma_nt(const GemmDmaArgs& a) {
     if (!egm_aligned16(a.A) || !egm_aligned16(a.B) || !egm_aligned16(a.C) || (a.R && !egm_aligned16(a.R)) || (a.bias && !egm_aligned16(a.bias))) return 0;
     if ((long long)BM * a.lda >= (1LL << 31) || 256LL * a.ldb >= (1LL << 31)) return 0;
     const int tm = egm_cdiv(a.M, BM);
-    if ((long long)tm * egm_cdiv(a.N, 256) >= 256) return 4;
+    const long long t4 = (long long)tm * egm_cdiv(a.N, 256);
+    if (t4 >= 256) return 4;
     // less than one 256 x 256 tile per CU (proj / fc2 at N = 768: 183): 192-wide tiles when they give (nearly) every CU exactly one
     const int tn3 = egm_cdiv(a.N, 192);
-    if (a.N % 192 == 0 && egm_cdiv(tm, 8) * tn3 <= 32 && (long long)tm * tn3 >= 192) return 3;
+    const long long t3 = (a.N % 192 == 0 && egm_cdiv(tm, 8) * tn3 <= 32) ? (long long)tm * tn3 : 0;
+    if (t3 >= 192 && t3 > t4) return 3;
+    if (t4 >= 192) return 4;                                           // three quarters of the chip in one round (text fc1: 31 x 8 = 248 tiles)
     return 0;                                                          // the 128-wide register-staged kernels fill the chip better
 }
 int egm_gemm_dma_ok(const GemmDmaArgs& a) { return gemm_dma_nt(a) != 0; }

@@ -287,7 +287,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void attention_fused_kernel(const bf16_t* __restrict__ qkv, int ld, int L, int H, int D, bf16_t* __restrict__ out,
                                                               int ldo, float scale_log2e) {
     __shared__ __attribute__((aligned(16))) unsigned char Xs[64 * 144];       // [key][64 d] + pad
-    __shared__ __attribute__((aligned(16))) unsigned char Vt[64 * 144];       // [d][64 keys] + pad
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * 144];       // [key][64 d] + pad: V as it lies in memory
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r31 = lane & 31, hq = lane >> 5;
     const int b = blockIdx.y / H, hh = blockIdx.y - b * H;
     const int qblk0 = blockIdx.x * 128, query = qblk0 + wv * 32 + r31;
@@ -329,9 +329,7 @@ __global__ __launch_bounds__(256) void attention_fused_kernel(const bf16_t* __re
                     vv = *reinterpret_cast<const uint4*>(row + 2 * D + v * 8);
                 }
                 *reinterpret_cast<uint4*>(Xs + key * 144 + v * 16) = xv;
-                const unsigned short* ve = reinterpret_cast<const unsigned short*>(&vv);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) *reinterpret_cast<unsigned short*>(Vt + (v * 8 + e) * 144 + key * 2) = ve[e];
+                *reinterpret_cast<uint4*>(Vs + key * 144 + v * 16) = vv;
             }
             __syncthreads();
 #pragma unroll
@@ -381,10 +379,16 @@ __global__ __launch_bounds__(256) void attention_fused_kernel(const bf16_t* __re
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2) {
-                        const unsigned char* vrow = Vt + (dt * 32 + r31) * 144 + (tile * 32 + k2 * 16 + 4 * hq) * 2;
-                        uint4 a;
-                        const uint2 lo = *reinterpret_cast<const uint2*>(vrow), hi = *reinterpret_cast<const uint2*>(vrow + 16);
-                        a.x = lo.x; a.y = lo.y; a.z = hi.x; a.w = hi.y;
+                        // V^T fragment by transposing LDS reads (ds_read_b64_tr_b16, the form of GMma<bf16_t>::load_t): a 16-lane group
+                        // reads 4 key rows x 16 d and lane t receives the 4 keys of d = t; this lane needs keys 4 hq + {0..3} and
+                        // 4 hq + {8..11} of the 16-key step (the k-slot numbering of the probabilities above).  (The first version
+                        // transposed V on the way INTO LDS with sixteen 2-byte writes per thread and key block.)
+                        const int gq4 = lane >> 4, t16 = lane & 15;
+                        const unsigned char* va = Vs + (tile * 32 + k2 * 16 + 4 * (gq4 >> 1) + (t16 >> 2)) * 144 + (dt * 32 + (gq4 & 1) * 16 + 4 * (t16 & 3)) * 2;
+                        typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
+                        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(va));
+                        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(va + 8 * 144));
+                        const s16x8_t a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), pk[k2], acc[dt], 0, 0, 0);
                     }
             }
