@@ -627,7 +627,8 @@ def main():
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command with
         # EGM_BENCH_NO_INSTRUMENT=1, i.e. graph replays only; FETCH_SIZE doubled per the gfx950 note of the guide): a CHECKED-IN
         # measurement keyed by kernel instantiation (tools/pmc_traffic.py)
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{r}_pmc_traffic.json") for r in (9, 8, 7, 6, 5, 4)) if os.path.exists(q)), "")
+        import glob
+        tpath = next((sorted(g)[-1] for g in (glob.glob(os.path.join(ROOT, "profiles", f"r0{r}*_pmc_traffic.json")) for r in (9, 8, 7, 6, 5, 4)) if g), "")
         tjson = json.load(open(tpath)) if (tpath and args.dtype == "bf16") else {}
         mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
 
@@ -649,6 +650,8 @@ def main():
                     "traffic_source": (os.path.relpath(tpath, ROOT) + ": rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over graph replays only "
                                        "(EGM_BENCH_NO_INSTRUMENT=1), per kernel instantiation, recorded earlier and checked in (FETCH doubled per the "
                                        "gfx950 note of MI355X_MICROARCH.md); not collected by this run") if tr else None,
+                    "traffic_note": ("the counter bytes include the kernel's fp32 partial-sum slabs (written once, summed by wgrad_reduce_multi_kernel); "
+                                     "the algorithmic figure counts the operands x and dy only") if (tr and "wgrad" in key) else None,
                     "kernel": key, "algorithmic_bytes_per_launch": round(byts_ / n_),
                     "algorithmic_bytes_per_launch_in_graph": round(alg_ung) if alg_ung else None, "launches_per_step_in_graph": n_ung,
                     "launches_per_step": n_, "avg_launch_ms": round(ms_ / n_, 4), "algorithmic_gflop_per_launch": round(flop_ / n_ / 1e9, 3),
