@@ -27,6 +27,12 @@ typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
 __device__ uint4 egm_gemm_zero_page[4];
+#ifdef EGM_GEMM_TIMING
+__device__ float* egm_gemm_timing_buf = nullptr;          // set from the host with hipMemcpyToSymbol (tools/gemm_diag.py via egm_gemm_dma_timing)
+extern "C" int egm_gemm_dma_timing(float* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(egm_gemm_timing_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 namespace {
 
@@ -49,7 +55,7 @@ struct Params {
 template <int ACT>
 __device__ __forceinline__ float act_of(float v) {                     // gemm_act of csrc/vit.hip
     if (ACT == 1) return v > 0.f ? v : 0.f;
-    if (ACT == 2) return v / (1.f + expf(-1.702f * v));                // QuickGELU
+    if (ACT == 2) return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v));   // QuickGELU, bf16 output: gemm_act(fast)
     return v;
 }
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
@@ -125,7 +131,10 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
         for (int k = 0; k < KT; ++k) dma(q, k);
         advance_issue();
     }
-    if (wv >= 4) __builtin_amdgcn_s_setprio(1);                       // the second-dispatched half loses issue arbitration otherwise (conv3x3_tile.hip)
+#ifndef EGM_GEMM_PRIO
+#define EGM_GEMM_PRIO 0            // 0: static raise for waves 4-7 (conv3x3_tile.hip); 1: raise around every MFMA cluster; 2: none (A/B builds)
+#endif
+    if (EGM_GEMM_PRIO == 0 && wv >= 4) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses issue arbitration otherwise
 
     // ---- fragment read addresses (bytes inside a stage buffer)
     const int pa = (wr * 64 + r31) * 128, pbb = BOFF + (wc * NT * 32 + r31) * 128;
@@ -148,10 +157,12 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
             for (int j = 0; j < NT; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(sb + pbb + j * 4096 + kso[ks]);
         };
         auto mmas = [&](const bf16x8_t (&a)[2], const bf16x8_t (&bfr)[NT]) __attribute__((always_inline)) {
+            if (EGM_GEMM_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], a[i], acc[i][j], 0, 0, 0);
+            if (EGM_GEMM_PRIO == 1) __builtin_amdgcn_s_setprio(0);
         };
         frags(0, fa[0], fb[0]);
         frags(1, fa[1], fb[1]);
@@ -236,10 +247,23 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
         }
     };
 
+#ifdef EGM_GEMM_TIMING
+    // diagnostic build (tools/gemm_diag.py): shader-clock totals per phase of every wave, written to egm_gemm_timing_buf
+    long long tph[5] = {0, 0, 0, 0, 0};
+    __builtin_amdgcn_sched_barrier(0);
+    long long tmark = __builtin_amdgcn_s_memtime();
+    const long long treal0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_sched_barrier(0);
+#define EGM_GTICK(i) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_amdgcn_s_memtime(); \
+                          __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); tph[i] += t_ - tmark; tmark = t_; } while (0)
+#else
+#define EGM_GTICK(i) do { } while (0)
+#endif
     // ---- stage pipeline over (tile, chunk)
     int cu_ch = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    EGM_GTICK(4);
     int bc = 0;
     for (int t = 0; t < S; ++t) {
         const bool more = t + 1 < S;
@@ -254,9 +278,12 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         }
         compute(bc, more, q);
+        EGM_GTICK(0);
         // stage t+1 has landed (this wave's share), then everybody's has and everybody is done reading stage t
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        EGM_GTICK(1);
         __builtin_amdgcn_s_barrier();
+        EGM_GTICK(2);
         if (++cu_ch == nch) {
             cu_ch = 0;
             epilogue(cu, bc);                                         // out tiles live in the buffer just consumed ...
@@ -265,9 +292,18 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
+            EGM_GTICK(3);
         }
         bc ^= 1;
     }
+#ifdef EGM_GEMM_TIMING
+    if (egm_gemm_timing_buf != nullptr && lane == 0) {      // [block][wave][8]: mfma phase, vmcnt wait, barrier, epilogue, prologue, stages, 100 MHz ticks
+        const long long treal = __builtin_amdgcn_s_memrealtime() - treal0;
+        float* o = egm_gemm_timing_buf + ((long long)blockIdx.x * 8 + wv) * 8;
+        for (int i = 0; i < 5; ++i) o[i] = (float)tph[i];
+        o[5] = (float)S; o[6] = (float)treal; o[7] = (float)ntl;
+    }
+#endif
 }
 
 int g_gemm_dma = -1;

@@ -51,9 +51,15 @@ struct GemmParams {
     float alpha;
 };
 
-__device__ __forceinline__ float gemm_act(float v, int act) {
+// fast != 0 (the result is stored as bf16): the sigmoid by v_exp_f32 + v_rcp_f32 (relative error ~1e-6, the bf16 rounding behind it is
+// 4e-3) instead of expf + an IEEE division -- 6 instructions per element against ~30; in the fc1 product of the ViT (15 520 x 3 072
+// outputs) the exact form was 39 % of the kernel (tools/gemm_diag.py).  Same expression in csrc/gemm_dma.hip.
+__device__ __forceinline__ float gemm_act(float v, int act, bool fast = false) {
     if (act == 1) return v > 0.f ? v : 0.f;
-    if (act == 2) return v / (1.f + expf(-1.702f * v));          // QuickGELU: x * sigmoid(1.702 x)
+    if (act == 2) {                                               // QuickGELU: x * sigmoid(1.702 x)
+        if (fast) return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v));
+        return v / (1.f + expf(-1.702f * v));
+    }
     return v;
 }
 
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         for (int i = 0; i < 16; ++i) {
             const int m = m0 + wv * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
             if (m >= p.M) continue;
-            float v = gemm_act(p.alpha * acc[t][i] + bv, p.act);
+            float v = gemm_act(p.alpha * acc[t][i] + bv, p.act, sizeof(T) == 2 && !p.c_f32);
             if (p.R) v += to_f32(reinterpret_cast<const T*>(p.R)[roff + (long long)m * p.ldr + n]);
             if (p.c_f32) reinterpret_cast<float*>(p.C)[coff + (long long)m * p.ldc + n] = v;
             else reinterpret_cast<T*>(p.C)[coff + (long long)m * p.ldc + n] = from_f32<T>(v);
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(128 * WMW, 2) void gemm_nt128_kernel(GemmParams p) 
                 if (n4 >= p.N) continue;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gemm_act(p.alpha * acc[i][j][gq * 4 + e] + ((p.bias && n4 + e < p.N) ? p.bias[n4 + e] : 0.f), p.act);
+                for (int e = 0; e < 4; ++e) v[e] = gemm_act(p.alpha * acc[i][j][gq * 4 + e] + ((p.bias && n4 + e < p.N) ? p.bias[n4 + e] : 0.f), p.act, !p.c_f32);
                 if (vec_ok) {
                     if (p.R) {
                         const uint2 rv = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.R) + roff + (long long)m * p.ldr + n4);
