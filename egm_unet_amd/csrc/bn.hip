@@ -44,7 +44,7 @@ __device__ __forceinline__ void channel_partials_body(const T* __restrict__ a, i
                 load8(y + p * ldy + cv * 8, yv);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float g = v[j] * act_grad(fmaf(yv[j], sc[j], sh[j]), act);
+                    const float g = v[j] * act_grad<sizeof(T) == 2>(fmaf(yv[j], sc[j], sh[j]), act);
                     s[j] += g; q[j] += g * (yv[j] - mu[j]) * rs[j];
                 }
             }
@@ -204,7 +204,7 @@ __device__ __forceinline__ void bn_act_fwd_body(const T* __restrict__ y, int ldy
             load8(y + p * ldy + cv * 8, v);
             load8(y + (p + stride) * ldy + cv * 8, u);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v[j] = bn_fwd_elem(v[j], sc[j], sh[j], act); u[j] = bn_fwd_elem(u[j], sc[j], sh[j], act); }
+            for (int j = 0; j < 8; ++j) { v[j] = bn_fwd_elem<sizeof(T) == 2>(v[j], sc[j], sh[j], act); u[j] = bn_fwd_elem<sizeof(T) == 2>(u[j], sc[j], sh[j], act); }
             store8(z + p * ldz + cv * 8, v);
             store8(z + (p + stride) * ldz + cv * 8, u);
         }
@@ -212,7 +212,7 @@ __device__ __forceinline__ void bn_act_fwd_body(const T* __restrict__ y, int ldy
             float v[8];
             load8(y + p * ldy + cv * 8, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = bn_fwd_elem(v[j], sc[j], sh[j], act);
+            for (int j = 0; j < 8; ++j) v[j] = bn_fwd_elem<sizeof(T) == 2>(v[j], sc[j], sh[j], act);
             store8(z + p * ldz + cv * 8, v);
         }
         return;
@@ -223,7 +223,7 @@ __device__ __forceinline__ void bn_act_fwd_body(const T* __restrict__ y, int ldy
         float v[8];
         load8(y + p * ldy + cv * 8, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = bn_fwd_elem(v[j], scale[cv * 8 + j], shift[cv * 8 + j], act);
+        for (int j = 0; j < 8; ++j) v[j] = bn_fwd_elem<sizeof(T) == 2>(v[j], scale[cv * 8 + j], shift[cv * 8 + j], act);
         store8(z + p * ldz + cv * 8, v);
     }
 }
@@ -273,8 +273,8 @@ __device__ __forceinline__ void bn_act_bwd_apply_body(const T* __restrict__ dz, 
             load8(y + (p + stride) * ldy + cv * 8, y2);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                g[j] = bn_bwd_elem(g[j], yv[j], sc[j], sh[j], cb[j], cc[j], act);
-                g2[j] = bn_bwd_elem(g2[j], y2[j], sc[j], sh[j], cb[j], cc[j], act);
+                g[j] = bn_bwd_elem<sizeof(T) == 2>(g[j], yv[j], sc[j], sh[j], cb[j], cc[j], act);
+                g2[j] = bn_bwd_elem<sizeof(T) == 2>(g2[j], y2[j], sc[j], sh[j], cb[j], cc[j], act);
             }
             store8(dy + p * lddy + cv * 8, g);
             store8(dy + (p + stride) * lddy + cv * 8, g2);
@@ -284,7 +284,7 @@ __device__ __forceinline__ void bn_act_bwd_apply_body(const T* __restrict__ dz, 
             load8(dz + p * lddz + cv * 8, g);
             load8(y + p * ldy + cv * 8, yv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] = bn_bwd_elem(g[j], yv[j], sc[j], sh[j], cb[j], cc[j], act);
+            for (int j = 0; j < 8; ++j) g[j] = bn_bwd_elem<sizeof(T) == 2>(g[j], yv[j], sc[j], sh[j], cb[j], cc[j], act);
             store8(dy + p * lddy + cv * 8, g);
         }
         return;
@@ -304,7 +304,7 @@ __device__ __forceinline__ void bn_act_bwd_apply_body(const T* __restrict__ dz, 
                 ccv = -scale[c] * rstd[c] * m1;
                 cbv = -scale[c] * m0 - ccv * mean[c];
             }
-            o[j] = bn_bwd_elem(g[j], yv[j], scale[c], shift[c], cbv, ccv, act);
+            o[j] = bn_bwd_elem<sizeof(T) == 2>(g[j], yv[j], scale[c], shift[c], cbv, ccv, act);
         }
         store8(dy + p * lddy + cv * 8, o);
     }

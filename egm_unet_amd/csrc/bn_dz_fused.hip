@@ -116,12 +116,12 @@ __global__ __launch_bounds__(256) void bn_dz_bwd_reduce_kernel(DzArgs d, const T
             load8(y + p * ldy + cv * 8, yv);
             if constexpr (MODE == DZ_MCA) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) z[j] = to_f32(from_f32<T>(bn_fwd_elem(yv[j], sc[j], sh[j], act)));
+                for (int j = 0; j < 8; ++j) z[j] = to_f32(from_f32<T>(bn_fwd_elem<sizeof(T) == 2>(yv[j], sc[j], sh[j], act)));
             }
             ctx.dz(d, p, cv, z, g);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float gg = g[j] * act_grad(fmaf(yv[j], sc[j], sh[j]), act);
+                const float gg = g[j] * act_grad<sizeof(T) == 2>(fmaf(yv[j], sc[j], sh[j]), act);
                 s[j] += gg; q[j] += gg * (yv[j] - mu[j]) * rs[j];
             }
         }
@@ -167,11 +167,11 @@ __global__ __launch_bounds__(256) void bn_dz_bwd_apply_kernel(DzArgs d, const T*
         load8(y + p * ldy + cv * 8, yv);
         if constexpr (MODE == DZ_MCA) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) z[j] = to_f32(from_f32<T>(bn_fwd_elem(yv[j], sc[j], sh[j], act)));
+            for (int j = 0; j < 8; ++j) z[j] = to_f32(from_f32<T>(bn_fwd_elem<sizeof(T) == 2>(yv[j], sc[j], sh[j], act)));
         }
         ctx.dz(d, p, cv, z, g);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = bn_bwd_elem(g[j], yv[j], sc[j], sh[j], cb[j], cc[j], act);
+        for (int j = 0; j < 8; ++j) g[j] = bn_bwd_elem<sizeof(T) == 2>(g[j], yv[j], sc[j], sh[j], cb[j], cc[j], act);
         store8(dy + p * lddy + cv * 8, g);
     }
 }
@@ -219,8 +219,8 @@ __global__ __launch_bounds__(256) void bn_act_cls_fwd_kernel(const T* __restrict
         load8(y + (p + stride) * ldy + cv * 8, u);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            v[j] = to_f32(from_f32<T>(bn_fwd_elem(v[j], sc[j], sh[j], act)));
-            u[j] = to_f32(from_f32<T>(bn_fwd_elem(u[j], sc[j], sh[j], act)));
+            v[j] = to_f32(from_f32<T>(bn_fwd_elem<sizeof(T) == 2>(v[j], sc[j], sh[j], act)));
+            u[j] = to_f32(from_f32<T>(bn_fwd_elem<sizeof(T) == 2>(u[j], sc[j], sh[j], act)));
         }
         store8(z + p * ldz + cv * 8, v);
         store8(z + (p + stride) * ldz + cv * 8, u);
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void bn_act_cls_fwd_kernel(const T* __restrict
         float v[8];
         load8(y + p * ldy + cv * 8, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<T>(bn_fwd_elem(v[j], sc[j], sh[j], act)));
+        for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<T>(bn_fwd_elem<sizeof(T) == 2>(v[j], sc[j], sh[j], act)));
         store8(z + p * ldz + cv * 8, v);
         finish(p, v);
     }

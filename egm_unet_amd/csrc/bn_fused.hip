@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256) void bn_ew_fwd_kernel(const T* __restrict__ y,
             load8(y + (px + stride) * ldy + cv * 8, y1); load8(p + (px + stride) * ldp + cv * 8, p1);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                p0[j] = ew_fwd<T, MODE>(p0[j], rnd<T>(bn_fwd_elem(y0[j], sc[j], sh[j], act)), alpha);
-                p1[j] = ew_fwd<T, MODE>(p1[j], rnd<T>(bn_fwd_elem(y1[j], sc[j], sh[j], act)), alpha);
+                p0[j] = ew_fwd<T, MODE>(p0[j], rnd<T>(bn_fwd_elem<sizeof(T) == 2>(y0[j], sc[j], sh[j], act)), alpha);
+                p1[j] = ew_fwd<T, MODE>(p1[j], rnd<T>(bn_fwd_elem<sizeof(T) == 2>(y1[j], sc[j], sh[j], act)), alpha);
             }
             store8(out + px * ldo + cv * 8, p0);
             store8(out + (px + stride) * ldo + cv * 8, p1);
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void bn_ew_fwd_kernel(const T* __restrict__ y,
             float y0[8], p0[8];
             load8(y + px * ldy + cv * 8, y0); load8(p + px * ldp + cv * 8, p0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) p0[j] = ew_fwd<T, MODE>(p0[j], rnd<T>(bn_fwd_elem(y0[j], sc[j], sh[j], act)), alpha);
+            for (int j = 0; j < 8; ++j) p0[j] = ew_fwd<T, MODE>(p0[j], rnd<T>(bn_fwd_elem<sizeof(T) == 2>(y0[j], sc[j], sh[j], act)), alpha);
             store8(out + px * ldo + cv * 8, p0);
         }
         return;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void bn_ew_fwd_kernel(const T* __restrict__ y,
         load8(p + px * ldp + cv * 8, pv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float z = rnd<T>(bn_fwd_elem(yv[j], scale[cv * 8 + j], shift[cv * 8 + j], act));
+            const float z = rnd<T>(bn_fwd_elem<sizeof(T) == 2>(yv[j], scale[cv * 8 + j], shift[cv * 8 + j], act));
             pv[j] = ew_fwd<T, MODE>(pv[j], z, alpha);
         }
         store8(out + px * ldo + cv * 8, pv);
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void bn_ew_bwd_reduce_kernel(const T* __restri
             for (int j = 0; j < 8; ++j) {
                 float dz, dp;
                 ew_bwd<T, MODE>(gv[j], qv[j], 0.f, alpha, dz, dp);
-                const float dzp = dz * act_grad(fmaf(yv[j], sc[j], sh[j]), act);
+                const float dzp = dz * act_grad<sizeof(T) == 2>(fmaf(yv[j], sc[j], sh[j]), act);
                 s[j] += dzp; t[j] += dzp * (yv[j] - mu[j]) * rs[j];
             }
         }
@@ -134,10 +134,10 @@ __device__ __forceinline__ void ew_apply8(const float (&gv)[8], const float (&qv
                                           float (&o1)[8], float (&o2)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float z = MODE == EGM_EW_GATE ? rnd<T>(bn_fwd_elem(yv[j], sc[j], sh[j], act)) : 0.f;
+        const float z = MODE == EGM_EW_GATE ? rnd<T>(bn_fwd_elem<sizeof(T) == 2>(yv[j], sc[j], sh[j], act)) : 0.f;
         float dz;
         ew_bwd<T, MODE>(gv[j], qv[j], z, alpha, dz, o2[j]);
-        o1[j] = bn_bwd_elem(dz, yv[j], sc[j], sh[j], cb[j], cc[j], act);
+        o1[j] = bn_bwd_elem<sizeof(T) == 2>(dz, yv[j], sc[j], sh[j], cb[j], cc[j], act);
     }
 }
 

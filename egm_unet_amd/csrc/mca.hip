@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void mca_reduce_row_kernel(const T* __restrict
             }
             if (MODE == 2) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<T>(bn_fwd_elem(v[j], sc8[j], sh8[j], act)));
+                for (int j = 0; j < 8; ++j) v[j] = to_f32(from_f32<T>(bn_fwd_elem<sizeof(T) == 2>(v[j], sc8[j], sh8[j], act)));
                 store8(zout + (rowbase + w) * ldz + cv * 8, v);
             }
 #pragma unroll

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_pool_kernel(const T* __restric
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[k][j] = to_f32(from_f32<T>(bn_fwd_elem(v[k][j], sc[j], sh[j], act)));
+            for (int j = 0; j < 8; ++j) v[k][j] = to_f32(from_f32<T>(bn_fwd_elem<sizeof(T) == 2>(v[k][j], sc[j], sh[j], act)));
             store8(z + off[k] * ldz + cv * 8, v[k]);
         }
 #pragma unroll
@@ -109,13 +109,13 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_kernel(const T* __rest
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) zr[k][j] = to_f32(from_f32<T>(bn_fwd_elem(yv[k][j], sc[j], sh[j], act)));
+                for (int j = 0; j < 8; ++j) zr[k][j] = to_f32(from_f32<T>(bn_fwd_elem<sizeof(T) == 2>(yv[k][j], sc[j], sh[j], act)));
             window_dz<T>(zr, gp, gs);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float g = gs[k][j] * act_grad(fmaf(yv[k][j], sc[j], sh[j]), act);
+                    const float g = gs[k][j] * act_grad<sizeof(T) == 2>(fmaf(yv[k][j], sc[j], sh[j]), act);
                     s[j] += g; q[j] += g * (yv[k][j] - mu[j]) * rs[j];
                 }
         }
@@ -168,12 +168,12 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T* __restr
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) zr[k][j] = to_f32(from_f32<T>(bn_fwd_elem(yv[k][j], sc[j], sh[j], act)));
+            for (int j = 0; j < 8; ++j) zr[k][j] = to_f32(from_f32<T>(bn_fwd_elem<sizeof(T) == 2>(yv[k][j], sc[j], sh[j], act)));
         window_dz<T>(zr, gp, gs);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) gs[k][j] = bn_bwd_elem(gs[k][j], yv[k][j], sc[j], sh[j], cb[j], cc[j], act);
+            for (int j = 0; j < 8; ++j) gs[k][j] = bn_bwd_elem<sizeof(T) == 2>(gs[k][j], yv[k][j], sc[j], sh[j], cb[j], cc[j], act);
             store8(dy + off[k] * lddy + cv * 8, gs[k]);
         }
     }
