@@ -350,27 +350,40 @@ __global__ __launch_bounds__(256) void attention_fused_kernel(const bf16_t* __re
                     st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fq[ks], st, 0, 0, 0);
                 }
                 // st[e]: key = key0 + tile*32 + 4 hq + (e&3) + 8 (e>>2), query = this lane's column
+                // The instruction stream of this loop, not its MFMAs (16 of ~700 instructions per key block in the first version), is what
+                // the kernel runs at: keys are only masked where a mask can bite (the block that crosses L; every block when causal),
+                // 2^x is the bare v_exp_f32 (arguments <= 0; exp2f() wraps it in denormal scaling: 4 instructions), and the
+                // accumulators -- which live in AGPRs and take a read + multiply + write each to rescale -- are only rescaled when some
+                // lane's running maximum moved (a factor of exactly 1 otherwise).
                 float sv[16], tmax = -INFINITY;
+                const bool may_mask = MODE == 1 || key0 + 64 > L;                // wave-uniform
+                if (may_mask) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = key0 + tile * 32 + 4 * hq + (e & 3) + 8 * (e >> 2);
-                    const bool dead = key >= L || (MODE == 1 && key > query);
-                    sv[e] = dead ? -INFINITY : st[e] * scale_log2e;
-                    tmax = fmaxf(tmax, sv[e]);
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = key0 + tile * 32 + 4 * hq + (e & 3) + 8 * (e >> 2);
+                        const bool dead = key >= L || (MODE == 1 && key > query);
+                        sv[e] = dead ? -INFINITY : st[e] * scale_log2e;
+                        tmax = fmaxf(tmax, sv[e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { sv[e] = st[e] * scale_log2e; tmax = fmaxf(tmax, sv[e]); }
                 }
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
                 const float m_new = fmaxf(m, tmax);
                 const float m_use = m_new == -INFINITY ? 0.f : m_new;           // fully masked so far: keep everything at zero
-                const float corr = exp2f(m - m_use);
+                const float corr = __builtin_amdgcn_exp2f(m - m_use);
                 float psum = 0.f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { sv[e] = exp2f(sv[e] - m_use); psum += sv[e]; }
+                for (int e = 0; e < 16; ++e) { sv[e] = __builtin_amdgcn_exp2f(sv[e] - m_use); psum += sv[e]; }
                 l = l * corr + psum;
                 m = m_new;
+                if (__any(corr != 1.f)) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                    for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[t][e] *= corr;
+                        for (int e = 0; e < 16; ++e) acc[t][e] *= corr;
+                }
                 bf16x8_t pk[2];
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
