@@ -41,8 +41,10 @@ constexpr int BOFF = BM * BK * 2;                    // B image behind the A ima
 // NT = 32-column blocks per wave: tile 256 x (64 NT).  NT = 4: 256 x 256, the general form.  NT = 3: 256 x 192 for N = 768 (proj / fc2 of
 // ViT-B: 244 tiles = one per CU where 256-wide tiles would leave 73 CUs idle); only offered when no workgroup gets a second tile,
 // because its fp32 out tiles (64 KiB) then may lie across both stage buffers (2 x 56 KiB).
-template <int NT> struct Geom {
-    static constexpr int BN = 64 * NT, STAGE = (BM + BN) * BK * 2, KT = 4 + NT, SMEM = 2 * STAGE;
+// NW = waves per workgroup: 8 (4 x 2, wave tile 64 x 32 NT, two waves per SIMD) or 4 (2 x 2, wave tile 128 x 32 NT, one wave per SIMD with
+// the accumulators in AGPRs: 4 + NT fragment reads per 4 NT MFMAs instead of 2 + NT per 2 NT -- the LDS is what the 8-wave form runs at).
+template <int NT, int NW = 8> struct Geom {
+    static constexpr int BN = 64 * NT, STAGE = (BM + BN) * BK * 2, KA = 32 / NW, KT = (32 + 8 * NT) / NW, SMEM = 2 * STAGE, R = 16 / NW;
 };
 
 struct Params {
@@ -69,10 +71,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr));
 }
 
-template <int NT, bool HAS_R, int ACT>
-__global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
+template <int NT, bool HAS_R, int ACT, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gemm_dma_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int BN = Geom<NT>::BN, STAGE = Geom<NT>::STAGE, KT = Geom<NT>::KT;
+    constexpr int BN = Geom<NT, NW>::BN, STAGE = Geom<NT, NW>::STAGE, KT = Geom<NT, NW>::KT, KA = Geom<NT, NW>::KA, R = Geom<NT, NW>::R;
     typedef __attribute__((address_space(3))) unsigned char* lds_p;
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3, nslot = gridDim.x >> 3;
     const int mt_cnt = (p.tiles_m - xcd + 7) >> 3;                    // m-tiles xcd, xcd + 8, ... of this XCD
@@ -86,9 +88,9 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
     const int wr = wv >> 1, wc = wv & 1;
     const unsigned smem_lds = (unsigned)(unsigned long long)(lds_p)smem;
 
-    // ---- per-lane DMA sources.  Instruction k of this wave: k < 4 -> rows 8 (wv + 8k) .. + 7 of the A tile, k >= 4 -> rows
-    //      8 (wv + 8 (k - 4)) .. of the B tile (NT instructions); lane l -> row + (l >> 3), LDS slot l & 7, k-slot (l & 7) ^ (l >> 3).
-    const int drow = 8 * wv + (lane >> 3);                            // row of instruction k: drow + 64 (k & 3)
+    // ---- per-lane DMA sources.  Instruction k of this wave: k < KA -> rows 8 (wv + NW k) .. + 7 of the A tile, k >= KA -> rows
+    //      8 (wv + NW (k - KA)) .. of the B tile; lane l -> row + (l >> 3), LDS slot l & 7, k-slot (l & 7) ^ (l >> 3).
+    const int drow = 8 * wv + (lane >> 3);                            // row of instruction k: drow + 8 NW (k mod KA)
     const int dks = ((lane & 7) ^ (lane >> 3)) * 8;                   // element offset of the k-slot inside the 64-deep chunk
     const int relA = drow * p.lda + dks, relB = drow * p.ldb + dks;
     const void* const zp = reinterpret_cast<const void*>(egm_gemm_zero_page);
@@ -109,14 +111,14 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
     };
     auto dma = [&](const Src& q, int k) __attribute__((always_inline)) {
         const void* src;
-        if (k < 4) {
-            const int row = drow + 64 * k;
-            src = q.m0 + row < p.M ? reinterpret_cast<const void*>(q.xa + relA + 64 * k * p.lda) : zp;
+        if (k < KA) {
+            const int row = drow + 8 * NW * k;
+            src = q.m0 + row < p.M ? reinterpret_cast<const void*>(q.xa + relA + 8 * NW * k * p.lda) : zp;
         } else {
-            const int row = drow + 64 * (k - 4);
-            src = q.n0 + row < p.N ? reinterpret_cast<const void*>(q.xb + relB + 64 * (k - 4) * p.ldb) : zp;
+            const int row = drow + 8 * NW * (k - KA);
+            src = q.n0 + row < p.N ? reinterpret_cast<const void*>(q.xb + relB + 8 * NW * (k - KA) * p.ldb) : zp;
         }
-        glds16(src, q.lds + k * 8192);
+        glds16(src, q.lds + k * (NW * 1024));
     };
 
     Tile it; it.li = slot; decode(it);
@@ -134,44 +136,47 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
 #ifndef EGM_GEMM_PRIO
 #define EGM_GEMM_PRIO 0            // 0: static raise for waves 4-7 (conv3x3_tile.hip); 1: raise around every MFMA cluster; 2: none (A/B builds)
 #endif
-    if (EGM_GEMM_PRIO == 0 && wv >= 4) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses issue arbitration otherwise
+    if (EGM_GEMM_PRIO == 0 && NW == 8 && wv >= 4) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses issue arbitration otherwise
 
     // ---- fragment read addresses (bytes inside a stage buffer)
-    const int pa = (wr * 64 + r31) * 128, pbb = BOFF + (wc * NT * 32 + r31) * 128;
+    const int pa = (wr * (R * 32) + r31) * 128, pbb = BOFF + (wc * NT * 32 + r31) * 128;
     int kso[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) kso[ks] = ((2 * ks + h) ^ (r31 & 7)) * 16;
 
-    f32x16_t acc[2][NT];
+    f32x16_t acc[R][NT];
 
     // MFMA phase of one stage: 4 k-steps of 16.  The fragments of k-step s+1 are read while the MFMAs of k-step s run (two register sets);
     // the 8 DMA instructions of the next stage go out in the first half of the phase (4 behind the reads of k-step 1, 4 behind those of
     // k-step 2), so the last of them has two k-steps of MFMA time to land before the wait at the end of the stage.
     auto compute = [&](int bufi, bool with_dma, const Src& q) __attribute__((always_inline)) {
         const unsigned char* sb = smem + bufi * STAGE;
-        bf16x8_t fa[2][2], fb[2][NT];
-        auto frags = [&](int ks, bf16x8_t (&a)[2], bf16x8_t (&bfr)[NT]) __attribute__((always_inline)) {
+        bf16x8_t fa[2][R], fb[2][NT];
+        auto frags = [&](int ks, bf16x8_t (&a)[R], bf16x8_t (&bfr)[NT]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sb + pa + i * 4096 + kso[ks]);
+            for (int i = 0; i < R; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sb + pa + i * 4096 + kso[ks]);
 #pragma unroll
             for (int j = 0; j < NT; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(sb + pbb + j * 4096 + kso[ks]);
         };
-        auto mmas = [&](const bf16x8_t (&a)[2], const bf16x8_t (&bfr)[NT]) __attribute__((always_inline)) {
+        auto mmas = [&](const bf16x8_t (&a)[R], const bf16x8_t (&bfr)[NT]) __attribute__((always_inline)) {
             if (EGM_GEMM_PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < R; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], a[i], acc[i][j], 0, 0, 0);
             if (EGM_GEMM_PRIO == 1) __builtin_amdgcn_s_setprio(0);
         };
         frags(0, fa[0], fb[0]);
         frags(1, fa[1], fb[1]);
-        if (with_dma) { dma(q, 0); dma(q, 1); dma(q, 2); dma(q, 3); }
+        if (with_dma) {
+#pragma unroll
+            for (int k = 0; k < KA; ++k) dma(q, k);
+        }
         mmas(fa[0], fb[0]);
         frags(2, fa[0], fb[0]);
         if (with_dma) {
 #pragma unroll
-            for (int k = 4; k < KT; ++k) dma(q, k);
+            for (int k = KA; k < KT; ++k) dma(q, k);
         }
         mmas(fa[1], fb[1]);
         frags(3, fa[1], fb[1]);
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
     auto epilogue = [&](const Tile& t, int bufi) __attribute__((always_inline)) {
         unsigned char* ot = smem + (NT == 4 ? bufi * STAGE : 0) + wv * 8192;   // (NT = 3: the workgroup's only tile is done, both buffers are free)
         const int cv = lane & 7, sl = lane >> 3;
-        // group g = (row block i = g >> 1, column pair jp = g & 1): 32 m x 64 n.  The residual vectors and the bias of group g+1 are
+        // group g = (row block i = g >> 1, column pair jp = g & 1): 32 m x 64 n, 2 R of them.  The residual vectors and the bias of group g+1 are
         // requested before group g is worked on (one exposed memory latency per tile, not four).
         uint4 rr[2][4];
         float4 bq[2][2];
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
             if (HAS_R) {
 #pragma unroll
                 for (int it2 = 0; it2 < 4; ++it2) {
-                    const int mr = t.m0 + wr * 64 + i * 32 + sl + it2 * 8;
+                    const int mr = t.m0 + wr * (R * 32) + i * 32 + sl + it2 * 8;
                     r4[it2] = *reinterpret_cast<const uint4*>(p.R + (long long)(mr < p.M ? mr : p.M - 1) * p.ldr + nc);
                 }
             }
@@ -206,12 +211,12 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
         };
         request(0, rr[0], bq[0]);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < 2 * R; ++g) {
             const int i = g >> 1, jp = g & 1;
-            if (g + 1 < 4) request(g + 1, rr[(g + 1) & 1], bq[(g + 1) & 1]);
+            if (g + 1 < 2 * R) request(g + 1, rr[(g + 1) & 1], bq[(g + 1) & 1]);
             const int n = t.n0 + wc * (NT * 32) + jp * 64 + cv * 8;
             const bool nin = jp * 64 + cv * 8 < NT * 32;              // (NT = 3: the second column group is one 32-column block)
-            const int mb = t.m0 + wr * 64 + i * 32 + sl;              // + 8 it2
+            const int mb = t.m0 + wr * (R * 32) + i * 32 + sl;        // + 8 it2
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma_kernel(Params p) {
         if (more) advance_issue();
         if (cu_ch == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < R; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -337,25 +342,26 @@ static int gemm_dma_nt(const GemmDmaArgs& a) {
 }
 int egm_gemm_dma_ok(const GemmDmaArgs& a) { return gemm_dma_nt(a) != 0; }
 
-template <int NT, bool HAS_R, int ACT>
+template <int NT, bool HAS_R, int ACT, int NW>
 static int launch_dma(const Params& p, int grid, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<NT, HAS_R, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           Geom<NT>::SMEM);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dma_kernel<NT, HAS_R, ACT, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (Geom<NT, NW>::SMEM));
         if (e != hipSuccess) EGM_FAIL(EGM_ERR_LAUNCH, "gemm_dma: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_dma_kernel<NT, HAS_R, ACT>), dim3(grid), dim3(512), Geom<NT>::SMEM, st, p);
+    constexpr int smem_bytes = Geom<NT, NW>::SMEM;
+    hipLaunchKernelGGL((gemm_dma_kernel<NT, HAS_R, ACT, NW>), dim3(grid), dim3(64 * NW), smem_bytes, st, p);
     EGM_CHECK_LAUNCH("gemm_dma");
     return EGM_OK;
 }
-template <int NT>
+template <int NT, int NW>
 static int launch_dma_nt(const Params& p, int grid, bool r, int act, hipStream_t st) {
     switch (act) {
-        case 0: return r ? launch_dma<NT, true, 0>(p, grid, st) : launch_dma<NT, false, 0>(p, grid, st);
-        case 1: return r ? launch_dma<NT, true, 1>(p, grid, st) : launch_dma<NT, false, 1>(p, grid, st);
-        default: return r ? launch_dma<NT, true, 2>(p, grid, st) : launch_dma<NT, false, 2>(p, grid, st);
+        case 0: return r ? launch_dma<NT, true, 0, NW>(p, grid, st) : launch_dma<NT, false, 0, NW>(p, grid, st);
+        case 1: return r ? launch_dma<NT, true, 1, NW>(p, grid, st) : launch_dma<NT, false, 1, NW>(p, grid, st);
+        default: return r ? launch_dma<NT, true, 2, NW>(p, grid, st) : launch_dma<NT, false, 2, NW>(p, grid, st);
     }
 }
 
@@ -367,5 +373,7 @@ int egm_gemm_dma_launch(const GemmDmaArgs& a, hipStream_t st) {
     p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc; p.ldr = a.ldr; p.M = a.M; p.N = a.N; p.K = a.K; p.act = a.act; p.alpha = a.alpha;
     p.tiles_m = egm_cdiv(a.M, BM); p.tiles_n = egm_cdiv(a.N, 64 * nt);
     const int grid = 256;                                             // one workgroup per CU, 32 per XCD; each walks its XCD's tile list
-    return nt == 4 ? launch_dma_nt<4>(p, grid, a.R != nullptr, a.act, st) : launch_dma_nt<3>(p, grid, a.R != nullptr, a.act, st);
+    if (egm_gemm_dma_mode(-1) == 2)                                    // the 4-wave form (128-row wave tiles)
+        return nt == 4 ? launch_dma_nt<4, 4>(p, grid, a.R != nullptr, a.act, st) : launch_dma_nt<3, 4>(p, grid, a.R != nullptr, a.act, st);
+    return nt == 4 ? launch_dma_nt<4, 8>(p, grid, a.R != nullptr, a.act, st) : launch_dma_nt<3, 8>(p, grid, a.R != nullptr, a.act, st);
 }

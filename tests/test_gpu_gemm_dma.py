@@ -29,6 +29,7 @@ SHAPES = [(15520, 2304, 768), (15520, 768, 768), (15520, 3072, 768), (15520, 768
 @pytest.mark.parametrize("M,N,K", SHAPES)
 @pytest.mark.parametrize("act,with_bias,with_r", [(0, True, False), (0, True, True), (2, True, False), (1, False, True), (0, False, False)])
 def test_gemm_dma_bit_identical_to_register_staged_kernel(M, N, K, act, with_bias, with_r):
+    """both forms of the LDS-DMA kernel (mode 1: 8 waves, 64-row wave tiles; mode 2: 4 waves, 128-row wave tiles, accumulators in AGPRs)"""
     from egm_unet_amd._lib import lib
     L = lib()
     old = L.cdll.egm_gemm_dma_mode(-1)
@@ -37,9 +38,12 @@ def test_gemm_dma_bit_identical_to_register_staged_kernel(M, N, K, act, with_bia
         A, B, bias, R, want = _run(M, N, K, act, with_bias, with_r, seed=M + N + K)
         L.cdll.egm_gemm_dma_mode(1)
         _, _, _, _, got = _run(M, N, K, act, with_bias, with_r, seed=M + N + K)
+        L.cdll.egm_gemm_dma_mode(2)
+        _, _, _, _, got4 = _run(M, N, K, act, with_bias, with_r, seed=M + N + K)
     finally:
         L.cdll.egm_gemm_dma_mode(old)
     assert torch.equal(got, want), f"max diff {(got.float() - want.float()).abs().max().item()}"
+    assert torch.equal(got4, want), f"4-wave form: max diff {(got4.float() - want.float()).abs().max().item()}"
     # and both against float64 (sampled rows: the full product in float64 on the host is slow)
     rows = torch.linspace(0, M - 1, 97).long().to(DEV)
     ref = A[rows, :K].double() @ B.double().T

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the two bf16 A * B^T kernels behind egm_gemm on the nn.Linear shapes of CLIPSeg's ViT-B/16 at 32 x 485 tokens
-(egm_gemm_dma_mode 0 = register-staged gemm_nt128_kernel, 1 = 8-wave LDS-DMA gemm_dma_kernel).  Interleaved rounds in one process,
+(egm_gemm_dma_mode 0 = register-staged gemm_nt128_kernel, 1 = 8-wave LDS-DMA gemm_dma_kernel, 2 = its 4-wave form).  Interleaved rounds in one process,
 HIP events around trains of back-to-back launches, median of rounds.   usage: gemm_bench.py [rounds] [train]"""
 import json
 import os
@@ -31,9 +31,9 @@ for name, M_, N, K, act, with_r in SHAPES:
         L.cdll.egm_gemm_dma_mode(mode)
         C.gemm(A, K, B, K, True, out, N, M_, N, K, torch.bfloat16, bias=bias, act=act, R=R, ldr=N)
 
-    times = {0: [], 1: []}
+    times = {0: [], 1: [], 2: []}
     for r in range(rounds):
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             run(mode)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -42,7 +42,7 @@ for name, M_, N, K, act, with_r in SHAPES:
             e1.record(); torch.cuda.synchronize()
             times[mode].append(e0.elapsed_time(e1) / train * 1e3)
     flop = 2.0 * M_ * N * K
-    t0, t1 = statistics.median(times[0]), statistics.median(times[1])
-    print(json.dumps({"gemm": name, "M": M_, "N": N, "K": K, "old_us": round(t0, 1), "new_us": round(t1, 1), "old_tflops": round(flop / t0 / 1e6),
-                      "new_tflops": round(flop / t1 / 1e6)}), flush=True)
+    t0, t1, t2 = statistics.median(times[0]), statistics.median(times[1]), statistics.median(times[2])
+    print(json.dumps({"gemm": name, "M": M_, "N": N, "K": K, "old_us": round(t0, 1), "new_us": round(t1, 1), "new4_us": round(t2, 1), "old_tflops": round(flop / t0 / 1e6),
+                      "new_tflops": round(flop / t1 / 1e6), "new4_tflops": round(flop / t2 / 1e6)}), flush=True)
 L.cdll.egm_gemm_dma_mode(1)
