@@ -290,64 +290,87 @@ __global__ __launch_bounds__(128 * WMW, 2) void gemm_nt128_kernel(GemmParams p) 
 // simply numbered in the order the score tile delivers them (key = 4h + (j&3) + 8(j>>2) inside a 16-key step), and V^T fragments
 // are read from LDS with the same numbering (two 8-byte reads).  No score / probability tensor in HBM, no LDS transpose of P.
 template <int MODE>
-__global__ __launch_bounds__(256) void attention_fused_kernel(const bf16_t* __restrict__ qkv, int ld, int L, int H, int D, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attention_fused_kernel(const bf16_t* __restrict__ qkv, int ld, int L, int H, int D, bf16_t* __restrict__ out,
                                                               int ldo, float scale_log2e) {
-    __shared__ __attribute__((aligned(16))) unsigned char Xs[64 * 144];       // [key][64 d] + pad
-    __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * 144];       // [key][64 d] + pad: V as it lies in memory
+    constexpr int NTERM = MODE == 2 ? 2 : 1;                                   // CSA: q q^T and k k^T, both in ONE pass over the keys (V staged once)
+    __shared__ __attribute__((aligned(16))) unsigned char Xs[NTERM][64 * 144]; // [key][64 d] + pad: the key-side matrix of each term
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * 144];        // [key][64 d] + pad: V as it lies in memory
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r31 = lane & 31, hq = lane >> 5;
     const int b = blockIdx.y / H, hh = blockIdx.y - b * H;
     const int qblk0 = blockIdx.x * 128, query = qblk0 + wv * 32 + r31;
     const bf16_t* base = qkv + (long long)b * L * ld + hh * 64;
-    const int nterms = MODE == 2 ? 2 : 1;
     const int Lk = MODE == 1 ? min(L, qblk0 + 128) : L;                        // causal: no key beyond the block's last query
-    f32x16_t otot[2];
+    // term t: scores = X_t(keys) . x_t(query); MODE 2: t = 0 -> (q, q), t = 1 -> (k, k); else (k keys, q query)
+    bf16x8_t fq[NTERM][4];
+    float m[NTERM], l[NTERM];
+    f32x16_t acc[NTERM][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) otot[t][e] = 0.f;
-
-    for (int term = 0; term < nterms; ++term) {
+    for (int term = 0; term < NTERM; ++term) {
         const int qoff = (MODE == 2 && term == 1) ? D : 0;
-        const int koff = MODE == 2 ? (term == 0 ? 0 : D) : D;
-        bf16x8_t fq[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (query < L) v = *reinterpret_cast<const uint4*>(base + (long long)query * ld + qoff + ks * 16 + hq * 8);
-            fq[ks] = __builtin_bit_cast(bf16x8_t, v);
+            fq[term][ks] = __builtin_bit_cast(bf16x8_t, v);
         }
-        float m = -INFINITY, l = 0.f;
-        f32x16_t acc[2];
+        m[term] = -INFINITY; l[term] = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[term][t][e] = 0.f;
+    }
 
-        for (int key0 = 0; key0 < Lk; key0 += 64) {
-            __syncthreads();
+    for (int key0 = 0; key0 < Lk; key0 += 64) {
+        __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {                                      // 64 keys x 8 vectors of X and of V
-                const int i = tid + 256 * j, key = i >> 3, v = i & 7;
-                uint4 xv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-                if (key0 + key < L) {
-                    const bf16_t* row = base + (long long)(key0 + key) * ld;
-                    xv = *reinterpret_cast<const uint4*>(row + koff + v * 8);
-                    vv = *reinterpret_cast<const uint4*>(row + 2 * D + v * 8);
+        for (int j = 0; j < 2; ++j) {                                          // 64 keys x 8 vectors of each X and of V
+            const int i = tid + 256 * j, key = i >> 3, v = i & 7;
+            uint4 xv[NTERM], vv = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int term = 0; term < NTERM; ++term) xv[term] = make_uint4(0, 0, 0, 0);
+            if (key0 + key < L) {
+                const bf16_t* row = base + (long long)(key0 + key) * ld;
+#pragma unroll
+                for (int term = 0; term < NTERM; ++term) {
+                    const int koff = MODE == 2 ? (term == 0 ? 0 : D) : D;
+                    xv[term] = *reinterpret_cast<const uint4*>(row + koff + v * 8);
                 }
-                *reinterpret_cast<uint4*>(Xs + key * 144 + v * 16) = xv;
-                *reinterpret_cast<uint4*>(Vs + key * 144 + v * 16) = vv;
+                vv = *reinterpret_cast<const uint4*>(row + 2 * D + v * 8);
             }
-            __syncthreads();
 #pragma unroll
-            for (int tile = 0; tile < 2; ++tile) {
-                if (key0 + tile * 32 >= Lk) break;
+            for (int term = 0; term < NTERM; ++term) *reinterpret_cast<uint4*>(Xs[term] + key * 144 + v * 16) = xv[term];
+            *reinterpret_cast<uint4*>(Vs + key * 144 + v * 16) = vv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tile = 0; tile < 2; ++tile) {
+            if (key0 + tile * 32 >= Lk) break;
+            // V^T fragments of this 32-key tile by transposing LDS reads (ds_read_b64_tr_b16, the form of GMma<bf16_t>::load_t): a
+            // 16-lane group reads 4 key rows x 16 d and lane t receives the 4 keys of d = t; this lane needs keys 4 hq + {0..3} and
+            // 4 hq + {8..11} of each 16-key step (the k-slot numbering of the probabilities below).  Shared by the terms.  (The first
+            // version transposed V on the way INTO LDS with sixteen 2-byte writes per thread and key block.)
+            bf16x8_t fv[2][2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int gq4 = lane >> 4, t16 = lane & 15;
+                    const unsigned char* va = Vs + (tile * 32 + k2 * 16 + 4 * (gq4 >> 1) + (t16 >> 2)) * 144 + (dt * 32 + (gq4 & 1) * 16 + 4 * (t16 & 3)) * 2;
+                    typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(va));
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(va + 8 * 144));
+                    const s16x8_t a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    fv[dt][k2] = __builtin_bit_cast(bf16x8_t, a);
+                }
+#pragma unroll
+            for (int term = 0; term < NTERM; ++term) {
                 f32x16_t st;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) st[e] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(Xs + (tile * 32 + r31) * 144 + ks * 32 + hq * 16);
-                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fq[ks], st, 0, 0, 0);
+                    const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(Xs[term] + (tile * 32 + r31) * 144 + ks * 32 + hq * 16);
+                    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fq[term][ks], st, 0, 0, 0);
                 }
                 // st[e]: key = key0 + tile*32 + 4 hq + (e&3) + 8 (e>>2), query = this lane's column
                 // The instruction stream of this loop, not its MFMAs (16 of ~700 instructions per key block in the first version), is what
@@ -370,19 +393,19 @@ __global__ __launch_bounds__(256) void attention_fused_kernel(const bf16_t* __re
                     for (int e = 0; e < 16; ++e) { sv[e] = st[e] * scale_log2e; tmax = fmaxf(tmax, sv[e]); }
                 }
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-                const float m_new = fmaxf(m, tmax);
+                const float m_new = fmaxf(m[term], tmax);
                 const float m_use = m_new == -INFINITY ? 0.f : m_new;           // fully masked so far: keep everything at zero
-                const float corr = __builtin_amdgcn_exp2f(m - m_use);
+                const float corr = __builtin_amdgcn_exp2f(m[term] - m_use);
                 float psum = 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { sv[e] = __builtin_amdgcn_exp2f(sv[e] - m_use); psum += sv[e]; }
-                l = l * corr + psum;
-                m = m_new;
+                l[term] = l[term] * corr + psum;
+                m[term] = m_new;
                 if (__any(corr != 1.f)) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[t][e] *= corr;
+                        for (int e = 0; e < 16; ++e) acc[term][t][e] *= corr;
                 }
                 bf16x8_t pk[2];
 #pragma unroll
@@ -397,27 +420,24 @@ __global__ __launch_bounds__(256) void attention_fused_kernel(const bf16_t* __re
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                    for (int k2 = 0; k2 < 2; ++k2) {
-                        // V^T fragment by transposing LDS reads (ds_read_b64_tr_b16, the form of GMma<bf16_t>::load_t): a 16-lane group
-                        // reads 4 key rows x 16 d and lane t receives the 4 keys of d = t; this lane needs keys 4 hq + {0..3} and
-                        // 4 hq + {8..11} of the 16-key step (the k-slot numbering of the probabilities above).  (The first version
-                        // transposed V on the way INTO LDS with sixteen 2-byte writes per thread and key block.)
-                        const int gq4 = lane >> 4, t16 = lane & 15;
-                        const unsigned char* va = Vs + (tile * 32 + k2 * 16 + 4 * (gq4 >> 1) + (t16 >> 2)) * 144 + (dt * 32 + (gq4 & 1) * 16 + 4 * (t16 & 3)) * 2;
-                        typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
-                        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(va));
-                        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr_t)(va + 8 * 144));
-                        const s16x8_t a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), pk[k2], acc[dt], 0, 0, 0);
-                    }
+                    for (int k2 = 0; k2 < 2; ++k2) acc[term][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv[dt][k2], pk[k2], acc[term][dt], 0, 0, 0);
             }
         }
-        const float ltot = l + __shfl_xor(l, 32, 64);
+    }
+    // out = sum over the terms of acc / l (each softmax normalised by its own sum, models/clipseg.py:96-102)
+    f32x16_t otot[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) otot[t][e] = 0.f;
+#pragma unroll
+    for (int term = 0; term < NTERM; ++term) {
+        const float ltot = l[term] + __shfl_xor(l[term], 32, 64);
         const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) otot[t][e] += acc[t][e] * inv;
+            for (int e = 0; e < 16; ++e) otot[t][e] += acc[term][t][e] * inv;
     }
     // out^T layout: column = query (this lane), rows d = dt*32 + (e&3) + 8 (e>>2) + 4 hq  -> 4 consecutive d per register quad
     if (query < L) {
@@ -618,7 +638,7 @@ int launch_gemm(const GemmParams& p, int transB, int batch, hipStream_t st) {
         a.lda = p.lda; a.ldb = p.ldb; a.ldc = p.ldc; a.ldr = p.ldr; a.M = p.M; a.N = p.N; a.K = p.K; a.act = p.act; a.alpha = p.alpha;
         if (egm_gemm_dma_ok(a)) return egm_gemm_dma_launch(a, st);
     }
-    if (sizeof(T) == 2 && transB && p.M >= 128 && p.N >= 96 && p.K % 8 == 0) {          // the large A * B^T products
+    if (sizeof(T) == 2 && transB && p.M >= 128 && p.N >= 48 && p.K % 8 == 0) {          // the large A * B^T products (N >= 48: the 768 -> 64 reduce projections of CLIPSeg at 15 520 rows run 24 synchronous 32-deep chunks in gemm_kernel, 38 us for 24 MB of reading; here 12 prefetched 64-deep chunks on a half-empty 128-wide tile)
         // 128 x 256 tiles (32 MFMAs per wave between barriers) when they still give every CU a few workgroups, else 128 x 128
         // 256 x 128 tiles (8 waves; 1/170 staged byte per FLOP instead of 1/128) when they still give every CU two workgroups
         const long long wg256 = (long long)((p.N + 127) / 128) * ((p.M + 255) / 256) * batch;
