@@ -214,6 +214,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void gemm_dma_kernel(Para
         for (int g = 0; g < 2 * R; ++g) {
             const int i = g >> 1, jp = g & 1;
             if (g + 1 < 2 * R) request(g + 1, rr[(g + 1) & 1], bq[(g + 1) & 1]);
+            if (jp * 2 >= NT) continue;                                // (NT <= 2: one column group per row block)
             const int n = t.n0 + wc * (NT * 32) + jp * 64 + cv * 8;
             const bool nin = jp * 64 + cv * 8 < NT * 32;              // (NT = 3: the second column group is one 32-column block)
             const int mb = t.m0 + wr * (R * 32) + i * 32 + sl;        // + 8 it2
@@ -322,23 +323,31 @@ extern "C" int egm_gemm_dma_mode(int mode) {
     return old;
 }
 
-// 0: not taken; 4: 256 x 256 tiles; 3: 256 x 192 tiles (N a multiple of 192 that 256-wide tiles would cut into less than one tile per CU)
+// 0: not taken; NT = 4: 256 x 256 tiles, 3: 256 x 192, 2: 256 x 128, 1: 256 x 64.
+// The register-staged kernels spend ~2.6 us per 64-deep chunk of a 128 x 128 tile whatever the shape (one chunk of prefetch: the memory
+// latency of every chunk is exposed); a stage of this kernel is ~2 us for 256 x 256 and less for narrower tiles, so it also wins where its
+// tiles fill only a quarter of the chip (the text encoder's N = 512 products: 62 tiles; CLIPSeg's 768 -> 64 reduce projections: 61 tiles
+// of 256 x 64).  The narrow forms (NT < 4) are only offered when no workgroup gets a second tile (their out tiles lie across both buffers).
 static int gemm_dma_nt(const GemmDmaArgs& a) {
     if (!egm_gemm_dma_mode(-1)) return 0;
     if (a.act < 0 || a.act > 2) return 0;
-    if (a.M < 512 || a.N < 192 || a.K < BK || a.K % BK != 0 || a.N % 8 != 0) return 0;
+    if (a.M < 512 || a.N < 48 || a.K < BK || a.K % BK != 0 || a.N % 8 != 0) return 0;
     if (a.lda % 8 || a.ldb % 8 || a.ldc % 8 || (a.R && a.ldr % 8)) return 0;
     if (!egm_aligned16(a.A) || !egm_aligned16(a.B) || !egm_aligned16(a.C) || (a.R && !egm_aligned16(a.R)) || (a.bias && !egm_aligned16(a.bias))) return 0;
     if ((long long)BM * a.lda >= (1LL << 31) || 256LL * a.ldb >= (1LL << 31)) return 0;
     const int tm = egm_cdiv(a.M, BM);
     const long long t4 = (long long)tm * egm_cdiv(a.N, 256);
     if (t4 >= 256) return 4;
+    auto single = [&](int bn) { return egm_cdiv(tm, 8) * egm_cdiv(a.N, bn) <= 32; };      // no workgroup gets a second tile
+    if (a.N <= 64) return (tm >= 48 && single(64)) ? 1 : 0;
+    if (a.N <= 128) return (tm >= 48 && single(128)) ? 2 : 0;
     // less than one 256 x 256 tile per CU (proj / fc2 at N = 768: 183): 192-wide tiles when they give (nearly) every CU exactly one
     const int tn3 = egm_cdiv(a.N, 192);
-    const long long t3 = (a.N % 192 == 0 && egm_cdiv(tm, 8) * tn3 <= 32) ? (long long)tm * tn3 : 0;
+    const long long t3 = (a.N % 192 == 0 && single(192)) ? (long long)tm * tn3 : 0;
     if (t3 >= 192 && t3 > t4) return 3;
-    if (t4 >= 192) return 4;                                           // three quarters of the chip in one round (text fc1: 31 x 8 = 248 tiles)
-    return 0;                                                          // the 128-wide register-staged kernels fill the chip better
+    if (t4 >= 192 || (t4 >= 48 && a.K <= 1024)) return 4;               // a quarter of the chip only pays while the product is short (text proj, K = 512: 29.8 -> 20.5 us;
+                                                                       // text fc2, K = 2048: 57.1 -> 59.5 us)
+    return 0;                                                          // a handful of tiles: the 128-wide register-staged kernels spread them better
 }
 int egm_gemm_dma_ok(const GemmDmaArgs& a) { return gemm_dma_nt(a) != 0; }
 
@@ -373,7 +382,12 @@ int egm_gemm_dma_launch(const GemmDmaArgs& a, hipStream_t st) {
     p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc; p.ldr = a.ldr; p.M = a.M; p.N = a.N; p.K = a.K; p.act = a.act; p.alpha = a.alpha;
     p.tiles_m = egm_cdiv(a.M, BM); p.tiles_n = egm_cdiv(a.N, 64 * nt);
     const int grid = 256;                                             // one workgroup per CU, 32 per XCD; each walks its XCD's tile list
-    if (egm_gemm_dma_mode(-1) == 2)                                    // the 4-wave form (128-row wave tiles)
+    if (egm_gemm_dma_mode(-1) == 2 && nt >= 3)                         // the 4-wave form (128-row wave tiles)
         return nt == 4 ? launch_dma_nt<4, 4>(p, grid, a.R != nullptr, a.act, st) : launch_dma_nt<3, 4>(p, grid, a.R != nullptr, a.act, st);
-    return nt == 4 ? launch_dma_nt<4, 8>(p, grid, a.R != nullptr, a.act, st) : launch_dma_nt<3, 8>(p, grid, a.R != nullptr, a.act, st);
+    switch (nt) {
+        case 4: return launch_dma_nt<4, 8>(p, grid, a.R != nullptr, a.act, st);
+        case 3: return launch_dma_nt<3, 8>(p, grid, a.R != nullptr, a.act, st);
+        case 2: return launch_dma_nt<2, 8>(p, grid, a.R != nullptr, a.act, st);
+        default: return launch_dma_nt<1, 8>(p, grid, a.R != nullptr, a.act, st);
+    }
 }

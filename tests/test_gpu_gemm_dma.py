@@ -23,7 +23,8 @@ def _run(M, N, K, act, with_bias, with_r, lda_pad=0, seed=0):
 # (M, N, K): ViT-B/16 at 32 x 485 tokens (qkv / proj / fc1 / fc2: proj and fc2 take the 192-wide tiles), ragged M, a shape neither tile form
 # takes, one k-chunk, many tiles per workgroup, 192-wide tiles with a ragged last row of tiles
 SHAPES = [(15520, 2304, 768), (15520, 768, 768), (15520, 3072, 768), (15520, 768, 3072), (4099, 1032, 64), (8192, 2048, 128), (33000, 512, 192),
-          (12000, 960, 128), (7936, 2048, 512), (7000, 2048, 128)]       # + the text encoder's fc1 (248 tiles of 256 x 256: one round, not full)
+          (12000, 960, 128), (7936, 2048, 512), (7000, 2048, 128),       # + the text encoder's fc1 (248 tiles of 256 x 256: one round, not full)
+          (15520, 64, 768), (15520, 128, 256), (13000, 96, 128), (7936, 512, 2048)]   # 256 x 64 / 256 x 128 tiles (reduce projections), 62 tiles of 256 x 256
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)

@@ -18,6 +18,7 @@ train = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 L = lib()
 M = 32 * 485
 SHAPES = [("qkv", M, 2304, 768, 0, False), ("proj", M, 768, 768, 0, True), ("fc1", M, 3072, 768, 2, False), ("fc2", M, 768, 3072, 0, True),
+          ("reduce", M, 64, 768, 0, False), ("text_proj", 7936, 512, 512, 0, True), ("text_fc2", 7936, 512, 2048, 0, True),
           ("square", 8192, 8192, 8192, 0, False)]
 for name, M_, N, K, act, with_r in SHAPES:
     g = torch.Generator().manual_seed(N + K)
