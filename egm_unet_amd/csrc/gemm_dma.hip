@@ -345,7 +345,11 @@ static int gemm_dma_nt(const GemmDmaArgs& a) {
     const int tn3 = egm_cdiv(a.N, 192);
     const long long t3 = (a.N % 192 == 0 && single(192)) ? (long long)tm * tn3 : 0;
     if (t3 >= 192 && t3 > t4) return 3;
-    if (t4 >= 192 || (t4 >= 48 && a.K <= 1024)) return 4;               // a quarter of the chip only pays while the product is short (text proj, K = 512: 29.8 -> 20.5 us;
+    if (t4 >= 192) return 4;
+    // a quarter of the chip in 256-wide tiles: 256 x 128 tiles put twice as many CUs to work (text encoder, N = 512: 124 tiles)
+    const long long t2 = single(128) ? (long long)tm * egm_cdiv(a.N, 128) : 0;
+    if (t2 >= 96 && t2 <= 256 && egm_gemm_dma_mode(-1) != 3) return 2;
+    if (t4 >= 48 && a.K <= 1024) return 4;               // a quarter of the chip only pays while the product is short (text proj, K = 512: 29.8 -> 20.5 us;
                                                                        // text fc2, K = 2048: 57.1 -> 59.5 us)
     return 0;                                                          // a handful of tiles: the 128-wide register-staged kernels spread them better
 }
