@@ -337,7 +337,7 @@ static int gemm_dma_nt(const GemmDmaArgs& a) {
     if ((long long)BM * a.lda >= (1LL << 31) || 256LL * a.ldb >= (1LL << 31)) return 0;
     const int tm = egm_cdiv(a.M, BM);
     const long long t4 = (long long)tm * egm_cdiv(a.N, 256);
-    if (t4 >= 256) return 4;
+    if (t4 >= 256 || egm_gemm_dma_mode(-1) == 4) return 4;              // (mode 4: experiments -- 256-wide tiles whatever N)
     auto single = [&](int bn) { return egm_cdiv(tm, 8) * egm_cdiv(a.N, bn) <= 32; };      // no workgroup gets a second tile
     if (a.N <= 64) return (tm >= 48 && single(64)) ? 1 : 0;
     if (a.N <= 128) return (tm >= 48 && single(128)) ? 2 : 0;

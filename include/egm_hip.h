@@ -498,7 +498,8 @@ int egm_gemm(int dtype, const void* A, int lda, const void* B, int ldb, int tran
              long long sR2, egm_stream_t s);
 /* Large bf16 A * B^T products (M >= 512, N >= 256, K a multiple of 64, one batch, >= 128 tiles of 256 x 256) run on the 8-wave LDS-DMA
  * kernel (csrc/gemm_dma.hip), bit-identical to the register-staged one.  mode 1 / 0: on / off, 2: its 4-wave form (128-row wave tiles),
- * -1: query; returns the previous mode (default: env EGM_GEMM_DMA, else 1).  For tests and A/B runs. */
+ * 3: on without the 256 x 128 tile rule, 4: 256-wide tiles whatever N (both for A/B runs, profiles/r04_ab_runs.md), -1: query; returns the
+ * previous mode (default: env EGM_GEMM_DMA, else 1). */
 int egm_gemm_dma_mode(int mode);
 /* P[r][:] (dtype) = softmax(S[r][:L]) (S fp32); causal != 0 keeps columns j <= r % L (text encoder mask,
  * clip/model.py:462-468); accumulate != 0 adds to P (CSA: softmax(q q^T) + softmax(k k^T), models/clipseg.py:96-102).
