@@ -569,6 +569,119 @@ __global__ void mca_bwd_dxo_kernel(const unsigned char* __restrict__ codes, cons
         store8(dxo + p * ldo + cv * 8, o);
     }
 }
+// ---- fused backward tail: (x_out, g, codes) -> dxo in ONE tiled pass (egm_mca_bwd_dudxo) ---------------------------------------------
+// Replaces mca_bwd_du + mca_bwd_dxo.  Those two read their 3 x 3 neighbourhoods straight from global memory: 19 + 36 load instructions
+// per 8-channel output vector (9 x {x_out, g} for du; 9 x {du, g, codes} + 8 two-byte loads of the un-shuffle for dxo) and the du tensor
+// written and read back -- 148 + 88 us at 8 x 256^2 x 64 for 234 MB of operands.  Here a workgroup owns a 16 x 16 pixel tile of a
+// 16-channel chunk: phase A stages x_out and g on the tile + 2-pixel halo and the codes on the tile + 1 halo in LDS (zeros / 0xff outside
+// the image: a zero neighbour adds exactly nothing, a 0xff code matches no window position), phase B computes du on the tile + 1 halo
+// into LDS (rounded to the storage type as the unfused kernel stored it, zero outside the image), phase C the window sums from LDS.
+// Same operand order in every sum as the unfused pair; du never reaches memory.
+constexpr int MB_T = 16, MB_CB = 16, MB_P = MB_T + 4, MB_U = MB_T + 2;
+template <typename T>
+__global__ __launch_bounds__(256) void mca_bwd_fused_kernel(const unsigned char* __restrict__ codes, const T* __restrict__ xo, int ldx,
+                                                            const T* __restrict__ g, int ldg, T* __restrict__ dxo, int ldo, int N, int H, int W, int C,
+                                                            int tiles_x, int tiles_y, int nchunk) {
+    __shared__ __attribute__((aligned(16))) T sxo[MB_P * MB_P * MB_CB];
+    __shared__ __attribute__((aligned(16))) T sg[MB_P * MB_P * MB_CB];
+    __shared__ __attribute__((aligned(16))) T sdu[MB_U * MB_U * MB_CB];
+    __shared__ __attribute__((aligned(16))) unsigned char scd[MB_U * MB_U * MB_CB];
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int chunk = b % nchunk; b /= nchunk;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y; const int n = b / tiles_y;
+    const int y0 = ty * MB_T, x0 = tx * MB_T, c0 = chunk * MB_CB;
+    const int nvec = (C - c0 < MB_CB ? C - c0 : MB_CB) >> 3;       // 1 or 2 channel vectors in this chunk
+    const long long img = (long long)n * H * W;
+    // ---- phase A: x_out, g on the tile + 2 halo; codes on the tile + 1 halo
+    for (int i = tid; i < MB_P * MB_P * 2; i += 256) {
+        const int pix = i >> 1, v = i & 1, py = pix / MB_P, px = pix - py * MB_P;
+        const int gy = y0 + py - 2, gx = x0 + px - 2;
+        uint4 a = make_uint4(0, 0, 0, 0), c = make_uint4(0, 0, 0, 0);
+        if (v < nvec && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const long long p = img + (long long)gy * W + gx;
+            a = *reinterpret_cast<const uint4*>(xo + p * ldx + c0 + v * 8);
+            c = *reinterpret_cast<const uint4*>(g + p * ldg + c0 + v * 8);
+        }
+        *reinterpret_cast<uint4*>(sxo + pix * MB_CB + v * 8) = a;
+        *reinterpret_cast<uint4*>(sg + pix * MB_CB + v * 8) = c;
+    }
+    for (int i = tid; i < MB_U * MB_U * 2; i += 256) {
+        const int pix = i >> 1, v = i & 1, uy = pix / MB_U, ux = pix - uy * MB_U;
+        const int gy = y0 + uy - 1, gx = x0 + ux - 1;
+        uint2 cd = make_uint2(0xffffffffu, 0xffffffffu);
+        if (v < nvec && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            cd = *reinterpret_cast<const uint2*>(codes + (img + (long long)gy * W + gx) * C + c0 + v * 8);
+        *reinterpret_cast<uint2*>(scd + pix * MB_CB + v * 8) = cd;
+    }
+    __syncthreads();
+    // ---- phase B: du = 0.4 (xo - avg3 xo) avg3(g) on the tile + 1 halo (zero outside the image), rounded to T
+    for (int i = tid; i < MB_U * MB_U * 2; i += 256) {
+        const int pix = i >> 1, v = i & 1, uy = pix / MB_U, ux = pix - uy * MB_U;
+        const int gy = y0 + uy - 1, gx = x0 + ux - 1;
+        float o[8];
+        zero8(o);
+        if (v < nvec && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            float c[8], s8[8], sg8[8], t[8];
+            const T* ctr = sxo + ((uy + 1) * MB_P + ux + 1) * MB_CB + v * 8;
+            const T* gtr = sg + ((uy + 1) * MB_P + ux + 1) * MB_CB + v * 8;
+            load8(ctr, c);
+            zero8(s8); zero8(sg8);
+#pragma unroll
+            for (int r = -1; r <= 1; ++r)
+#pragma unroll
+                for (int q = -1; q <= 1; ++q) {
+                    load8(ctr + (r * MB_P + q) * MB_CB, t);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s8[j] += t[j];
+                    load8(gtr + (r * MB_P + q) * MB_CB, t);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sg8[j] += t[j];
+                }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = 0.4f * (c[j] - s8[j] * (1.f / 9.f)) * sg8[j] * (1.f / 9.f);
+        }
+        store8_lds(sdu + pix * MB_CB + v * 8, o);
+    }
+    __syncthreads();
+    // ---- phase C: dxo = 0.51 g + 0.1 unshuffle(g) + du - avg3(du) + 0.2 sum_nbr g_nbr ([argmax_nbr == here] - [argmin_nbr == here])
+    for (int i = tid; i < MB_T * MB_T * 2; i += 256) {
+        const int pix = i >> 1, v = i & 1, ly = pix / MB_T, lx = pix - ly * MB_T;
+        const int gy = y0 + ly, gx = x0 + lx;
+        if (v >= nvec || gy >= H || gx >= W) continue;
+        const long long p = img + (long long)gy * W + gx;
+        float acc[8], sd[8], t[8], gp[8];
+        zero8(acc); zero8(sd);
+        const T* dctr = sdu + ((ly + 1) * MB_U + lx + 1) * MB_CB + v * 8;
+        const T* gctr = sg + ((ly + 2) * MB_P + lx + 2) * MB_CB + v * 8;
+        const unsigned char* cctr = scd + ((ly + 1) * MB_U + lx + 1) * MB_CB + v * 8;
+#pragma unroll
+        for (int r = -1; r <= 1; ++r)
+#pragma unroll
+            for (int q = -1; q <= 1; ++q) {
+                load8(dctr + (r * MB_U + q) * MB_CB, t);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sd[j] += t[j];
+                load8(gctr + (r * MB_P + q) * MB_CB, gp);
+                const uint2 cd = *reinterpret_cast<const uint2*>(cctr + (r * MB_U + q) * MB_CB);
+                const int me = (1 - r) * 3 + (1 - q);               // this pixel's scan index inside the neighbour's window
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned code = ((j < 4 ? cd.x : cd.y) >> ((j & 3) * 8)) & 0xffu;
+                    acc[j] += gp[j] * (((int)(code & 15u) == me ? 1.f : 0.f) - ((int)(code >> 4) == me ? 1.f : 0.f));
+                }
+            }
+        float gc[8], dc[8], o[8];
+        load8(gctr, gc); load8(dctr, dc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gs = to_f32(g[p * ldg + shuffle_dst(c0 + v * 8 + j, C)]);
+            o[j] = 0.51f * gc[j] + 0.1f * gs + dc[j] - sd[j] * (1.f / 9.f) + 0.2f * acc[j];
+        }
+        store8(dxo + p * ldo + c0 + v * 8, o);
+    }
+}
 // dx = dxo*(g_h+g_w+g_c)/3 + sum_axes (A + B*x)
 template <typename T>
 __global__ void mca_bwd_dx_kernel(const T* __restrict__ dxo, int ldd, const T* __restrict__ x, int ldx, const float* __restrict__ gates,
@@ -765,6 +878,22 @@ extern "C" int egm_mca_bwd_dxo(int dtype, const unsigned char* codes, const void
     EGM_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((mca_bwd_dxo_kernel<T>), dim3(EGM_MCA_GRID), dim3(256), 0, (hipStream_t)s, codes, (const T*)g,
                                                  ldg, (const T*)du, ldd, (T*)dxo, ldo, N, H, W, C));
     EGM_CHECK_LAUNCH("mca_bwd_dxo");
+    return EGM_OK;
+}
+/* du and dxo of the MCALayer backward in one tiled pass (bf16): dxo = 0.51 g + 0.1 unshuffle(g) + du - avg3(du) + 0.2 (window arg terms)
+ * with du = 0.4 (xo - avg3 xo) avg3(g) kept in LDS.  Same operand order as egm_mca_bwd_du + egm_mca_bwd_dxo. */
+extern "C" int egm_mca_bwd_dudxo(int dtype, const unsigned char* codes, const void* xo, int ldxo, const void* g, int ldg, void* dxo, int ldo,
+                                 int N, int H, int W, int C, egm_stream_t s) {
+    EGM_REQ_VEC("mca_bwd_dudxo", xo, ldxo, C); EGM_REQ_VEC("mca_bwd_dudxo", g, ldg, C); EGM_REQ_VEC("mca_bwd_dudxo", dxo, ldo, C);
+    EGM_REQ_SHAPE("mca_bwd_dudxo");
+    EGM_REQUIRE(codes && (reinterpret_cast<uintptr_t>(codes) & 7) == 0 && C % 4 == 0, "mca_bwd_dudxo: bad codes buffer");
+    if (dtype != EGM_BF16) EGM_FAIL(EGM_ERR_UNSUPPORTED, "mca_bwd_dudxo: bf16 only (fp32: egm_mca_bwd_du + egm_mca_bwd_dxo)");
+    const int tiles_x = (W + MB_T - 1) / MB_T, tiles_y = (H + MB_T - 1) / MB_T, nchunk = (C + MB_CB - 1) / MB_CB;
+    const long long grid = (long long)N * tiles_x * tiles_y * nchunk;
+    EGM_REQUIRE(grid < (1LL << 31), "mca_bwd_dudxo: grid too large");
+    hipLaunchKernelGGL((mca_bwd_fused_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)s, codes, (const bf16_t*)xo, ldxo,
+                       (const bf16_t*)g, ldg, (bf16_t*)dxo, ldo, N, H, W, C, tiles_x, tiles_y, nchunk);
+    EGM_CHECK_LAUNCH("mca_bwd_dudxo");
     return EGM_OK;
 }
 extern "C" int egm_mca_bwd_dx(int dtype, const void* dxo, int ldd, const void* x, int ldx, const float* gates, const float* coef, void* dx,

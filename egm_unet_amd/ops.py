@@ -1001,6 +1001,15 @@ _FUSE_POOL = os.environ.get("EGM_FUSE_POOL", "1") != "0"
 
 
 _FUSE_MCA_BN = os.environ.get("EGM_FUSE_MCA_BN", "1") != "0"
+_FUSE_MCA_BWD = os.environ.get("EGM_FUSE_MCA_BWD", "1") != "0"
+
+
+def fuse_mca_bwd(enabled=None):
+    """Get / set whether the MCALayer backward computes du and dxo in one tiled launch (bf16; egm_mca_bwd_dudxo)."""
+    global _FUSE_MCA_BWD
+    if enabled is not None:
+        _FUSE_MCA_BWD = bool(enabled)
+    return _FUSE_MCA_BWD
 
 
 def fuse_mca_bn(enabled=None):
@@ -2710,10 +2719,14 @@ class _MCALayer(Function):
         N, H, W, C = x.shape
         L, dt, st, dev = lib(), dtype_code(x.dtype), stream(), x.device
         Lax = H + W + C
-        du = torch.empty_like(xo)
-        L.call("egm_mca_bwd_du", dt, ptr(xo), C, ptr(g), ldg, ptr(du), C, N, H, W, C, st)
         dxo = torch.empty_like(xo)
-        L.call("egm_mca_bwd_dxo", dt, ptr(codes), ptr(g), ldg, ptr(du), C, ptr(dxo), C, N, H, W, C, st)
+        if _FUSE_MCA_BWD and x.dtype == torch.bfloat16:
+            # du and dxo in one tiled pass: the 3 x 3 neighbourhoods come from LDS, du never reaches memory
+            L.call("egm_mca_bwd_dudxo", dt, ptr(codes), ptr(xo), C, ptr(g), ldg, ptr(dxo), C, N, H, W, C, st)
+        else:
+            du = torch.empty_like(xo)
+            L.call("egm_mca_bwd_du", dt, ptr(xo), C, ptr(g), ldg, ptr(du), C, N, H, W, C, st)
+            L.call("egm_mca_bwd_dxo", dt, ptr(codes), ptr(g), ldg, ptr(du), C, ptr(dxo), C, N, H, W, C, st)
         ws = torch.empty(L.query("egm_mca_reduce_workspace", N, H, W, C) // 4 + 4, dtype=torch.float32, device=dev)
         dG = _f32((N, Lax, 2), dev)
         L.call("egm_mca_reduce", dt, 1, ptr(dxo), C, ptr(x), ldx, ptr(dG), ptr(ws), N, H, W, C, st)

@@ -483,6 +483,10 @@ int egm_mca_bwd_du(int dtype, const void* xo, int ld, const void* g, int ldg, vo
                    egm_stream_t s);
 int egm_mca_bwd_dxo(int dtype, const unsigned char* codes, const void* g, int ldg, const void* du, int ldd, void* dxo, int ldo,
                     int N, int H, int W, int C, egm_stream_t s);
+/* egm_mca_bwd_du + egm_mca_bwd_dxo as ONE tiled pass, bf16 only (x_out, g and the codes staged with their halo in LDS, du kept there):
+ * same operand order in every sum as the pair.  Replaces the du / dxo steps of MCALayer's autograd backward (src/EGM-UNet.py:729-772). */
+int egm_mca_bwd_dudxo(int dtype, const unsigned char* codes, const void* xo, int ldxo, const void* g, int ldg, void* dxo, int ldo,
+                      int N, int H, int W, int C, egm_stream_t s);
 int egm_mca_bwd_dx(int dtype, const void* dxo, int ldd, const void* x, int ldx, const float* gates, const float* coef, void* dx,
                    int ldo, int N, int H, int W, int C, int no_spatial, egm_stream_t s);
 

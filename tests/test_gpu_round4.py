@@ -192,3 +192,51 @@ def test_bias_grad_multi_equals_channel_sums_and_refuses_bad_calls():
             L.call("egm_bias_grad_multi", code, ptr(table), 0, n1, n2, stream())
         with pytest.raises(RuntimeError, match="bias_grad_multi"):
             L.call("egm_bias_grad_multi", code, None, len(cases), n1, n2, stream())
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 29, 24), (1, 64, 48, 64), (2, 16, 16, 8), (1, 40, 33, 128), (1, 5, 3, 16)],
+                         ids=["ragged_c24", "c64", "one_tile_c8", "c128", "tiny"])
+def test_mca_backward_tiled_pass_equals_the_two_kernels(shape):
+    """egm_mca_bwd_dudxo (x_out, g, codes staged with their halo in LDS, du kept there) against egm_mca_bwd_du + egm_mca_bwd_dxo on the same
+    operands, bf16: same operand order in every sum, so equal up to a stray last bit from FMA contraction (as the forward's fused tail);
+    ragged tiles, partial 16-channel chunks and images smaller than a tile included."""
+    from egm_unet_amd._lib import lib, ptr, stream
+    N, H, W, C = shape
+    g_ = torch.Generator().manual_seed(sum(shape))
+    xo = torch.randn(N, H, W, C, generator=g_).to(DEV).bfloat16()
+    g = torch.randn(N, H, W, C, generator=g_).to(DEV).bfloat16()
+    lo = torch.randint(0, 9, (N, H, W, C), generator=g_, dtype=torch.int32)
+    hi = torch.randint(0, 9, (N, H, W, C), generator=g_, dtype=torch.int32)
+    codes = (lo | (hi << 4)).to(torch.uint8).to(DEV)
+    L, st = lib(), stream()
+    du = torch.empty_like(xo); want = torch.empty_like(xo); got = torch.full_like(xo, 7.0)
+    L.call("egm_mca_bwd_du", 1, ptr(xo), C, ptr(g), C, ptr(du), C, N, H, W, C, st)
+    L.call("egm_mca_bwd_dxo", 1, ptr(codes), ptr(g), C, ptr(du), C, ptr(want), C, N, H, W, C, st)
+    L.call("egm_mca_bwd_dudxo", 1, ptr(codes), ptr(xo), C, ptr(g), C, ptr(got), C, N, H, W, C, st)
+    torch.cuda.synchronize()
+    diff = (got.float() - want.float()).abs()
+    assert float(diff.max()) <= 1e-2 * (1.0 + float(want.float().abs().max())), float(diff.max())
+    assert float((diff > 0).float().mean()) < 0.02
+    with pytest.raises(RuntimeError, match="bf16 only"):
+        L.call("egm_mca_bwd_dudxo", 0, ptr(codes), ptr(xo.float()), C, ptr(g.float()), C, ptr(got.float()), C, N, H, W, C, st)
+
+
+def test_mca_backward_switch_gives_the_same_model_gradients():
+    """ops.fuse_mca_bwd on / off: every gradient of the bf16 model within bf16 rounding of each other."""
+    from egm_unet_amd import ops
+    default = ops.fuse_mca_bwd()
+    got = {}
+    try:
+        for fused in (False, True):
+            ops.fuse_mca_bwd(fused)
+            m, x, gl = _model_and_batch(torch.bfloat16)
+            m(x)["out"].backward(gl)
+            torch.cuda.synchronize()
+            got[fused] = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    finally:
+        ops.fuse_mca_bwd(default)
+    worst = 0.0
+    for k in got[True]:
+        a, b = got[True][k].float(), got[False][k].float()
+        worst = max(worst, float((a - b).norm() / (b.norm() + 1e-12)))
+    assert worst < 0.05, worst
