@@ -17,14 +17,18 @@ def cast_weight(w: torch.Tensor, dtype):
     """fp32 parameter -> contiguous matrix in the activation dtype (cached on storage + version)."""
     if dtype == torch.float32:
         return w.detach().contiguous()
-    key = (w.data_ptr(), w._version, _cast_generation[0], dtype, tuple(w.shape))
-    hit = _cast_cache.get(id(w))
+    # a view of a parameter (weight.reshape(...), a slice of in_proj_weight) is a new tensor object on every call: the cache entry hangs on
+    # the base tensor + offset + shape, so those hit too (they re-cast every step before: 17 cast launches per CLIPSeg forward)
+    base = w._base if w._base is not None else w
+    slot = (id(base), w.storage_offset(), tuple(w.shape), tuple(w.stride()))
+    key = (w.data_ptr(), base._version, _cast_generation[0], dtype)
+    hit = _cast_cache.get(slot)
     if hit is not None and hit[0] == key:
         return hit[1]
     src = w.detach().contiguous()
     out = torch.empty(src.shape, dtype=dtype, device=w.device)
     lib().call("egm_cast_f32", dtype_code(dtype), ptr(src), ptr(out), src.numel(), stream())
-    _cast_cache[id(w)] = (key, out)
+    _cast_cache[slot] = (key, out)
     return out
 
 

@@ -105,6 +105,13 @@ class CLIPDensePredT(nn.Module):
         mask = (layer | 'all', 'cls_token', seg [B, H, W]): the visual-prompt mask of CLIPDensePredTMasked (models/clipseg.py:222-231):
         seg is sampled (nearest, like nnf.interpolate's default) onto the token grid and multiplies the class token's attention row
         in the selected layers."""
+        q, acts = self._visual_run(x_inp, extract_layers, mask)
+        return q.float(), [a.float().permute(1, 0, 2) for a in acts], []
+
+    @torch.no_grad()
+    def _visual_run(self, x_inp, extract_layers=(), mask=None):
+        """The encoder pass behind visual_forward in the compute dtype, batch-first: (q [B, 512], [activations [B, L, 768]]).  forward() takes
+        these as they are; the reference's fp32 [L, B, 768] copies (4 x 48 MB per call at B = 32) are only made where they are returned."""
         require_gpu()
         dev = self.model.conv1.weight.device
         cls_mask = None
@@ -117,9 +124,7 @@ class CLIPDensePredT(nn.Module):
             iy = (torch.arange(g, device=dev) * seg.shape[1] // g).long()          # nearest source index = floor(dst * in / out)
             ix = (torch.arange(g, device=dev) * seg.shape[2] // g).long()
             cls_mask = (mask_layer, seg[:, iy][:, :, ix].reshape(seg.shape[0], g * g).contiguous())
-        q, acts = self.model.run(x_inp.to(dev), self.compute_dtype, extract_layers=tuple(extract_layers), cls_mask=cls_mask)
-        self._acts_bf = acts                                           # batch-first, compute dtype: consumed by forward()
-        return q.float(), [a.float().permute(1, 0, 2) for a in acts], []
+        return self.model.run(x_inp.to(dev), self.compute_dtype, extract_layers=tuple(extract_layers), cls_mask=cls_mask)
 
     def _encoder_layer(self, blk, a):
         """nn.TransformerEncoderLayer defaults in eval mode: post-norm, ReLU feed-forward, no dropout."""
@@ -163,9 +168,9 @@ class CLIPDensePredT(nn.Module):
         bs = x_inp.shape[0]
         with torch.no_grad():
             cond = self.get_cond_vec(conditional, bs)
-            visual_q, activations, _ = self.visual_forward(x_inp, extract_layers=[0] + list(self.extract_layers))
+            q_raw, acts_all = self._visual_run(x_inp, extract_layers=[0] + list(self.extract_layers))
         dt, code = self.compute_dtype, dtype_code(self.compute_dtype)
-        acts = self._acts_bf[1:]
+        acts = acts_all[1:]
         acts = acts[::-1] if not self.rev_activations else acts
         condT = torch.empty(cond.shape, dtype=dt, device=dev)
         lib().call("egm_cast_f32", code, ptr(cond.float().contiguous()), ptr(condT), cond.numel(), stream())
@@ -178,7 +183,7 @@ class CLIPDensePredT(nn.Module):
             a = self._encoder_layer_train(blk, a)
         out = T.TransConvFn.apply(a, self.trans_conv.weight, self.trans_conv.bias)
         if return_features:
-            return out, visual_q, cond, activations
+            return out, q_raw.float(), cond, [t.float().permute(1, 0, 2) for t in acts_all]
         return out,
 
     def _forward_eval(self, inp_image, conditional=None, return_features=False):
@@ -186,9 +191,9 @@ class CLIPDensePredT(nn.Module):
         x_inp = inp_image.to(dev)
         bs = x_inp.shape[0]
         cond = self.get_cond_vec(conditional, bs)
-        visual_q, activations, _ = self.visual_forward(x_inp, extract_layers=[0] + list(self.extract_layers))
+        q_raw, acts_all = self._visual_run(x_inp, extract_layers=[0] + list(self.extract_layers))
         dt, code, L_ = self.compute_dtype, dtype_code(self.compute_dtype), lib()
-        acts = self._acts_bf[1:]
+        acts = acts_all[1:]
         acts = acts[::-1] if not self.rev_activations else acts
         condT = torch.empty(cond.shape, dtype=dt, device=dev)
         L_.call("egm_cast_f32", code, ptr(cond.float().contiguous()), ptr(condT), cond.numel(), stream())
@@ -207,7 +212,7 @@ class CLIPDensePredT(nn.Module):
         out = torch.empty((bs, 1, g * P, g * P), dtype=torch.float32, device=dev)
         L_.call("egm_pixel_shuffle", code, ptr(y), P * P, 1, Ltot, ptr(self.trans_conv.bias.detach().float()), ptr(out), bs, g, P, stream())
         if return_features:
-            return out, visual_q, cond, activations
+            return out, q_raw.float(), cond, [t.float().permute(1, 0, 2) for t in acts_all]
         return out,
 
 
