@@ -4,6 +4,7 @@
 // channel-contiguous so a wave reads whole pixels; reductions are two-stage with plain stores (deterministic).
 #include "common.h"
 #include "bn_elem.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -128,6 +129,11 @@ __device__ __forceinline__ void bn_finalize_body(const float* __restrict__ st, i
         }
     }
 }
+#ifdef EGM_DIAG_EXTRA_LAUNCHES
+__global__ __launch_bounds__(1024) void diag_tiny_kernel(const float* __restrict__ st, float* __restrict__ scale) {
+    if (st[0] == 12345.678f && threadIdx.x == 2000) scale[0] = 0.f;       // reads one line, writes nothing
+}
+#endif
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ st, int ntiles, double count,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                            float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
@@ -468,6 +474,16 @@ extern "C" int egm_bn_finalize(const float* stats, int ntiles, long long count, 
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)s, stats, ntiles, (double)count, gamma, beta,
                        eps, momentum, running_mean, running_var, scale, shift, save_mean, save_rstd, C, C_real);
     EGM_CHECK_LAUNCH("bn_finalize");
+#ifdef EGM_DIAG_EXTRA_LAUNCHES
+    // diagnostic build (profiles/r04_ab_runs.md): what ONE more tiny dependent launch costs inside the captured step -- k extra kernels of
+    // the finalize kernel's geometry that only read their arguments, behind each of the 30 egm_bn_finalize calls of a step
+    {
+        static int extra = -1;
+        if (extra < 0) extra = getenv("EGM_EXTRA_LAUNCHES") ? atoi(getenv("EGM_EXTRA_LAUNCHES")) : 0;
+        for (int i = 0; i < extra; ++i)
+            hipLaunchKernelGGL(diag_tiny_kernel, dim3((C + 7) / 8), dim3(1024), 0, (hipStream_t)s, stats, scale);
+    }
+#endif
     return EGM_OK;
 }
 
