@@ -22,11 +22,16 @@ __device__ __forceinline__ float sigm(float v) { return 1.f / (1.f + expf(-v)); 
     const int ncv = C >> 3;                                                                            \
     const long long total = (total_expr);                                                              \
     for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+// the same with an XCD-contiguous block order (common.h xcd_contiguous_item): for kernels that read a pixel's neighbours
+#define PIX_LOOP_XCD(total_expr)                                                                       \
+    const int ncv = C >> 3;                                                                            \
+    const long long total = (total_expr);                                                              \
+    for (long long i = xcd_contiguous_item(blockIdx.x, gridDim.x) * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
 
 // ---- out = x - avgpool3x3(x)  (zero pad, divisor 9: count_include_pad=True); self-adjoint ------------
 template <typename T>
 __global__ void highpass3_kernel(const T* __restrict__ x, int ldx, T* __restrict__ out, int ldo, int N, int H, int W, int C) {
-    PIX_LOOP((long long)N * H * W * ncv) {
+    PIX_LOOP_XCD((long long)N * H * W * ncv) {
         long long p; int cv; egm_divmod(i, ncv, p, cv);
         int xx, yy; egm_pix_yx(p, H, W, yy, xx);
         float s[8], c[8], v[8];

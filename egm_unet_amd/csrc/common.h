@@ -188,6 +188,17 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
          else if ((dtype) == EGM_BF16) { using T = bf16_t; __VA_ARGS__; } \
          else EGM_FAIL(EGM_ERR_ARG, "unknown dtype %d", (int)(dtype)); } while (0)
 
+// Workgroups b, b + 8, b + 16, ... of a launch share an XCD (round-robin dispatch) and its L2.  The tiled MCALayer kernels (mca.hip) cut a pixel's
+// channels into chunks, so the chunks of one tile read different 32-/64-byte pieces of the SAME 128-byte lines: with the chunk index
+// running fastest in blockIdx they landed on different XCDs and every L2 fetched the whole line again (mca_bwd_fused at 8 x 256^2 x 64:
+// 475 MB fetched for 167 MB of operands).  This map gives each XCD a contiguous run of (tile, chunk) items instead: the chunks of a tile and
+// the tiles next to it (their halos) meet in one L2.  Bijective for any grid size (MI355X_MICROARCH.md, "XCD swizzle must be bijective").
+__device__ __forceinline__ int xcd_contiguous_item(int b, int G) {
+    const int q = G >> 3, r = G & 7, xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+// (Also for the grid-stride 3 x 3 stencil kernels: with it an XCD sweeps a contiguous band of image rows per pass, so the rows above and
+// below a pixel are in the same L2 except at the band edges.)
 // Multi-tensor launches: block b -> table entry.  Every entry carries chunk0 = the index of its first block (exclusive prefix sum of
 // the per-entry chunk counts, written by the host); the lookup is a binary search every lane runs on uniform values (scalar loads).
 // (The first version let lane 0 scan the table and recompute the chunk counts: with ~550 entries and a 64-bit division per entry

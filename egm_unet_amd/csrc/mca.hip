@@ -330,15 +330,6 @@ __global__ void add_avg3_kernel(const T* __restrict__ a, int lda, const T* __res
         store8(out + p * ldo + cv * 8, c);
     }
 }
-// Workgroups b, b + 8, b + 16, ... of a launch share an XCD (round-robin dispatch) and its L2.  The tiled kernels below cut a pixel's
-// channels into chunks, so the chunks of one tile read different 32-/64-byte pieces of the SAME 128-byte lines: with the chunk index
-// running fastest in blockIdx they landed on different XCDs and every L2 fetched the whole line again (mca_bwd_fused at 8 x 256^2 x 64:
-// 475 MB fetched for 167 MB of operands).  This map gives each XCD a contiguous run of (tile, chunk) items instead: the chunks of a tile and
-// the tiles next to it (their halos) meet in one L2.  Bijective for any grid size (MI355X_MICROARCH.md, "XCD swizzle must be bijective").
-__device__ __forceinline__ int xcd_contiguous_item(int b, int G) {
-    const int q = G >> 3, r = G & 7, xcd = b & 7, idx = b >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
 // ---- fused forward tail: x, gates -> x_out (optional) / out / codes in ONE pass --------------------------------------------------
 // Replaces mca_xout + mca_stencil1 + add_avg3 (9.5 tensor passes, 4.5 of them writes, which cost about twice a read on this part) by
 // x read once (+ a 2-pixel halo that comes out of L2) and out / codes / x_out written once.  Measured at 8x256x256x64 bf16: 166 us

@@ -494,7 +494,7 @@ __global__ void sum4_hp_kernel(const T* __restrict__ a, int lda, const T* __rest
                                const T* __restrict__ d, int ldd, T* __restrict__ out, int ldo, int N, int H, int W, int C) {
     const int ncv = C >> 3;
     const long long total = (long long)N * H * W * ncv;
-    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    for (long long i = xcd_contiguous_item(blockIdx.x, gridDim.x) * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {   // (3 x 3 stencil: common.h)
         long long p; int cv; egm_divmod(i, ncv, p, cv);
         int xx, yy; egm_pix_yx(p, H, W, yy, xx);
         float v[8], u[8], s8[8];
