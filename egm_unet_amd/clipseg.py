@@ -82,10 +82,11 @@ class CLIPDensePredT(nn.Module):
     def compute_conditional(self, conditional):
         dev = next(self.parameters()).device
         if type(conditional) in {list, tuple}:
-            return self.clip_model.encode_text(tokenize(list(conditional), context_length=248, truncate=True).to(dev))
+            # (the token tensor stays on the host: encode_text prepares ids and EOT positions there -- no cast / argmax kernels on the device)
+            return self.clip_model.encode_text(tokenize(list(conditional), context_length=248, truncate=True))
         if conditional in self.precomputed_prompts:
             return self.precomputed_prompts[conditional].float().to(dev)
-        return self.clip_model.encode_text(tokenize([conditional], context_length=248, truncate=True).to(dev))[0]
+        return self.clip_model.encode_text(tokenize([conditional], context_length=248, truncate=True))[0]
 
     def get_cond_vec(self, conditional, batch_size):
         if conditional is not None and type(conditional) == str:
