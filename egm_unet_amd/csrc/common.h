@@ -62,8 +62,17 @@ __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
     float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
+#ifndef EGM_LOAD_MODE
+#define EGM_LOAD_MODE 0            // 2: non-temporal 16-byte loads in the bf16 streaming kernels (A/B builds, profiles/r04_ab_runs.md)
+#endif
 __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+#if EGM_LOAD_MODE == 2
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+    const u32x4_ t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_*>(p));
+    uint4 a; a.x = t.x; a.y = t.y; a.z = t.z; a.w = t.w;
+#else
     uint4 a = *reinterpret_cast<const uint4*>(p);
+#endif
     v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
     v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
     v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
