@@ -24,6 +24,29 @@ def _transpose(x2, rows, cols, ld=None, batch=1, sbatch=0):
     return out, rp
 
 
+def _wgrad_gemm(A, lda, B, ldb, transB, dw, M, N, rows, dt):
+    """dw [M][N] fp32 = A [M][rows] @ (B^T if transB else B): the weight-gradient products of the decoder, whose reduction dimension is
+    the token count (B x L = 31 040 rows at batch 64) while M x N is a weight matrix of 64 .. 2 048 rows -- as ONE product that is a
+    dozen workgroups walking ~970 32-deep chunks each (529 us for 64 x 768: 13 such launches were 22 % of the training step).  Here
+    the rows are cut into S slices that run as a batch (S x more workgroups), fp32 partials, summed in slice order by the slab reduction
+    of the conv weight gradients (egm_wgrad_reduce): deterministic.  Falls back to the single product when the slices would not line up
+    with 16-byte rows or the product is already wide enough."""
+    wgs = ((M + 127) // 128) * ((N + 63) // 64)
+    S = 0
+    if rows >= 8192 and wgs < 128 and N % 8 == 0:
+        for cand in (64, 48, 40, 32, 24, 20, 16, 12, 10, 8, 6, 5, 4):
+            if rows % cand == 0 and (rows // cand) % 8 == 0 and rows // cand >= 256:
+                S = cand
+                break
+    if S == 0:
+        O.gemm(A, lda, B, ldb, transB, dw, N, M, N, rows, dt, c_f32=True)
+        return
+    ks = rows // S
+    part = torch.empty((S, M, N), dtype=torch.float32, device=dw.device)
+    O.gemm(A, lda, B, ldb, transB, part, N, M, N, ks, dt, c_f32=True, nb1=S, nb2=1, sA=(ks, 0), sB=(ks if transB else ks * ldb, 0), sC=(M * N, 0))
+    lib().call("egm_wgrad_reduce", ptr(part), ptr(dw), S, 1, M, N, M, N, 1, 0, stream())
+
+
 def _colsum(g2):
     """fp32 column sums of [M, N] (N % 8 == 0) via the channel-sum kernels."""
     return base_ops._channel_sum(g2.reshape(1, 1, g2.shape[0], g2.shape[1]))[0]
@@ -60,7 +83,10 @@ class LinearFn(Function):
         if ctx.needs_input_grad[1]:
             (gT, mp), (xT, _) = _transpose(g2, M, N), _transpose(x2, M, K)
             dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
-            O.gemm(gT, mp, xT, mp, True, dw, K, N, K, M, dt, c_f32=True)                            # dW = g^T @ x
+            if mp == M:
+                _wgrad_gemm(gT, mp, xT, mp, True, dw, N, K, M, dt)                                   # dW = g^T @ x (split over the rows)
+            else:
+                O.gemm(gT, mp, xT, mp, True, dw, K, N, K, M, dt, c_f32=True)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(g2)[:N]
         return dx, dw, db, None, (gy if ctx.has_res else None)
@@ -243,7 +269,10 @@ class TransConvFn(Function):
         O.gemm(dy, P * P, O.cast_weight(weight.reshape(rd, P * P), dt), P * P, True, da, rd, B * Ltot, rd, P * P, dt)      # da = dy @ W^T
         aT, mp = _transpose(a.reshape(-1, rd), B * Ltot, rd)
         dw = torch.empty((rd, P * P), dtype=torch.float32, device=dev)
-        O.gemm(aT, mp, dy, P * P, False, dw, P * P, rd, P * P, B * Ltot, dt, c_f32=True)                                    # dW = a^T @ dy
+        if mp == B * Ltot:
+            _wgrad_gemm(aT, mp, dy, P * P, False, dw, rd, P * P, B * Ltot, dt)                                              # dW = a^T @ dy
+        else:
+            O.gemm(aT, mp, dy, P * P, False, dw, P * P, rd, P * P, B * Ltot, dt, c_f32=True)
         db = torch.empty(1, dtype=torch.float32, device=dev)
         scratch = torch.empty(1024, dtype=torch.float32, device=dev)
         lib().call("egm_sum_f32", ptr(gout), gout.numel(), 1.0, ptr(scratch), ptr(db), stream())
