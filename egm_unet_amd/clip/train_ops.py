@@ -24,6 +24,10 @@ def _transpose(x2, rows, cols, ld=None, batch=1, sbatch=0):
     return out, rp
 
 
+import os
+_WGRAD_AS_CONV = os.environ.get("EGM_CLIP_WGRAD_CONV", "1") != "0"
+
+
 def _wgrad_gemm(A, lda, B, ldb, transB, dw, M, N, rows, dt):
     """dw [M][N] fp32 = A [M][rows] @ (B^T if transB else B): the weight-gradient products of the decoder, whose reduction dimension is
     the token count (B x L = 31 040 rows at batch 64) while M x N is a weight matrix of 64 .. 2 048 rows -- as ONE product that is a
@@ -80,7 +84,15 @@ class LinearFn(Function):
             dx = torch.empty((M, K), dtype=dt, device=x.device)
             O.gemm(g2, N, O.cast_weight(weight, dt), K, False, dx, K, M, K, N, dt)                 # dx = g @ W
             dx = dx.reshape(x.shape)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and _WGRAD_AS_CONV and N % 8 == 0 and K % 8 == 0 and M >= 4096:
+            # dW = g^T x is the weight gradient of a 1x1 convolution over the tokens (x = NHWC "pixels" x K, g = pixels x N): the conv
+            # weight-gradient kernel reads both operands as they lie (transposing LDS reads, K = pixels split into slabs summed in fixed
+            # order) -- no transposed copies of g and x (two 35 us transposes + a split product per layer before)
+            L = lib()
+            dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+            ws = torch.empty(L.query("egm_conv_wgrad_workspace", 1, 1, M, K, N, 1, 1) // 4 + 4, dtype=torch.float32, device=x.device)
+            L.call("egm_conv_wgrad", dtype_code(dt), ptr(x2), K, ptr(g2), N, ptr(dw), ptr(ws), 1, 1, M, K, N, K, N, 1, 1, 1, 1, 0, stream())
+        elif ctx.needs_input_grad[1]:
             (gT, mp), (xT, _) = _transpose(g2, M, N), _transpose(x2, M, K)
             dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
             if mp == M:

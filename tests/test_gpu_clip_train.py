@@ -238,3 +238,29 @@ def test_attention_dropout_gradients_match_torch_with_same_mask():
     (P @ v).transpose(1, 2).reshape(B, L, D).backward(gout)
     assert rel(out.detach(), (P @ v).transpose(1, 2).reshape(B, L, D).detach()) < 2e-5
     assert rel(xq.grad, qr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 64, 768), (9700, 2048, 64), (31040, 64, 64)])
+def test_linear_weight_gradient_routes_agree(M, N, K):
+    """dW = g^T x of clip/train_ops.LinearFn at decoder-training sizes by its three routes -- the conv weight-gradient kernel over the tokens
+    (default), the row-split batched product, the single product -- against a float64 product of the same bf16 operands."""
+    import egm_unet_amd.clip.train_ops as T
+    g_ = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g_) * 0.5).to(DEV).bfloat16()
+    w = (torch.randn(N, K, generator=g_) / K ** 0.5).to(DEV).requires_grad_(True)
+    gy = (torch.randn(M, N, generator=g_) * 0.1).to(DEV).bfloat16()
+    want = gy.double().T @ x.double()
+    got = {}
+    default = T._WGRAD_AS_CONV
+    try:
+        for route in (True, False):
+            T._WGRAD_AS_CONV = route
+            w.grad = None
+            T.linear(x, w).backward(gy)
+            torch.cuda.synchronize()
+            got[route] = w.grad.double().clone()
+    finally:
+        T._WGRAD_AS_CONV = default
+    scale = float(want.abs().max())
+    for route, gw in got.items():
+        assert float((gw - want).abs().max()) <= 2e-3 * scale, (route, float((gw - want).abs().max()), scale)
